@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""Generate golden fixtures by running the REFERENCE classes (build container only).
+
+Run:  python tests/golden/make_goldens.py            (needs /root/reference)
+
+What it does
+------------
+* imports the reference's own nets / learners from ``/root/reference``
+  (``src.models.core_models.coop``) -- nothing of the reference is copied;
+* bridges transformers-4.4x -> 5.x API drift with a small in-memory shim
+  (SURVEY.md §8c): the two mask helpers the reference imports, and the
+  ``(hidden, attention_mask, causal_attention_mask, output_attentions=)``
+  calling convention of ``CLIPSegEncoderLayer`` / ``CLIPSegDecoderLayer``;
+* replaces ``from_pretrained`` (no network) by a local constructor that loads the
+  seeded random weights of ``tunevlseg_amd.weights.init_clipseg_state_dict``;
+* runs forward + backward in strict fp32 on CPU and writes ``tests/golden/*.npz``
+  holding inputs, trainable parameters, logits, loss and parameter gradients.
+
+The fixtures are data only.  Backbone weights are NOT stored; they are re-drawn
+from ``(config preset, seed)`` and guarded by a checksum stored in the fixture.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+from functools import partial
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+REFERENCE = Path(os.environ.get("TVL_REFERENCE", "/root/reference"))
+sys.path.insert(0, str(REFERENCE))
+
+from tunevlseg_amd.config import CLIPSegConfig  # noqa: E402
+from tunevlseg_amd.weights import init_clipseg_state_dict  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+
+# ----------------------------------------------------------------------------
+# shim: transformers 5.x  <->  reference written for 4.4x
+# ----------------------------------------------------------------------------
+def install_shim():
+    from transformers.models.clipseg import modeling_clipseg as M
+
+    def _create_4d_causal_attention_mask(shape, dtype, device=None):
+        B, T = shape
+        m = torch.full((T, T), torch.finfo(dtype).min, dtype=dtype, device=device).triu(1)
+        return m[None, None].expand(B, 1, T, T)
+
+    def _prepare_4d_attention_mask(mask, dtype, tgt_len=None):
+        B, S = mask.shape
+        T = tgt_len or S
+        inv = 1.0 - mask[:, None, None, :].to(dtype).expand(B, 1, T, S)
+        return inv.masked_fill(inv.bool(), torch.finfo(dtype).min)
+
+    M._create_4d_causal_attention_mask = _create_4d_causal_attention_mask
+    M._prepare_4d_attention_mask = _prepare_4d_attention_mask
+
+    def wrap(cls):
+        orig = cls.forward
+
+        def forward(self, hidden_states, attention_mask=None, *args, **kwargs):
+            ref_style = len(args) >= 1 or "causal_attention_mask" in kwargs
+            if not ref_style:
+                return orig(self, hidden_states, attention_mask, **kwargs)
+            causal = args[0] if args else kwargs.pop("causal_attention_mask", None)
+            kwargs.pop("output_attentions", None)
+            mask = attention_mask
+            if causal is not None:
+                mask = causal if mask is None else (mask + causal).clamp(min=torch.finfo(hidden_states.dtype).min)
+            return (orig(self, hidden_states, mask),)
+
+        cls.forward = forward
+
+    wrap(M.CLIPSegEncoderLayer)
+    wrap(M.CLIPSegDecoderLayer)
+    return M
+
+
+def hf_model_from_state(cfg: CLIPSegConfig, sd):
+    from transformers import CLIPSegConfig as HFConfig
+    from transformers import CLIPSegForImageSegmentation
+
+    d = cfg.to_dict()
+    hf_cfg = HFConfig(
+        text_config={k: v for k, v in d["text_config"].items() if not k.startswith(("output_", "use_return"))},
+        vision_config={k: v for k, v in d["vision_config"].items() if not k.startswith(("output_", "use_return"))},
+        projection_dim=cfg.projection_dim,
+        extract_layers=list(cfg.extract_layers),
+        reduce_dim=cfg.reduce_dim,
+        decoder_num_attention_heads=cfg.decoder_num_attention_heads,
+        decoder_intermediate_size=cfg.decoder_intermediate_size,
+        conditional_layer=cfg.conditional_layer,
+    )
+    hf_cfg._attn_implementation = "eager"
+    hf_cfg.text_config._attn_implementation = "eager"
+    hf_cfg.vision_config._attn_implementation = "eager"
+    model = CLIPSegForImageSegmentation(hf_cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if "position_ids" not in m]
+    assert not missing and not unexpected, (missing, unexpected)
+    for c in (model.config, model.config.text_config, model.config.vision_config):
+        if not hasattr(c, "use_return_dict"):
+            try:
+                c.use_return_dict = True
+            except Exception:
+                pass
+    return model.eval()
+
+
+class StubTokenizer:
+    """The learner only reads ``.input_ids`` (coop_context_learner.py:71-77)."""
+
+    def __init__(self, ids):
+        self.ids = ids
+
+    def __call__(self, text, **kw):
+        class R:
+            pass
+
+        r = R()
+        n = 1 if isinstance(text, str) else len(text)
+        r.input_ids = torch.tensor([self.ids] * n, dtype=torch.long)
+        return r
+
+
+def state_checksum(sd) -> float:
+    return float(sum(v.double().abs().sum() for v in sd.values()))
+
+
+# ----------------------------------------------------------------------------
+def synth_inputs(cfg: CLIPSegConfig, B: int, H: int, L: int, seed: int, pad: bool = True):
+    """img N(0,1); ids rows padded to L; mask = U(0,1) > 0.7."""
+    g = torch.Generator().manual_seed(seed)
+    t = cfg.text_config
+    pix = torch.randn(B, 3, H, H, generator=g)
+    ids = torch.full((B, L), t.pad_token_id, dtype=torch.long)
+    am = torch.zeros(B, L, dtype=torch.long)
+    eos = 49407 if t.vocab_size > 49407 else t.vocab_size - 1
+    if t.eos_token_id != 2:
+        eos = t.eos_token_id
+    for b in range(B):
+        n_words = (L - 2) if not pad else max(1, L - 2 - (b % 3) - (1 if B == 1 else 0))
+        words = torch.randint(2, min(t.vocab_size - 2, 40000), (n_words,), generator=g)
+        if t.eos_token_id != 2:
+            words = words.masked_fill(words == t.eos_token_id, 3)
+        row = [t.bos_token_id, *words.tolist(), eos]
+        ids[b, : len(row)] = torch.tensor(row)
+        am[b, : len(row)] = 1
+    mask = (torch.rand(B, 1, H, H, generator=g) > 0.7).float()
+    return pix, ids, am, mask
+
+
+def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, learner_kw: dict, net_kw: dict,
+             B: int, H: int, L: int, iseed: int, M):
+    from src.models.components.hf_clipseg_wrapper import HFCLIPSegWrapper
+    from src.models.core_models import coop as R
+    from src.models.core_models.coop import context_learner as CL
+
+    sys.path.insert(0, str(ROOT))
+    from oracle.clipseg_oracle import dice_ce_loss
+
+    cfg = CLIPSegConfig.tiny(eos_token_id=eos) if preset == "tiny" else CLIPSegConfig.rd64(eos_token_id=eos)
+    sd = init_clipseg_state_dict(cfg, wseed)
+    HFCLIPSegWrapper.get_pretrained_model = staticmethod(lambda *a, **k: hf_model_from_state(cfg, sd))
+
+    net_cls = {"vpt": R.VPTCLIPSeg, "coop": R.COOPCLIPSeg, "cocoop": R.COOPCLIPSeg, "maple": R.MapleCLIPSeg}[net_kind]
+    learner_cls = {"vpt": CL.VPTContextLearner, "coop": CL.CoOpContextLearner,
+                   "cocoop": CL.CoCoOpContextLearner, "maple": CL.MapleContextLearner}[net_kind]
+    lkw = dict(learner_kw)
+    if lkw.get("context_initializer") is not None:
+        lkw["tokenizer"] = StubTokenizer(lkw.pop("_init_ids"))
+    torch.manual_seed(1000 + iseed)
+    net = net_cls(context_learner=partial(learner_cls, **lkw),
+                  model_cfg={"pretrained_model_name_or_path": None, "freeze_encoder": False, "freeze_decoder": False},
+                  **net_kw)
+    torch.set_float32_matmul_precision("highest")  # reference sets "medium" on import; goldens are strict fp32
+    # give every trainable tensor an O(1)-visible, seeded value (biases too)
+    g = torch.Generator().manual_seed(2000 + iseed)
+    params = {k: p for k, p in net.named_parameters() if p.requires_grad}
+    with torch.no_grad():
+        for k, p in params.items():
+            if k.endswith("context_vectors") and lkw.get("context_initializer") is None:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            elif k == "residual_ratio":
+                pass
+            elif p.dim() == 1 and "projection_layers" in k and not k.endswith(".bias"):
+                p.copy_(1 + 0.05 * torch.randn(p.shape, generator=g))
+            elif k.endswith(".bias"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+
+    pix, ids, am, mask = synth_inputs(cfg, B, H, L, iseed)
+    logits = net(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix)
+    loss = dice_ce_loss(logits, mask)
+    loss.backward()
+
+    arrays = {"in.pixel_values": pix.numpy(), "in.input_ids": ids.numpy(), "in.attention_mask": am.numpy(),
+              "in.mask": mask.numpy(), "out.logits": logits.detach().numpy(), "out.loss": loss.detach().numpy()}
+    grads_none = []
+    for k, p in params.items():
+        arrays["param." + k] = p.detach().numpy()
+        if p.grad is None:
+            grads_none.append(k)
+        else:
+            arrays["grad." + k] = p.grad.numpy()
+    meta = {"name": name, "preset": preset, "eos_token_id": eos, "weight_seed": wseed, "net": net_kind,
+            "learner_kw": {k: v for k, v in learner_kw.items()}, "net_kw": net_kw, "B": B, "H": H, "L": L,
+            "input_seed": iseed, "weights_checksum": state_checksum(sd), "grads_none": grads_none,
+            "torch": torch.__version__}
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / f"{name}.npz", **arrays)
+    print(f"{name}: logits mean {logits.mean():+.4f} std {logits.std():.4f} |max| {logits.abs().max():.3f} "
+          f"pos-frac {(logits > 0).float().mean():.3f} loss {loss.item():.6f} "
+          f"grads {[(k, float(p.grad.abs().max())) for k, p in params.items() if p.grad is not None][:3]} none={grads_none}")
+
+
+def main():
+    M = install_shim()
+    T = dict(preset="tiny", B=2, H=64, L=6, M=M)
+    base_new = dict(use_new_last_layer=True, new_last_layer_kernel_size=5, residual_ratio=0.5)
+    base_old = dict(use_new_last_layer=False)
+    # --- tiny: VPT ------------------------------------------------------------
+    run_case("tiny_vpt_n4_d1", eos=2, wseed=11, net_kind="vpt", iseed=1,
+             learner_kw=dict(prompt_depth=1, num_context=4, vector_std=0.02), net_kw=base_old, **T)
+    run_case("tiny_vpt_n1_d3_newlast", eos=2, wseed=11, net_kind="vpt", iseed=2,
+             learner_kw=dict(prompt_depth=3, num_context=1, vector_std=0.02), net_kw=base_new, **T)
+    run_case("tiny_vpt_n10_d2_eos", eos=63, wseed=12, net_kind="vpt", iseed=3,
+             learner_kw=dict(prompt_depth=2, num_context=10, vector_std=0.02), net_kw=base_old, **T)
+    # --- tiny: CoOp / CoCoOp --------------------------------------------------
+    run_case("tiny_coop_n4_d1", eos=2, wseed=11, net_kind="coop", iseed=4,
+             learner_kw=dict(prompt_depth=1, num_context=4, vector_std=0.02), net_kw=base_old, **T)
+    run_case("tiny_coop_init_d3_eos", eos=63, wseed=12, net_kind="coop", iseed=5,
+             learner_kw=dict(prompt_depth=3, num_context=4, context_initializer="a photo of a", _init_ids=[5, 9, 7, 5],
+                             vector_std=0.02), net_kw=base_old, **T)
+    run_case("tiny_coop_trunc_n12", eos=2, wseed=11, net_kind="coop", iseed=6,
+             learner_kw=dict(prompt_depth=1, num_context=12, vector_std=0.02), net_kw=base_old, **T)
+    run_case("tiny_cocoop_d2_i8_norm", eos=2, wseed=11, net_kind="cocoop", iseed=7,
+             learner_kw=dict(prompt_depth=2, num_context=4, vector_std=0.02, use_unified_projection=False,
+                             intermediate_dim=8, use_proj_norm=True, use_lora_proj=False, norm_image_features=True),
+             net_kw=base_old, **T)
+    run_case("tiny_cocoop_d3_unified_lora", eos=2, wseed=11, net_kind="cocoop", iseed=8,
+             learner_kw=dict(prompt_depth=3, num_context=2, vector_std=0.02, use_unified_projection=True,
+                             intermediate_dim=8, use_proj_norm=False, use_lora_proj=True, norm_image_features=False),
+             net_kw=base_old, **T)
+    # --- tiny: MaPLe ----------------------------------------------------------
+    run_case("tiny_maple_d3_n2_newlast", eos=2, wseed=11, net_kind="maple", iseed=9,
+             learner_kw=dict(prompt_depth=3, num_context=2, vector_std=0.02, use_unified_projection=False,
+                             intermediate_dim=8, use_proj_norm=True, use_lora_proj=False), net_kw=base_new, **T)
+    run_case("tiny_maple_d1_init", eos=63, wseed=12, net_kind="maple", iseed=10,
+             learner_kw=dict(prompt_depth=1, num_context=4, context_initializer="a photo of a", _init_ids=[5, 9, 7, 5],
+                             vector_std=0.02, use_unified_projection=True, intermediate_dim=None, use_proj_norm=False),
+             net_kw=base_old, **T)
+    # --- full size (ViT-B/16 rd64 geometry), B=1 ------------------------------
+    F_ = dict(preset="rd64", B=1, H=352, L=8, M=M)
+    run_case("rd64_vpt_n10_d1", eos=2, wseed=21, net_kind="vpt", iseed=21,
+             learner_kw=dict(prompt_depth=1, num_context=10, vector_std=0.02), net_kw=base_old, **F_)
+    run_case("rd64_coop_n4_d1", eos=2, wseed=21, net_kind="coop", iseed=22,
+             learner_kw=dict(prompt_depth=1, num_context=4, vector_std=0.02), net_kw=base_old, **F_)
+    run_case("rd64_maple_n4_d9_newlast", eos=2, wseed=21, net_kind="maple", iseed=23,
+             learner_kw=dict(prompt_depth=9, num_context=4, vector_std=0.02, use_unified_projection=False,
+                             intermediate_dim=64, use_proj_norm=True, use_lora_proj=False), net_kw=base_new, **F_)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""Helpers shared by the parity tests: load golden fixtures, rebuild learner parameters."""
+from __future__ import annotations
+
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from tunevlseg_amd.config import CLIPSegConfig
+from tunevlseg_amd.weights import init_clipseg_state_dict
+
+GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
+
+
+def golden_names(prefix: str = "") -> list[str]:
+    return sorted(p.stem for p in GOLDEN_DIR.glob(f"{prefix}*.npz"))
+
+
+def load_golden(name: str) -> dict:
+    z = np.load(GOLDEN_DIR / f"{name}.npz")
+    fx = {k: z[k] for k in z.files if k != "meta"}
+    fx["meta"] = json.loads(bytes(z["meta"]).decode())
+    return fx
+
+
+def config_of(fx) -> CLIPSegConfig:
+    m = fx["meta"]
+    return CLIPSegConfig.tiny(m["eos_token_id"]) if m["preset"] == "tiny" else CLIPSegConfig.rd64(m["eos_token_id"])
+
+
+def state_of(fx) -> dict[str, torch.Tensor]:
+    sd = init_clipseg_state_dict(config_of(fx), fx["meta"]["weight_seed"])
+    chk = float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(chk - fx["meta"]["weights_checksum"]) <= 1e-6 * abs(chk), "seeded weight draw drifted from the fixture"
+    return sd
+
+
+def trainable_of(fx, requires_grad: bool = True) -> dict[str, torch.Tensor]:
+    out = {}
+    for k, v in fx.items():
+        if k.startswith("param."):
+            t = torch.from_numpy(np.array(v)).clone()
+            out[k[len("param."):]] = t.requires_grad_(requires_grad)
+    return out
+
+
+def oracle_learner(fx, params: dict[str, torch.Tensor]) -> dict:
+    """Describe the fixture's learner the way ``oracle.clipseg_oracle`` expects."""
+    m = fx["meta"]
+    kind = m["net"]
+    ctx = params["context_learner.context_vectors"]
+    depth = ctx.shape[0]
+    learner = {"kind": kind, "ctx": ctx}
+    pat = re.compile(r"context_learner\.projection_layers\.(\d+)\.(?:(\d+)\.)?(weight|bias)$")
+    layers: dict[int, dict[int, dict[str, torch.Tensor]]] = {}
+    for k, t in params.items():
+        mm = pat.match(k)
+        if mm:
+            li, sub, wb = int(mm.group(1)), int(mm.group(2) or 0), mm.group(3)
+            layers.setdefault(li, {}).setdefault(sub, {})[wb] = t
+    if layers:
+        proj = []
+        for d in range(depth):
+            src = layers[d if d in layers else 0]  # unified projection: one shared module
+            ops = []
+            for sub in range(max(src) + 1):
+                if sub not in src:
+                    ops.append(("relu",))
+                    continue
+                w, b = src[sub]["weight"], src[sub].get("bias")
+                ops.append(("linear", w, b) if w.dim() == 2 else ("layernorm", w, b, 1e-5))
+            proj.append(ops)
+        learner["proj"] = proj
+    if kind == "cocoop":
+        learner["norm_image_features"] = m["learner_kw"].get("norm_image_features", True)
+    return learner
+
+
+def new_last_of(fx, params):
+    if "additive_decoder_layer.1.weight" not in params:
+        return None
+    return (params["additive_decoder_layer.1.weight"], params["additive_decoder_layer.1.bias"], params["residual_ratio"])
+
+
+def inputs_of(fx):
+    return (torch.from_numpy(fx["in.pixel_values"]), torch.from_numpy(fx["in.input_ids"]),
+            torch.from_numpy(fx["in.attention_mask"]), torch.from_numpy(fx["in.mask"]))

@@ -1,0 +1,60 @@
+"""The CPU oracle against the reference's own outputs (golden fixtures).
+
+Fixtures were produced by running the reference classes themselves
+(tests/golden/make_goldens.py); this pins ``oracle/clipseg_oracle.py``.
+Tolerance: fp32 round-off of two different op orders on CPU (atol 2e-5 on O(1)
+logits; grads compared relative to their own scale).
+"""
+import pytest
+import torch
+
+from oracle import clipseg_oracle as O
+from tests.golden_util import (config_of, golden_names, inputs_of, load_golden, new_last_of, oracle_learner,
+                               state_of, trainable_of)
+
+
+def run_oracle(fx):
+    cfg, sd = config_of(fx), state_of(fx)
+    params = trainable_of(fx)
+    learner = oracle_learner(fx, params)
+    pix, ids, am, mask = inputs_of(fx)
+    kind = fx["meta"]["net"]
+    if kind == "vpt":
+        logits = O.vpt_forward(sd, cfg, learner, pix, ids, am, new_last_of(fx, params))
+    elif kind in ("coop", "cocoop"):
+        logits = O.coop_forward(sd, cfg, learner, pix, ids, am)
+    else:
+        logits = O.maple_forward(sd, cfg, learner, pix, ids, am, new_last_of(fx, params))
+    loss = O.dice_ce_loss(logits, mask)
+    loss.backward()
+    return logits.detach(), loss.detach(), params
+
+
+def check(fx):
+    logits, loss, params = run_oracle(fx)
+    ref = torch.from_numpy(fx["out.logits"])
+    assert logits.shape == ref.shape
+    assert (logits - ref).abs().max().item() <= 2e-5
+    assert abs(loss.item() - float(fx["out.loss"])) <= 1e-6
+    # thresholded label map: bit-exact
+    assert torch.equal(torch.sigmoid(logits) > 0.5, torch.sigmoid(ref) > 0.5)
+    for k in params:
+        if k in fx["meta"]["grads_none"]:
+            assert params[k].grad is None or params[k].grad.abs().max() == 0, k
+            continue
+        g_ref = torch.from_numpy(fx["grad." + k])
+        g = params[k].grad
+        assert g is not None, k
+        scale = g_ref.abs().max().item() + 1e-12
+        assert (g - g_ref).abs().max().item() <= 2e-4 * scale + 1e-9, (k, (g - g_ref).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("name", golden_names("tiny_"))
+def test_oracle_matches_reference_tiny(name):
+    check(load_golden(name))
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", golden_names("rd64_"))
+def test_oracle_matches_reference_full_size(name):
+    check(load_golden(name))
