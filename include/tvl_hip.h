@@ -1,0 +1,178 @@
+/*
+ * tvl_hip.h -- C ABI of libtvl_hip.so: the MI355X (gfx950) kernels behind the
+ * prompt-tuning hot path of naamiinepal/tunevlseg.
+ *
+ * The reference has no native code and no FFI: its hot path is
+ * the PyTorch op sequence inside ``net(text_input, image_input)``
+ * (reference src/models/image_text_mask_module.py:68-70,257-265).  Each entry
+ * point below replaces the op sequence cited next to it.  Conventions:
+ *
+ *   - plain C symbols, device pointers + sizes + a hipStream_t (as void*);
+ *   - return 0 on success, non-zero on bad arguments / launch failure
+ *     (tvl_last_error() gives the text; the Python host raises RuntimeError);
+ *   - no allocation, no synchronisation, no global state: re-entrant per stream
+ *     and capturable into a hipGraph;
+ *   - all tensors are fp32, row-major, unless stated; "ld*" are leading
+ *     dimensions in elements.
+ */
+#ifndef TVL_HIP_H
+#define TVL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tvlStream_t; /* hipStream_t */
+
+const char* tvl_last_error(void);
+int tvl_abi_version(void);
+
+/* row' = (r / div) * mul + (r % div) + off   (div <= 0: identity) */
+typedef struct { int32_t div, mul, off; } tvlRowMap;
+
+enum { TVL_NT = 0, TVL_NN = 1, TVL_TN = 2 };
+enum { TVL_ACT_NONE = 0, TVL_ACT_QUICK_GELU = 1, TVL_ACT_RELU = 2 };
+
+/*
+ * C = epilogue(alpha * op(A) . op(B)), exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   layout NT: A[M,K] (lda), B[N,K] (ldb)   -> nn.Linear forward  (HF modeling_clipseg.py:290-292,333,352-354)
+ *   layout NN: A[M,K] (lda), B[K,N] (ldb)   -> data gradient  dX = dY . W
+ *   layout TN: A[K,M] (lda), B[K,N] (ldb)   -> weight gradient dW = dY^T . X
+ * epilogue, in this order, per element (m, n):
+ *   v = alpha*acc; v += bias[n]; v *= act'(dact_aux[m,n]) (dact); pre_out[m,n] = v;
+ *   v = act(v); v += residual[m,n]; C[map(m), n] = v
+ * a_map remaps the rows of A as stored (the M rows for NT/NN, the K rows for TN);
+ * c_map remaps rows of C / pre_out / residual / dact_aux.
+ */
+typedef struct {
+    int32_t layout, M, N, K;
+    const float* A; int32_t lda;
+    const float* B; int32_t ldb;
+    float* C; int32_t ldc;
+    const float* bias;
+    const float* residual; int32_t ldr;
+    int32_t act;
+    float* pre_out;
+    const float* dact_aux; int32_t ld_aux; int32_t dact;
+    float alpha;
+    tvlRowMap a_map, c_map;
+} tvlGemmArgs;
+int tvl_gemm_f32(const tvlGemmArgs* args, tvlStream_t stream);
+
+/* LayerNorm over the last dim (nn.LayerNorm, eps 1e-5; HF:347,355,392,396).  mean/rstd may be NULL. */
+int tvl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                      int64_t rows, int32_t cols, float eps, tvlStream_t stream);
+/* dx = [dres +] LN'(dy); dgamma/dbeta (may be NULL) are ACCUMULATED with atomics (tiny trainable norms only). */
+int tvl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                      const float* dres, float* dx, float* dgamma, float* dbeta,
+                      int64_t rows, int32_t cols, tvlStream_t stream);
+
+/*
+ * Multi-head softmax attention, flash style (HF eager_attention_forward, modeling_clipseg.py:232-252).
+ * q/k/v: element (b, t, h, d) at ptr[b*bs + t*ts + h*dh + d] (packed QKV GEMM output or separate).
+ * o: [B, T, H*dh] (ldo = row stride).  lse: [B, H, T] natural-log-sum-exp of the scaled scores.
+ * causal != 0: key j visible to query i iff j <= i (reference coop_clipseg.py:229-233);
+ * key_mask (may be NULL): int32 [B, T], 0 = padded key (coop_clipseg.py:236-246).
+ * dh in {8,16,32,64}.
+ */
+typedef struct {
+    const float *q, *k, *v; int64_t q_bs, k_bs, v_bs; int32_t q_ts, k_ts, v_ts;
+    float* o; int32_t ldo;
+    float* lse;
+    const int32_t* key_mask;
+    int32_t B, H, T, dh, causal;
+    float scale;
+} tvlAttnFwdArgs;
+int tvl_attn_fwd(const tvlAttnFwdArgs* a, tvlStream_t stream);
+
+typedef struct {
+    const float *q, *k, *v; int64_t q_bs, k_bs, v_bs; int32_t q_ts, k_ts, v_ts;
+    const float* o; const float* d_o; int32_t ldo;
+    const float* lse;
+    float* delta;               /* workspace [B,H,T] */
+    float *dq, *dk, *dv; int64_t dq_bs, dk_bs, dv_bs; int32_t dq_ts, dk_ts, dv_ts;
+    const int32_t* key_mask;
+    int32_t B, H, T, dh, causal;
+    float scale;
+} tvlAttnBwdArgs;
+int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream);
+
+/* ---- token plumbing (reference vpt_context_learner.py:46-64, base_visual_learner.py:18-23,
+ *      coop_context_learner.py:124-181, HF:190-206) ---- */
+/* im2col for the 16x16/s16 patch conv: img [B,C,H,W] -> cols [B*gh*gw, C*ps*ps] */
+int tvl_im2col_patch(const float* img, float* cols, int32_t B, int32_t C, int32_t H, int32_t W, int32_t ps, tvlStream_t stream);
+/* x0[b,t,:] = t==0 ? cls+pos[0] : t<=P ? patch[b*P+t-1]+pos[t] : ctx[(b*ctx_bs) + t-1-P]  ; T = 1+P+n */
+int tvl_vision_assemble(const float* patch, const float* cls, const float* pos, const float* ctx, int64_t ctx_bs,
+                        float* x0, int32_t B, int32_t P, int32_t n, int32_t D, tvlStream_t stream);
+/* out[b,t,:] = (map[t] >= 0 ? table[ids[b*L + map[t]]] : ctx[b*ctx_bs + (-map[t]-1)*D]) + pos[t]  (ids int64) */
+int tvl_text_assemble(const int64_t* ids, int32_t L, const int32_t* map, const float* table, const float* ctx, int64_t ctx_bs,
+                      const float* pos, float* out, int32_t B, int32_t T, int32_t D, tvlStream_t stream);
+/* x[b, row0+j, :] = src[b*src_bs + j*D ...]  for j < n  (src_bs = 0: broadcast one [n,D] block over the batch) */
+int tvl_rows_overwrite(float* x, const float* src, int64_t src_bs, int32_t B, int32_t T, int32_t D, int32_t row0, int32_t n, tvlStream_t stream);
+/* dst[(b*dst_bs) + j*D + c] (+)= sum_b? g[b, row0+j, c]; reduce_batch != 0 sums over b into one [n,D] block;
+ * zero_src != 0 clears g[b,row0+j,:] afterwards (gradient cut of an in-place overwrite). accumulate != 0: += */
+int tvl_rows_grad(float* g, float* dst, int32_t B, int32_t T, int32_t D, int32_t row0, int32_t n,
+                  int32_t reduce_batch, int32_t zero_src, int32_t accumulate, tvlStream_t stream);
+/* out[b,:] = x[b, idx[b], :]  /  dx[b, idx[b], :] += dout[b,:]  (dx pre-zeroed by caller) ; idx int32 */
+int tvl_gather_rows(const float* x, const int32_t* idx, float* out, int32_t B, int32_t T, int32_t D, tvlStream_t stream);
+int tvl_scatter_rows_add(const float* dout, const int32_t* idx, float* dx, int32_t B, int32_t T, int32_t D, tvlStream_t stream);
+
+/* ---- decoder pieces (reference base_clipseg.py:82-172, vpt_clipseg.py:237-319, HF:549-586) ---- */
+/* FiLM: y[b,t,c] = mul[b,c]*x[b,t,c] + add[b,c] */
+int tvl_film_fwd(const float* x, const float* mul, const float* add, float* y, int32_t B, int32_t T, int32_t C, tvlStream_t stream);
+/* dx = mul*dy ; dmul[b,c] = sum_t dy*x ; dadd[b,c] = sum_t dy  (dmul/dadd may be NULL) */
+int tvl_film_bwd(const float* dy, const float* x, const float* mul, float* dx, float* dmul, float* dadd,
+                 int32_t B, int32_t T, int32_t C, tvlStream_t stream);
+/* ConvTranspose2d(k=s=ps) tail: logits[b, gy*ps+py, gx*ps+px] = a*(cols[(b*G*G+gy*G+gx), py*ps+px] + bias) + r*extra[...]
+ * (extra may be NULL; a, r implement `+=` (1,1) or `(1-r)*..+r*..` mixing of the new last layer) */
+int tvl_pixel_shuffle_fwd(const float* cols, const float* bias, const float* extra, float a, float r,
+                          float* logits, int32_t B, int32_t G, int32_t ps, tvlStream_t stream);
+/* dcols[(b,gy,gx),(py,px)] = a * dlogits[b, gy*ps+py, gx*ps+px] */
+int tvl_pixel_unshuffle_bwd(const float* dlogits, float a, float* dcols, int32_t B, int32_t G, int32_t ps, tvlStream_t stream);
+/* new last layer (reference base_clipseg.py:58-71): Upsample(x ps, bilinear, align_corners=False) ->
+ * Conv2d(C->1, k, same, replicate).  The channel contraction is a GEMM done by the caller:
+ * taps[(b,i,j), ky*k+kx] = sum_c feat[b,i,j,c] * w[c,ky,kx]   ([B*G*G, ldg]); then
+ *   out[b,y,x] = bias + sum_{ky,kx} bilinear(taps[b,:,:,ky,kx])(clamp(y+ky-pl), clamp(x+kx-pl))
+ * so the C x (G*ps)^2 upsampled map is never materialised. k <= 7. */
+int tvl_upconv_taps_fwd(const float* taps, int32_t ldg, const float* bias, float* out,
+                        int32_t B, int32_t G, int32_t ps, int32_t k, tvlStream_t stream);
+/* dtaps [B*G*G, ldg] (first k*k columns written); work: [B*k*G*ps*G] floats */
+int tvl_upconv_taps_bwd(const float* dout, float* dtaps, int32_t ldg, float* work,
+                        int32_t B, int32_t G, int32_t ps, int32_t k, tvlStream_t stream);
+
+/* ---- loss + metrics (monai DiceCELoss(sigmoid) + torchmetrics Dice/Jaccard; reference
+ *      image_text_mask_module.py:87-107,272-302, configs/model/vpt_clipseg.yaml:21-25) ---- */
+/* per-sample sums over N = H*W pixels, one pass:
+ *   fsum[b] = {sum p*t, sum p, sum t, sum bce}  (float64 x4)   p = sigmoid(logit)
+ *   isum[b] = {TP, FP, FN, TN} of (p > thr) vs (int64)t  (int64 x4, bit-exact)
+ * label (may be NULL): uint8 thresholded map */
+int tvl_dicece_stats(const float* logits, const float* target, double* fsum, int64_t* isum, uint8_t* label,
+                     int32_t B, int64_t N, float thr, tvlStream_t stream);
+/* dlogits = gscale * ( lambda_dice * dDice/dlogit + lambda_ce * (p - t)/(B*N) ), using fsum from tvl_dicece_stats */
+int tvl_dicece_bwd(const float* logits, const float* target, const double* fsum, float* dlogits,
+                   int32_t B, int64_t N, float lambda_dice, float lambda_ce, float smooth_nr, float smooth_dr,
+                   const float* gscale, tvlStream_t stream);
+
+/* ---- optimiser + misc ---- */
+/* torch.optim.AdamW step over a flat fp32 buffer (decoupled weight decay); step_t is 1-based */
+int tvl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int32_t step_t, float grad_scale, tvlStream_t stream);
+int tvl_fill(float* p, float val, int64_t n, tvlStream_t stream);
+/* y = a*x + b*y */
+int tvl_axpby(const float* x, float a, float* y, float b, int64_t n, tvlStream_t stream);
+/* y[r,c] = act(x[r,c]) or dact: y = dy * act'(x) */
+int tvl_bias_act(const float* x, const float* bias, float* y, int64_t rows, int32_t cols, int32_t act, tvlStream_t stream);
+/* l2-normalise rows: y = x / ||x|| ; bwd */
+int tvl_l2norm_fwd(const float* x, float* y, float* inv_norm, int32_t rows, int32_t cols, tvlStream_t stream);
+int tvl_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int32_t rows, int32_t cols, tvlStream_t stream);
+/* out[0] (+)= sum_i x[i]*y[i]  (y NULL: plain sum) */
+int tvl_dot(const float* x, const float* y, float* out, int64_t n, int32_t accumulate, tvlStream_t stream);
+/* colsum[c] (+)= sum_r x[r,c]  (bias gradients of small trainable Linears) */
+int tvl_colsum(const float* x, float* out, int64_t rows, int32_t cols, int32_t accumulate, tvlStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TVL_HIP_H */

@@ -1,0 +1,338 @@
+"""Kernel-level parity: every C-ABI entry point against a float64 PyTorch restatement of the same op.
+
+Runs on the GPU box only (-m gpu).  Tolerances are fp32 round-off of the exact-fp32 MFMA path:
+rtol 2e-5 on GEMM/attention outputs relative to the operand scale, bit-exact for integer counts.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tunevlseg_amd import hip as H
+
+    H.load()
+    return H
+
+
+def dev(t):
+    return t.to("cuda").contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, tol, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item() + 1e-30
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+def qgelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(300, 200, 100), (128, 128, 32), (1000, 768, 768), (4100, 2048, 96), (77, 64, 64), (65, 70, 36),
+                                   (50, 25, 64)])
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_layouts(hip, M, N, K, layout):
+    A = rnd(M, K, seed=1)
+    B = rnd(N, K, seed=2) if layout == 0 else rnd(K, N, seed=2)
+    ref = A.double() @ (B.double().T if layout == 0 else B.double())
+    Ad = dev(A.T) if layout == 2 else dev(A)  # TN stores A as [K, M]
+    Bd = dev(B)
+    Cd = torch.empty(M, N, device="cuda")
+    hip.gemm(layout, M, N, K, Ad, Ad.shape[1], Bd, Bd.shape[1], Cd, N)
+    close(Cd, ref, 3e-6 * math.sqrt(K), f"gemm layout {layout}")
+
+
+def test_gemm_unaligned_k(hip):
+    M, N, K = 130, 67, 70  # lda % 4 != 0 -> scalar-guarded loads
+    A, W = rnd(M, K, seed=3), rnd(N, K, seed=4)
+    Cd = torch.empty(M, N, device="cuda")
+    hip.gemm(hip.NT, M, N, K, dev(A), K, dev(W), K, Cd, N)
+    close(Cd, A.double() @ W.double().T, 2e-5, "gemm unaligned")
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "relu", None])
+def test_gemm_epilogue_forward(hip, act):
+    M, N, K = 515, 192, 64
+    x, W, b, res = rnd(M, K, seed=5), rnd(N, K, seed=6, scale=0.2), rnd(N, seed=7), rnd(M, N, seed=8)
+    pre_ref = x.double() @ W.double().T + b.double()
+    a_ref = {"quick_gelu": qgelu, "relu": F.relu, None: lambda v: v}[act](pre_ref)
+    y, pre = hip.linear_fwd(dev(x), dev(W), dev(b), act=hip.ACT_IDS[act], residual=dev(res), want_pre=True)
+    close(pre, pre_ref, 1e-5, "pre")
+    close(y, a_ref + res.double(), 1e-5, "y")
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "relu"])
+def test_gemm_dgrad_with_dact(hip, act):
+    M, N, K = 300, 96, 160  # dy [M,N], W [N,K]
+    dy, W, z, res = rnd(M, N, seed=9), rnd(N, K, seed=10, scale=0.3), rnd(M, K, seed=11), rnd(M, K, seed=12)
+    zz = z.double().requires_grad_(True)
+    f = (qgelu(zz) if act == "quick_gelu" else F.relu(zz)).sum()
+    (gz,) = torch.autograd.grad(f, zz)
+    ref = (dy.double() @ W.double()) * gz + res.double()
+    dx = hip.linear_dgrad(dev(dy), dev(W), dact=hip.ACT_IDS[act], dact_aux=dev(z), residual=dev(res))
+    close(dx, ref, 1e-5, "dgrad")
+
+
+def test_gemm_wgrad_and_rowmaps(hip):
+    B_, T, P, Cc, N = 3, 12, 9, 16, 25
+    tok = rnd(B_, T, Cc, seed=13)
+    w = rnd(Cc, N, seed=14)
+    strip = tok[:, 1:1 + P].reshape(B_ * P, Cc)
+    # forward with a_map: rows 1..P of every T-row block
+    out = torch.empty(B_ * P, N, device="cuda")
+    amap = hip.RowMap(P, T, 1)
+    hip.gemm(hip.NN, B_ * P, N, Cc, dev(tok.reshape(B_ * T, Cc)), Cc, dev(w), N, out, N, a_map=amap)
+    close(out, strip.double() @ w.double(), 1e-5, "a_map")
+    # wgrad with the K rows remapped
+    dy = rnd(B_ * P, N, seed=15)
+    dW = torch.empty(Cc, N, device="cuda")
+    hip.gemm(hip.TN, Cc, N, B_ * P, dev(tok.reshape(B_ * T, Cc)), Cc, dev(dy), N, dW, N, a_map=amap)
+    close(dW, strip.double().T @ dy.double(), 1e-5, "tn a_map")
+    # dgrad scattered through c_map into a zeroed token buffer
+    dtok = torch.zeros(B_ * T, Cc, device="cuda")
+    hip.gemm(hip.NT, B_ * P, Cc, N, dev(dy), N, dev(w), N, dtok, Cc, c_map=amap)
+    ref = torch.zeros(B_, T, Cc, dtype=torch.double)
+    ref[:, 1:1 + P] = (dy.double() @ w.double().T).reshape(B_, P, Cc)
+    close(dtok.reshape(B_, T, Cc), ref, 1e-5, "c_map")
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols", [(1001, 768), (37, 64), (5, 32), (9, 10), (130, 512)])
+def test_layernorm_fwd_bwd(hip, rows, cols):
+    x, g, b, dy, dres = rnd(rows, cols, seed=1) * 2 + 0.5, 1 + 0.1 * rnd(cols, seed=2), rnd(cols, seed=3), rnd(rows, cols, seed=4), rnd(rows, cols, seed=5)
+    xd = x.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yref = F.layer_norm(xd, (cols,), gd, bd, 1e-5)
+    yref.backward(dy.double())
+    y, mean, rstd = hip.layernorm_fwd(dev(x), dev(g), dev(b), 1e-5)
+    close(y, yref, 2e-6, "ln fwd")
+    dgam = torch.zeros(cols, device="cuda")
+    dbet = torch.zeros(cols, device="cuda")
+    dx = hip.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd, dres=dev(dres), dgamma=dgam, dbeta=dbet)
+    close(dx, xd.grad + dres.double(), 5e-6, "ln dx")
+    close(dgam, gd.grad, 2e-5, "ln dgamma")
+    close(dbet, bd.grad, 2e-5, "ln dbeta")
+
+
+# ----------------------------------------------------------------------------------------------
+def attn_ref(qkv, B, T, H, dh, causal, key_mask):
+    D = H * dh
+    q, k, v = (qkv[..., i * D:(i + 1) * D].reshape(B, T, H, dh).transpose(1, 2) for i in range(3))
+    w = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    allowed = torch.ones(T, T, dtype=torch.bool)
+    if causal:
+        allowed = allowed.tril()
+    allowed = allowed.expand(B, 1, T, T)
+    if key_mask is not None:
+        allowed = allowed & key_mask.bool()[:, None, None, :]
+    w = w.masked_fill(~allowed, float("-inf"))
+    p = torch.softmax(w, -1)
+    return (p @ v).transpose(1, 2).reshape(B, T, D), torch.logsumexp(w, -1)
+
+
+@pytest.mark.parametrize("B,T,H,dh,causal,masked", [(2, 495, 2, 64, False, False), (3, 77, 2, 64, True, True), (2, 50, 3, 16, False, False),
+                                                    (2, 17, 2, 8, True, True), (1, 130, 1, 32, True, False), (2, 21, 4, 16, False, True)])
+def test_attention_fwd_bwd(hip, B, T, H, dh, causal, masked):
+    D = H * dh
+    qkv = rnd(B, T, 3 * D, seed=21)
+    d_o = rnd(B, T, D, seed=22)
+    km = None
+    if masked:
+        km = torch.ones(B, T, dtype=torch.int32)
+        for b in range(B):
+            km[b, T - 1 - 2 * b - 1:] = 0  # trailing padding; key 0 always visible
+    qd = qkv.double().requires_grad_(True)
+    oref, lseref = attn_ref(qd, B, T, H, dh, causal, km)
+    oref.backward(d_o.double())
+    qkv_d = dev(qkv.reshape(B * T, 3 * D))
+    kmd = dev(km) if km is not None else None
+    o, lse = hip.attn_fwd_packed(qkv_d, B, T, H, dh, dh ** -0.5, causal=causal, key_mask=kmd)
+    close(o.reshape(B, T, D), oref, 1e-5, "attn o")
+    close(lse, lseref, 1e-5, "attn lse")
+    dqkv = hip.attn_bwd_packed(qkv_d, o, dev(d_o.reshape(B * T, D)), lse, B, T, H, dh, dh ** -0.5, causal=causal, key_mask=kmd)
+    gref = qd.grad.reshape(B * T, 3 * D)
+    close(dqkv[:, :D], gref[:, :D], 2e-5, "dq")
+    close(dqkv[:, D:2 * D], gref[:, D:2 * D], 2e-5, "dk")
+    close(dqkv[:, 2 * D:], gref[:, 2 * D:], 2e-5, "dv")
+
+
+# ----------------------------------------------------------------------------------------------
+def test_im2col_matches_conv(hip):
+    B, Cc, H, ps, Dm = 2, 3, 64, 16, 20
+    img, w = rnd(B, Cc, H, H, seed=31), rnd(Dm, Cc, ps, ps, seed=32, scale=0.05)
+    cols = hip.im2col_patch(dev(img), ps)
+    ref = F.conv2d(img.double(), w.double(), stride=ps).flatten(2).transpose(1, 2).reshape(-1, Dm)
+    out = hip.linear_fwd(cols, dev(w.reshape(Dm, -1)))
+    close(out, ref, 1e-5, "patch embed")
+
+
+def test_vision_and_text_assemble(hip):
+    B, P, n, D = 3, 16, 4, 32
+    patch, cls, pos, ctx = rnd(B * P, D, seed=33), rnd(D, seed=34), rnd(1 + P, D, seed=35), rnd(n, D, seed=36)
+    x0 = hip.vision_assemble(dev(patch), dev(cls), dev(pos), dev(ctx), 0, B, P, n, D)
+    ref = torch.cat((torch.cat((cls.expand(B, 1, D), patch.reshape(B, P, D)), 1) + pos, ctx.expand(B, n, D)), 1)
+    close(x0, ref, 1e-7, "vision assemble")
+    # text: [BOS, ctx(2), tok1, tok2, last]
+    L, V, Dt, T = 5, 50, 16, 6
+    ids = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(1))
+    table, tpos, tctx = rnd(V, Dt, seed=37), rnd(T, Dt, seed=38), rnd(B, 2, Dt, seed=39)
+    tmap = torch.tensor([0, -1, -2, 1, 2, L - 1], dtype=torch.int32)
+    out = hip.text_assemble(dev(ids), dev(tmap), dev(table), dev(tctx), 2 * Dt, dev(tpos), B, T, Dt)
+    emb = table[ids]
+    ref = torch.cat((emb[:, :1], tctx, emb[:, 1:3], emb[:, -1:]), 1) + tpos
+    close(out, ref, 1e-7, "text assemble")
+
+
+def test_rows_overwrite_grad_gather_scatter(hip):
+    B, T, D, n = 3, 10, 8, 3
+    x, src = rnd(B, T, D, seed=40), rnd(n, D, seed=41)
+    xd = dev(x)
+    hip.rows_overwrite(xd, dev(src), 0, T - n, n)
+    ref = x.clone()
+    ref[:, -n:] = src
+    close(xd, ref, 0, "overwrite bcast")
+    src_b = rnd(B, n, D, seed=42)
+    hip.rows_overwrite(xd, dev(src_b), n * D, 1, n)
+    ref[:, 1:1 + n] = src_b
+    close(xd, ref, 0, "overwrite per-sample")
+    g = dev(rnd(B, T, D, seed=43))
+    g0 = g.clone().cpu()
+    dst = torch.empty(n, D, device="cuda")
+    hip.rows_grad(g, dst, T - n, n, True, True)
+    close(dst, g0[:, -n:].sum(0), 1e-6, "rows_grad reduce")
+    assert g[:, -n:].abs().max().item() == 0
+    dst_b = torch.ones(B, n, D, device="cuda")
+    hip.rows_grad(g, dst_b, 1, n, False, False, accumulate=True)
+    close(dst_b, 1 + g0[:, 1:1 + n], 1e-6, "rows_grad per-sample accumulate")
+    idx = torch.tensor([2, 0, 9], dtype=torch.int32)
+    out = hip.gather_rows(dev(x), dev(idx))
+    close(out, x[torch.arange(B), idx.long()], 0, "gather")
+    dx = torch.zeros(B, T, D, device="cuda")
+    hip.scatter_rows_add(out, dev(idx), dx)
+    ref = torch.zeros(B, T, D)
+    ref[torch.arange(B), idx.long()] = x[torch.arange(B), idx.long()]
+    close(dx, ref, 0, "scatter")
+
+
+def test_film(hip):
+    B, T, Cc = 3, 21, 16
+    x, mul, add, dy = rnd(B, T, Cc, seed=44), rnd(B, Cc, seed=45), rnd(B, Cc, seed=46), rnd(B, T, Cc, seed=47)
+    y = hip.film_fwd(dev(x), dev(mul), dev(add))
+    close(y, mul[:, None] * x + add[:, None], 1e-6, "film fwd")
+    dx, dmul, dadd = hip.film_bwd(dev(dy), dev(x), dev(mul), True)
+    close(dx, mul[:, None] * dy, 1e-6, "film dx")
+    close(dmul, (dy * x).sum(1), 1e-5, "film dmul")
+    close(dadd, dy.sum(1), 1e-5, "film dadd")
+
+
+def test_pixel_shuffle_is_conv_transpose(hip):
+    B, Cc, G, ps = 2, 8, 4, 16
+    feat, w, b = rnd(B, Cc, G, G, seed=48), rnd(Cc, 1, ps, ps, seed=49), rnd(1, seed=50)
+    ref = F.conv_transpose2d(feat.double(), w.double(), b.double(), stride=ps)[:, 0]
+    tok = feat.permute(0, 2, 3, 1).reshape(B * G * G, Cc)
+    cols = torch.empty(B * G * G, ps * ps, device="cuda")
+    hip.gemm(hip.NN, B * G * G, ps * ps, Cc, dev(tok), Cc, dev(w.reshape(Cc, ps * ps)), ps * ps, cols, ps * ps)
+    logits = hip.pixel_shuffle_fwd(cols, dev(b), None, 1.0, 0.0, B, G, ps)
+    close(logits, ref, 1e-5, "tconv")
+    dl = rnd(B, G * ps, G * ps, seed=51)
+    dcols = hip.pixel_unshuffle_bwd(dev(dl), 0.5, B, G, ps)
+    ref_d = 0.5 * dl.reshape(B, G, ps, G, ps).permute(0, 1, 3, 2, 4).reshape(B * G * G, ps * ps)
+    close(dcols, ref_d, 0, "unshuffle")
+
+
+@pytest.mark.parametrize("k,G", [(5, 4), (3, 2), (5, 22)])
+def test_upconv_taps(hip, k, G):
+    B, Cc, ps = 2, 6, 16
+    feat = rnd(B, Cc, G, G, seed=52).double().requires_grad_(True)
+    w = rnd(1, Cc, k, k, seed=53, scale=0.3).double().requires_grad_(True)
+    b = rnd(1, seed=54).double().requires_grad_(True)
+    up = F.interpolate(feat, scale_factor=float(ps), mode="bilinear")
+    up = F.pad(up, (k // 2,) * 4, mode="replicate")
+    ref = F.conv2d(up, w, b)[:, 0]
+    dout = rnd(B, G * ps, G * ps, seed=55)
+    ref.backward(dout.double())
+    tok = feat.detach().float().permute(0, 2, 3, 1).reshape(B * G * G, Cc)
+    w2 = w.detach().float().reshape(Cc, k * k)
+    taps = torch.empty(B * G * G, k * k, device="cuda")
+    hip.gemm(hip.NN, B * G * G, k * k, Cc, dev(tok), Cc, dev(w2), k * k, taps, k * k)
+    out = hip.upconv_taps_fwd(taps, dev(b.detach().float()), B, G, ps, k)
+    close(out, ref, 1e-5, "upconv fwd")
+    dtaps = hip.upconv_taps_bwd(dev(dout), B, G, ps, k)
+    dtok = hip.linear_fwd(dtaps, dev(w2))  # [M, k*k] x [C, k*k]^T
+    close(dtok.reshape(B, G, G, Cc).permute(0, 3, 1, 2), feat.grad, 2e-5, "upconv dfeat")
+    dW = hip.linear_wgrad(dev(tok), dtaps)  # [C, k*k] = tok^T dtaps
+    close(dW.reshape(1, Cc, k, k), w.grad, 2e-5, "upconv dw")
+    close(hip.dot(dev(dout)), b.grad, 1e-5, "upconv dbias")
+
+
+def test_dicece_stats_and_grad(hip):
+    from oracle import clipseg_oracle as O
+
+    B, S = 3, 48
+    logits = rnd(B, 1, S, S, seed=56) * 2
+    target = (torch.rand(B, 1, S, S, generator=torch.Generator().manual_seed(57)) > 0.7).float()
+    ld = logits.double().requires_grad_(True)
+    loss_ref = O.dice_ce_loss(ld, target.double())
+    loss_ref.backward()
+    fsum, isum, label = hip.dicece_stats(dev(logits), dev(target), 0.5, want_label=True)
+    f = fsum.cpu()
+    dice = (1 - (2 * f[:, 0] + 1e-5) / (f[:, 1] + f[:, 2] + 1e-5)).mean()
+    loss = dice + 0.2 * f[:, 3].sum() / (B * S * S)
+    assert abs(loss.item() - loss_ref.item()) < 1e-6
+    tp, fp, fn, tn = O.confusion_counts(torch.sigmoid(logits), target.long())
+    assert torch.equal(isum.cpu(), torch.stack((tp, fp, fn, tn), 1))
+    assert torch.equal(label.cpu().bool(), torch.sigmoid(logits) > 0.5)
+    gs = torch.tensor([0.7], device="cuda")
+    dl = hip.dicece_bwd(dev(logits), dev(target), fsum, 1.0, 0.2, 1e-5, 1e-5, gs)
+    close(dl, 0.7 * ld.grad, 2e-5, "dicece grad")
+
+
+def test_adamw_matches_torch(hip):
+    n = 1000
+    p0, g1, g2 = rnd(n, seed=58), rnd(n, seed=59), rnd(n, seed=60)
+    pt = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.AdamW([pt], lr=2e-4, weight_decay=0.01)
+    p, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for t, g in enumerate((g1, g2), 1):
+        pt.grad = g.double()
+        opt.step()
+        hip.adamw(p, dev(g), m, v, 2e-4, 0.9, 0.999, 1e-8, 0.01, t)
+    close(p, pt.detach(), 1e-6, "adamw")
+
+
+def test_small_reductions(hip):
+    x = rnd(37, 20, seed=61)
+    y, inv = hip.l2norm_fwd(dev(x))
+    xd = x.double().requires_grad_(True)
+    yr = xd / xd.norm(dim=-1, keepdim=True)
+    dy = rnd(37, 20, seed=62)
+    yr.backward(dy.double())
+    close(y, yr, 1e-6, "l2norm")
+    close(hip.l2norm_bwd(dev(dy), y, inv), xd.grad, 1e-5, "l2norm bwd")
+    close(hip.colsum(dev(x)), x.double().sum(0), 1e-5, "colsum")
+    big = rnd(5000, 3, seed=63)
+    close(hip.colsum(dev(big)), big.double().sum(0), 1e-5, "colsum tall")
+    close(hip.dot(dev(x), dev(dy)), (x.double() * dy.double()).sum().reshape(1), 1e-5, "dot")
+    out = hip.bias_act(dev(x), dev(rnd(20, seed=64)), hip.ACT_QUICK_GELU)
+    close(out, qgelu(x.double() + rnd(20, seed=64).double()), 1e-6, "bias_act")
+    t = torch.empty(100, device="cuda")
+    hip.fill(t, 3.0)
+    assert (t == 3.0).all()
+    hip.axpby(dev(torch.ones(100)), 2.0, t, 0.5)
+    assert torch.allclose(t.cpu(), torch.full((100,), 3.5))

@@ -1,0 +1,68 @@
+// Shared device/host helpers for libtvl_hip (gfx950 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tvl_hip.h"
+
+#define TVL_WAVE 64
+
+void tvl_set_error(const char* fmt, ...);
+
+#define TVL_REQUIRE(cond, ...)                \
+    do {                                      \
+        if (!(cond)) {                        \
+            tvl_set_error(__VA_ARGS__);       \
+            return 1;                         \
+        }                                     \
+    } while (0)
+
+#define TVL_LAUNCH_CHECK(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            tvl_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return 2;                                                                 \
+        }                                                                             \
+    } while (0)
+
+static inline bool tvl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float quick_gelu_f(float z) {
+    return z / (1.0f + expf(-1.702f * z));
+}
+__device__ __forceinline__ float quick_gelu_grad_f(float z) {
+    const float s = 1.0f / (1.0f + expf(-1.702f * z));
+    return s + 1.702f * z * s * (1.0f - s);
+}
+__device__ __forceinline__ float act_f(float v, int act) {
+    if (act == TVL_ACT_QUICK_GELU) return quick_gelu_f(v);
+    if (act == TVL_ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+__device__ __forceinline__ float dact_f(float z, int act) {
+    if (act == TVL_ACT_QUICK_GELU) return quick_gelu_grad_f(z);
+    if (act == TVL_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    return 1.f;
+}

@@ -1,0 +1,400 @@
+"""ctypes binding of ``libtvl_hip.so`` (the C ABI declared in ``include/tvl_hip.h``).
+
+This is the only place the Python host touches the native library.  There is no
+fallback: if the library is missing, or a tensor is not an fp32 contiguous device
+tensor, the call raises.  PyTorch supplies device memory and the current HIP
+stream; every wrapper passes raw device pointers + sizes + the stream handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "libtvl_hip.so"
+
+NT, NN, TN = 0, 1, 2
+ACT_NONE, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2
+ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "quick_gelu": ACT_QUICK_GELU, "relu": ACT_RELU}
+
+
+class RowMap(C.Structure):
+    _fields_ = [("div", C.c_int32), ("mul", C.c_int32), ("off", C.c_int32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("layout", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("A", C.c_void_p), ("lda", C.c_int32),
+        ("B", C.c_void_p), ("ldb", C.c_int32),
+        ("C", C.c_void_p), ("ldc", C.c_int32),
+        ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_int32),
+        ("act", C.c_int32),
+        ("pre_out", C.c_void_p),
+        ("dact_aux", C.c_void_p), ("ld_aux", C.c_int32), ("dact", C.c_int32),
+        ("alpha", C.c_float),
+        ("a_map", RowMap), ("c_map", RowMap),
+    ]
+
+
+class AttnFwdArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
+        ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64),
+        ("q_ts", C.c_int32), ("k_ts", C.c_int32), ("v_ts", C.c_int32),
+        ("o", C.c_void_p), ("ldo", C.c_int32),
+        ("lse", C.c_void_p),
+        ("key_mask", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("T", C.c_int32), ("dh", C.c_int32), ("causal", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
+        ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64),
+        ("q_ts", C.c_int32), ("k_ts", C.c_int32), ("v_ts", C.c_int32),
+        ("o", C.c_void_p), ("d_o", C.c_void_p), ("ldo", C.c_int32),
+        ("lse", C.c_void_p),
+        ("delta", C.c_void_p),
+        ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
+        ("dq_bs", C.c_int64), ("dk_bs", C.c_int64), ("dv_bs", C.c_int64),
+        ("dq_ts", C.c_int32), ("dk_ts", C.c_int32), ("dv_ts", C.c_int32),
+        ("key_mask", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("T", C.c_int32), ("dh", C.c_int32), ("causal", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+# name -> argtypes (stream appended automatically); mirrors include/tvl_hip.h one to one
+_SIGS = {
+    "tvl_gemm_f32": [C.POINTER(GemmArgs)],
+    "tvl_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F],
+    "tvl_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
+    "tvl_attn_fwd": [C.POINTER(AttnFwdArgs)],
+    "tvl_attn_bwd": [C.POINTER(AttnBwdArgs)],
+    "tvl_im2col_patch": [_P, _P, _I, _I, _I, _I, _I],
+    "tvl_vision_assemble": [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I],
+    "tvl_text_assemble": [_P, _I, _P, _P, _P, _L, _P, _P, _I, _I, _I],
+    "tvl_rows_overwrite": [_P, _P, _L, _I, _I, _I, _I, _I],
+    "tvl_rows_grad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I],
+    "tvl_gather_rows": [_P, _P, _P, _I, _I, _I],
+    "tvl_scatter_rows_add": [_P, _P, _P, _I, _I, _I],
+    "tvl_film_fwd": [_P, _P, _P, _P, _I, _I, _I],
+    "tvl_film_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "tvl_pixel_shuffle_fwd": [_P, _P, _P, _F, _F, _P, _I, _I, _I],
+    "tvl_pixel_unshuffle_bwd": [_P, _F, _P, _I, _I, _I],
+    "tvl_upconv_taps_fwd": [_P, _I, _P, _P, _I, _I, _I, _I],
+    "tvl_upconv_taps_bwd": [_P, _P, _I, _P, _I, _I, _I, _I],
+    "tvl_dicece_stats": [_P, _P, _P, _P, _P, _I, _L, _F],
+    "tvl_dicece_bwd": [_P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _P],
+    "tvl_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F],
+    "tvl_fill": [_P, _F, _L],
+    "tvl_axpby": [_P, _F, _P, _F, _L],
+    "tvl_bias_act": [_P, _P, _P, _L, _I, _I],
+    "tvl_l2norm_fwd": [_P, _P, _P, _I, _I],
+    "tvl_l2norm_bwd": [_P, _P, _P, _P, _I, _I],
+    "tvl_dot": [_P, _P, _P, _L, _I],
+    "tvl_colsum": [_P, _P, _L, _I, _I],
+}
+EXPORTS = ["tvl_last_error", "tvl_abi_version", *_SIGS]
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library (torch must be imported first so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C {LIB_PATH.parent}` "
+            "or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    lib.tvl_last_error.restype = C.c_char_p
+    lib.tvl_abi_version.restype = C.c_int
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [*sig, C.c_void_p]
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args, _stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.tvl_last_error().decode()}")
+
+
+def _p(t: torch.Tensor | None, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"HIP op needs a contiguous {dtype} device tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def _ident():
+    return RowMap(0, 0, 0)
+
+
+# --------------------------------------------------------------------------------------
+# GEMM
+# --------------------------------------------------------------------------------------
+def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias=None, residual=None, ldr=0, act=ACT_NONE,
+         pre_out=None, dact_aux=None, ld_aux=0, dact=ACT_NONE, alpha=1.0, a_map=None, c_map=None):
+    args = GemmArgs(layout, M, N, K, _p(A), lda, _p(B), ldb, _p(Cout), ldc, _p(bias), _p(residual), ldr, act, _p(pre_out),
+                    _p(dact_aux), ld_aux, dact, alpha, a_map or _ident(), c_map or _ident())
+    _call("tvl_gemm_f32", C.byref(args))
+    return Cout
+
+
+def linear_fwd(x2d: torch.Tensor, W: torch.Tensor, b=None, *, act=ACT_NONE, residual=None, want_pre=False, out=None,
+               a_map=None, c_map=None, M=None, out_rows=None):
+    """y = act(x W^T + b) + residual ; x2d [M,K] (or more rows with a_map), W [N,K]."""
+    Mx = x2d.shape[0] if M is None else M
+    K = x2d.shape[1]
+    N = W.shape[0]
+    rows = Mx if out_rows is None else out_rows
+    y = out if out is not None else torch.empty((rows, N), device=x2d.device, dtype=torch.float32)
+    pre = torch.empty_like(y) if want_pre else None
+    gemm(NT, Mx, N, K, x2d, K, W, K, y, N, bias=b, residual=residual, ldr=N, act=act, pre_out=pre, a_map=a_map, c_map=c_map)
+    return (y, pre) if want_pre else y
+
+
+def linear_dgrad(dy2d: torch.Tensor, W: torch.Tensor, *, dact=ACT_NONE, dact_aux=None, residual=None, out=None, c_map=None,
+                 out_rows=None, M=None):
+    """dx = (dy W) * act'(aux) + residual ; dy2d [M,N], W [N,K] -> [M,K]."""
+    Mx = dy2d.shape[0] if M is None else M
+    N, K = W.shape
+    rows = Mx if out_rows is None else out_rows
+    dx = out if out is not None else torch.empty((rows, K), device=dy2d.device, dtype=torch.float32)
+    gemm(NN, Mx, K, N, dy2d, N, W, K, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map)
+    return dx
+
+
+def linear_wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, *, a_map=None, M=None) -> torch.Tensor:
+    """dW[N,K] = dy^T x ; dy2d [M,N], x2d [M,K]."""
+    Mx = dy2d.shape[0] if M is None else M
+    N, K = dy2d.shape[1], x2d.shape[1]
+    dW = torch.empty((N, K), device=dy2d.device, dtype=torch.float32)
+    gemm(TN, N, K, Mx, dy2d, N, x2d, K, dW, K, a_map=a_map)
+    return dW
+
+
+# --------------------------------------------------------------------------------------
+# LayerNorm
+# --------------------------------------------------------------------------------------
+def layernorm_fwd(x2d, gamma, beta, eps: float, want_stats=True):
+    rows, cols = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
+    rstd = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
+    _call("tvl_layernorm_fwd", _p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, cols, float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None):
+    rows, cols = x2d.shape
+    dx = torch.empty_like(x2d)
+    _call("tvl_layernorm_bwd", _p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma), _p(dbeta), rows, cols)
+    return dx
+
+
+# --------------------------------------------------------------------------------------
+# attention over a packed [B, T, 3*H*dh] QKV buffer
+# --------------------------------------------------------------------------------------
+def attn_fwd_packed(qkv: torch.Tensor, B: int, T: int, H: int, dh: int, scale: float, causal=False, key_mask=None, want_lse=True):
+    D = H * dh
+    o = torch.empty((B * T, D), device=qkv.device, dtype=torch.float32)
+    lse = torch.empty((B, H, T), device=qkv.device, dtype=torch.float32) if want_lse else None
+    base = _p(qkv)
+    a = AttnFwdArgs(base, base + 4 * D, base + 8 * D, 3 * D * T, 3 * D * T, 3 * D * T, 3 * D, 3 * D, 3 * D, _p(o), D, _p(lse),
+                    _p(key_mask, torch.int32), B, H, T, dh, int(bool(causal)), float(scale))
+    _call("tvl_attn_fwd", C.byref(a))
+    return o, lse
+
+
+def attn_bwd_packed(qkv, o, d_o, lse, B: int, T: int, H: int, dh: int, scale: float, causal=False, key_mask=None):
+    D = H * dh
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, T), device=qkv.device, dtype=torch.float32)
+    base, dbase = _p(qkv), _p(dqkv)
+    s3 = 3 * D
+    a = AttnBwdArgs(base, base + 4 * D, base + 8 * D, s3 * T, s3 * T, s3 * T, s3, s3, s3, _p(o), _p(d_o), D, _p(lse), _p(delta),
+                    dbase, dbase + 4 * D, dbase + 8 * D, s3 * T, s3 * T, s3 * T, s3, s3, s3, _p(key_mask, torch.int32),
+                    B, H, T, dh, int(bool(causal)), float(scale))
+    _call("tvl_attn_bwd", C.byref(a))
+    return dqkv
+
+
+# --------------------------------------------------------------------------------------
+# token plumbing
+# --------------------------------------------------------------------------------------
+def im2col_patch(img: torch.Tensor, ps: int) -> torch.Tensor:
+    B, Cc, H, W = img.shape
+    cols = torch.empty((B * (H // ps) * (W // ps), Cc * ps * ps), device=img.device, dtype=torch.float32)
+    _call("tvl_im2col_patch", _p(img), _p(cols), B, Cc, H, W, ps)
+    return cols
+
+
+def vision_assemble(patch, cls, pos, ctx, ctx_bs: int, B: int, P: int, n: int, D: int) -> torch.Tensor:
+    x0 = torch.empty((B, 1 + P + n, D), device=patch.device, dtype=torch.float32)
+    _call("tvl_vision_assemble", _p(patch), _p(cls), _p(pos), _p(ctx), ctx_bs, _p(x0), B, P, n, D)
+    return x0
+
+
+def text_assemble(ids, tmap, table, ctx, ctx_bs: int, pos, B: int, T: int, D: int) -> torch.Tensor:
+    out = torch.empty((B, T, D), device=table.device, dtype=torch.float32)
+    _call("tvl_text_assemble", _p(ids, torch.int64), ids.shape[1], _p(tmap, torch.int32), _p(table), _p(ctx), ctx_bs, _p(pos),
+          _p(out), B, T, D)
+    return out
+
+
+def rows_overwrite(x, src, src_bs: int, row0: int, n: int):
+    B, T, D = x.shape
+    _call("tvl_rows_overwrite", _p(x), _p(src), src_bs, B, T, D, row0, n)
+
+
+def rows_grad(g, dst, row0: int, n: int, reduce_batch: bool, zero_src: bool, accumulate: bool = False):
+    B, T, D = g.shape
+    _call("tvl_rows_grad", _p(g), _p(dst), B, T, D, row0, n, int(reduce_batch), int(zero_src), int(accumulate))
+
+
+def gather_rows(x, idx):
+    B, T, D = x.shape
+    out = torch.empty((B, D), device=x.device, dtype=torch.float32)
+    _call("tvl_gather_rows", _p(x), _p(idx, torch.int32), _p(out), B, T, D)
+    return out
+
+
+def scatter_rows_add(dout, idx, dx):
+    B, T, D = dx.shape
+    _call("tvl_scatter_rows_add", _p(dout), _p(idx, torch.int32), _p(dx), B, T, D)
+
+
+# --------------------------------------------------------------------------------------
+# decoder pieces
+# --------------------------------------------------------------------------------------
+def film_fwd(x, mul, add):
+    B, T, Cc = x.shape
+    y = torch.empty_like(x)
+    _call("tvl_film_fwd", _p(x), _p(mul), _p(add), _p(y), B, T, Cc)
+    return y
+
+
+def film_bwd(dy, x, mul, want_cond_grads: bool):
+    B, T, Cc = x.shape
+    dx = torch.empty_like(x)
+    dmul = torch.empty((B, Cc), device=x.device, dtype=torch.float32) if want_cond_grads else None
+    dadd = torch.empty((B, Cc), device=x.device, dtype=torch.float32) if want_cond_grads else None
+    _call("tvl_film_bwd", _p(dy), _p(x), _p(mul), _p(dx), _p(dmul), _p(dadd), B, T, Cc)
+    return dx, dmul, dadd
+
+
+def pixel_shuffle_fwd(cols, bias, extra, a: float, r: float, B: int, G: int, ps: int):
+    logits = torch.empty((B, G * ps, G * ps), device=cols.device, dtype=torch.float32)
+    _call("tvl_pixel_shuffle_fwd", _p(cols), _p(bias), _p(extra), float(a), float(r), _p(logits), B, G, ps)
+    return logits
+
+
+def pixel_unshuffle_bwd(dlogits, a: float, B: int, G: int, ps: int):
+    dcols = torch.empty((B * G * G, ps * ps), device=dlogits.device, dtype=torch.float32)
+    _call("tvl_pixel_unshuffle_bwd", _p(dlogits), float(a), _p(dcols), B, G, ps)
+    return dcols
+
+
+def upconv_taps_fwd(taps, bias, B: int, G: int, ps: int, k: int):
+    out = torch.empty((B, G * ps, G * ps), device=taps.device, dtype=torch.float32)
+    _call("tvl_upconv_taps_fwd", _p(taps), taps.shape[1], _p(bias), _p(out), B, G, ps, k)
+    return out
+
+
+def upconv_taps_bwd(dout, B: int, G: int, ps: int, k: int):
+    dtaps = torch.empty((B * G * G, k * k), device=dout.device, dtype=torch.float32)
+    work = torch.empty(B * k * G * ps * G, device=dout.device, dtype=torch.float32)
+    _call("tvl_upconv_taps_bwd", _p(dout), _p(dtaps), k * k, _p(work), B, G, ps, k)
+    return dtaps
+
+
+# --------------------------------------------------------------------------------------
+# loss / metrics / optimiser / misc
+# --------------------------------------------------------------------------------------
+def dicece_stats(logits, target, thr: float, want_label=False):
+    B = logits.shape[0]
+    N = logits[0].numel()
+    fsum = torch.empty((B, 4), device=logits.device, dtype=torch.float64)
+    isum = torch.empty((B, 4), device=logits.device, dtype=torch.int64)
+    label = torch.empty(logits.shape, device=logits.device, dtype=torch.uint8) if want_label else None
+    _call("tvl_dicece_stats", _p(logits), _p(target), _p(fsum, torch.float64), _p(isum, torch.int64), _p(label, torch.uint8), B, N,
+          float(thr))
+    return fsum, isum, label
+
+
+def dicece_bwd(logits, target, fsum, lambda_dice, lambda_ce, smooth_nr, smooth_dr, gscale):
+    B = logits.shape[0]
+    N = logits[0].numel()
+    dl = torch.empty_like(logits)
+    _call("tvl_dicece_bwd", _p(logits), _p(target), _p(fsum, torch.float64), _p(dl), B, N, float(lambda_dice), float(lambda_ce),
+          float(smooth_nr), float(smooth_dr), _p(gscale))
+    return dl
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_t: int, grad_scale: float = 1.0):
+    _call("tvl_adamw", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+          int(step_t), float(grad_scale))
+
+
+def fill(t, val: float):
+    _call("tvl_fill", _p(t), float(val), t.numel())
+
+
+def axpby(x, a: float, y, b: float):
+    _call("tvl_axpby", _p(x), float(a), _p(y), float(b), x.numel())
+
+
+def bias_act(x2d, bias, act: int):
+    y = torch.empty_like(x2d)
+    _call("tvl_bias_act", _p(x2d), _p(bias), _p(y), x2d.shape[0], x2d.shape[1], act)
+    return y
+
+
+def l2norm_fwd(x2d):
+    y = torch.empty_like(x2d)
+    inv = torch.empty(x2d.shape[0], device=x2d.device, dtype=torch.float32)
+    _call("tvl_l2norm_fwd", _p(x2d), _p(y), _p(inv), x2d.shape[0], x2d.shape[1])
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv):
+    dx = torch.empty_like(y)
+    _call("tvl_l2norm_bwd", _p(dy), _p(y), _p(inv), _p(dx), y.shape[0], y.shape[1])
+    return dx
+
+
+def dot(x, y=None, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+    _call("tvl_dot", _p(x), _p(y), _p(out), x.numel(), int(accumulate))
+    return out
+
+
+def colsum(x2d, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(x2d.shape[1], device=x2d.device, dtype=torch.float32)
+    _call("tvl_colsum", _p(x2d), _p(out), x2d.shape[0], x2d.shape[1], int(accumulate))
+    return out

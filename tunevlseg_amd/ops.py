@@ -1,0 +1,458 @@
+"""autograd nodes of the hot path; every forward/backward body is a sequence of HIP launches.
+
+The frozen towers only ever need *data* gradients (SURVEY.md §8a "Backward requirements"),
+so the two layer nodes below carry hand-written dgrad-only backwards and save exactly what
+those need (layer input, LN statistics, packed QKV, attention output + LSE, MLP pre-activation).
+Weight gradients exist only for the small trainable pieces (prompts, meta-nets, new last layer).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import hip
+
+Fn = torch.autograd.Function
+
+
+@dataclass
+class LayerWeights:
+    """Frozen weights of one transformer layer, QKV packed as [3D, D] (built once per device)."""
+    ln1_w: torch.Tensor
+    ln1_b: torch.Tensor
+    wqkv: torch.Tensor
+    bqkv: torch.Tensor
+    wo: torch.Tensor
+    bo: torch.Tensor
+    ln2_w: torch.Tensor
+    ln2_b: torch.Tensor
+    w1: torch.Tensor
+    b1: torch.Tensor
+    w2: torch.Tensor
+    b2: torch.Tensor
+
+
+@dataclass
+class AttnSpec:
+    heads: int
+    act: int
+    eps: float
+    causal: bool = False
+    key_mask: torch.Tensor | None = None  # int32 [B, T]
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# pre-LN encoder layer (HF CLIPSegEncoderLayer, modeling_clipseg.py:341-371)
+# ----------------------------------------------------------------------------------------------
+class EncoderLayerFn(Fn):
+    @staticmethod
+    def forward(ctx, h, lw: LayerWeights, spec: AttnSpec):
+        h = _c(h)
+        B, T, D = h.shape
+        M = B * T
+        H = spec.heads
+        dh = D // H
+        need = ctx.needs_input_grad[0]
+        h2d = h.view(M, D)
+        x1, mean1, rstd1 = hip.layernorm_fwd(h2d, lw.ln1_w, lw.ln1_b, spec.eps, want_stats=need)
+        qkv = hip.linear_fwd(x1, lw.wqkv, lw.bqkv)
+        del x1
+        o, lse = hip.attn_fwd_packed(qkv, B, T, H, dh, dh**-0.5, spec.causal, spec.key_mask, want_lse=need)
+        h2 = hip.linear_fwd(o, lw.wo, lw.bo, residual=h2d)
+        x2, mean2, rstd2 = hip.layernorm_fwd(h2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
+        if need:
+            a, z = hip.linear_fwd(x2, lw.w1, lw.b1, act=spec.act, want_pre=True)
+        else:
+            a, z = hip.linear_fwd(x2, lw.w1, lw.b1, act=spec.act), None
+        del x2
+        out = hip.linear_fwd(a, lw.w2, lw.b2, residual=h2)
+        if need:
+            ctx.save_for_backward(h2d, mean1, rstd1, qkv, o, lse, h2, mean2, rstd2, z)
+            ctx.lw, ctx.spec, ctx.shape = lw, spec, (B, T, D)
+        return out.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h2d, mean1, rstd1, qkv, o, lse, h2, mean2, rstd2, z = ctx.saved_tensors
+        lw, spec = ctx.lw, ctx.spec
+        B, T, D = ctx.shape
+        H = spec.heads
+        dh = D // H
+        dout2d = _c(dout).view(B * T, D)
+        dz = hip.linear_dgrad(dout2d, lw.w2, dact=spec.act, dact_aux=z)
+        dx2 = hip.linear_dgrad(dz, lw.w1)
+        del dz
+        dh2 = hip.layernorm_bwd(dx2, h2, lw.ln2_w, mean2, rstd2, dres=dout2d)
+        del dx2
+        do = hip.linear_dgrad(dh2, lw.wo)
+        dqkv = hip.attn_bwd_packed(qkv, o, do, lse, B, T, H, dh, dh**-0.5, spec.causal, spec.key_mask)
+        del do
+        dx1 = hip.linear_dgrad(dqkv, lw.wqkv)
+        del dqkv
+        dh_in = hip.layernorm_bwd(dx1, h2d, lw.ln1_w, mean1, rstd1, dres=dh2)
+        return dh_in.view(B, T, D), None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# post-LN decoder layer (HF CLIPSegDecoderLayer, modeling_clipseg.py:374-410)
+# ----------------------------------------------------------------------------------------------
+class DecoderLayerFn(Fn):
+    @staticmethod
+    def forward(ctx, x, lw: LayerWeights, spec: AttnSpec):
+        x = _c(x)
+        B, T, D = x.shape
+        M = B * T
+        H = spec.heads
+        dh = D // H
+        need = ctx.needs_input_grad[0]
+        x2d = x.view(M, D)
+        qkv = hip.linear_fwd(x2d, lw.wqkv, lw.bqkv)
+        o, lse = hip.attn_fwd_packed(qkv, B, T, H, dh, dh**-0.5, False, None, want_lse=need)
+        t1 = hip.linear_fwd(o, lw.wo, lw.bo, residual=x2d)
+        x1, m1, r1 = hip.layernorm_fwd(t1, lw.ln1_w, lw.ln1_b, spec.eps, want_stats=need)
+        if need:
+            u, zu = hip.linear_fwd(x1, lw.w1, lw.b1, act=spec.act, want_pre=True)
+        else:
+            u, zu = hip.linear_fwd(x1, lw.w1, lw.b1, act=spec.act), None
+        t2 = hip.linear_fwd(u, lw.w2, lw.b2, residual=x1)
+        del u
+        out, m2, r2 = hip.layernorm_fwd(t2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
+        if need:
+            ctx.save_for_backward(qkv, o, lse, t1, m1, r1, zu, t2, m2, r2)
+            ctx.lw, ctx.spec, ctx.shape = lw, spec, (B, T, D)
+        return out.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, o, lse, t1, m1, r1, zu, t2, m2, r2 = ctx.saved_tensors
+        lw, spec = ctx.lw, ctx.spec
+        B, T, D = ctx.shape
+        H = spec.heads
+        dh = D // H
+        dout2d = _c(dout).view(B * T, D)
+        dt2 = hip.layernorm_bwd(dout2d, t2, lw.ln2_w, m2, r2)
+        dzu = hip.linear_dgrad(dt2, lw.w2, dact=spec.act, dact_aux=zu)
+        dx1 = hip.linear_dgrad(dzu, lw.w1, residual=dt2)
+        del dzu, dt2
+        dt1 = hip.layernorm_bwd(dx1, t1, lw.ln1_w, m1, r1)
+        del dx1
+        do = hip.linear_dgrad(dt1, lw.wo)
+        dqkv = hip.attn_bwd_packed(qkv, o, do, lse, B, T, H, dh, dh**-0.5, False, None)
+        dx = hip.linear_dgrad(dqkv, lw.wqkv, residual=dt1)
+        return dx.view(B, T, D), None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# generic small pieces
+# ----------------------------------------------------------------------------------------------
+class LinearFn(Fn):
+    """y = act(x W^T + b) [+ residual]; data gradient always, weight/bias gradients when they are trainable."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, residual):
+        shape = x.shape
+        x2d = _c(x).view(-1, shape[-1])
+        W = _c(W)
+        need_any = any(ctx.needs_input_grad)
+        if act != hip.ACT_NONE and need_any:
+            y, pre = hip.linear_fwd(x2d, W, b, act=act, residual=None if residual is None else _c(residual).view(-1, W.shape[0]), want_pre=True)
+        else:
+            y, pre = hip.linear_fwd(x2d, W, b, act=act, residual=None if residual is None else _c(residual).view(-1, W.shape[0])), None
+        ctx.act = act
+        ctx.has_b = b is not None
+        ctx.in_shape = shape
+        ctx.save_for_backward(x2d if ctx.needs_input_grad[1] else None, W, pre)
+        return y.view(*shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, W, pre = ctx.saved_tensors
+        dy2d = _c(dy).view(-1, W.shape[0])
+        if ctx.act != hip.ACT_NONE:
+            # dz = dy * act'(pre): epilogue of an identity-free path -> reuse bias_act-style kernel through the GEMM dact hook
+            dz = _dact_mul(dy2d, pre, ctx.act)
+        else:
+            dz = dy2d
+        dx = dW = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = hip.linear_dgrad(dz, W).view(ctx.in_shape)
+        if ctx.needs_input_grad[1]:
+            dW = hip.linear_wgrad(dz, x2d)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = hip.colsum(dz)
+        if ctx.needs_input_grad[4]:
+            dres = dy
+        return dx, dW, db, None, dres
+
+
+def _dact_mul(dy2d, pre, act):
+    """dy * act'(pre) with the FiLM kernel shape trick avoided: tiny tensors only (meta-nets)."""
+    # One GEMM-free elementwise pass: out = dy * act'(pre).  Expressed with the GEMM epilogue on an identity would
+    # waste FLOPs; these tensors are at most [B*n, 128], so use the dedicated bias_act-derivative kernel.
+    return hip.dact_mul(dy2d, pre, act)
+
+
+def linear(x, W, b=None, act=hip.ACT_NONE, residual=None):
+    return LinearFn.apply(x, W, b, act, residual)
+
+
+class LayerNormFn(Fn):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        shape = x.shape
+        x2d = _c(x).view(-1, shape[-1])
+        need = any(ctx.needs_input_grad)
+        y, mean, rstd = hip.layernorm_fwd(x2d, gamma, beta, eps, want_stats=need)
+        if need:
+            ctx.save_for_backward(x2d, gamma, mean, rstd)
+            ctx.has_beta = beta is not None
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, gamma, mean, rstd = ctx.saved_tensors
+        dy2d = _c(dy).view(x2d.shape)
+        dgamma = torch.zeros_like(gamma) if ctx.needs_input_grad[1] else None
+        dbeta = torch.zeros_like(gamma) if (ctx.has_beta and ctx.needs_input_grad[2]) else None
+        dx = hip.layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dgamma=dgamma, dbeta=dbeta)
+        return (dx.view(dy.shape) if ctx.needs_input_grad[0] else None), dgamma, dbeta, None
+
+
+def layer_norm(x, gamma, beta, eps):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class L2NormFn(Fn):
+    @staticmethod
+    def forward(ctx, x):
+        y, inv = hip.l2norm_fwd(_c(x))
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        return hip.l2norm_bwd(_c(dy), y, inv)
+
+
+class OuterAddFn(Fn):
+    """out[b, j, :] = bias[b, :] + ctx[j, :]   (CoCoOp: cocoop_context_learner.py:50-58)."""
+
+    @staticmethod
+    def forward(ctx, bias, cvec):
+        ctx.shapes = (bias.shape, cvec.shape)
+        return hip.outer_add(_c(bias), _c(cvec))
+
+    @staticmethod
+    def backward(ctx, dout):
+        dbias, dc = hip.outer_add_bwd(_c(dout))
+        return dbias, dc
+
+
+class VisionAssembleFn(Fn):
+    """[CLS+pos0 | patches+pos | prompts] (HF:190-206 + vpt_context_learner.py:46-64); only the prompts carry grad."""
+
+    @staticmethod
+    def forward(ctx, patch, cls, pos, prompts):
+        B = patch.shape[0]
+        P, D = patch.shape[1], patch.shape[2]
+        n = 0 if prompts is None else prompts.shape[-2]
+        per_sample = prompts is not None and prompts.dim() == 3
+        ctx.meta = (B, P, n, D, per_sample)
+        return hip.vision_assemble(_c(patch).view(B * P, D), cls, pos, None if prompts is None else _c(prompts),
+                                   n * D if per_sample else 0, B, P, n, D)
+
+    @staticmethod
+    def backward(ctx, dx0):
+        B, P, n, D, per_sample = ctx.meta
+        dprompts = None
+        if n and ctx.needs_input_grad[3]:
+            dprompts = torch.empty((B, n, D) if per_sample else (n, D), device=dx0.device, dtype=torch.float32)
+            hip.rows_grad(_c(dx0), dprompts, 1 + P, n, not per_sample, False)
+        return None, None, None, dprompts
+
+
+class TextAssembleFn(Fn):
+    """[BOS, ctx(n), words.., last] + pos  (coop_context_learner.py:136-181, coop_clipseg.py:40-73)."""
+
+    @staticmethod
+    def forward(ctx, ids, tmap, table, ctxv, pos, n_ctx):
+        B = ids.shape[0]
+        T = tmap.shape[0]
+        D = table.shape[1]
+        per_sample = ctxv is not None and ctxv.dim() == 3
+        ctx.meta = (B, T, D, n_ctx, per_sample)
+        return hip.text_assemble(ids, tmap, table, None if ctxv is None else _c(ctxv), n_ctx * D if per_sample else 0, pos, B, T, D)
+
+    @staticmethod
+    def backward(ctx, dx):
+        B, T, D, n, per_sample = ctx.meta
+        dctx = None
+        if n and ctx.needs_input_grad[3]:
+            dctx = torch.empty((B, n, D) if per_sample else (n, D), device=dx.device, dtype=torch.float32)
+            hip.rows_grad(_c(dx), dctx, 1, n, not per_sample, False)
+        return None, None, None, dctx, None, None
+
+
+class RowsOverwriteFn(Fn):
+    """In-place ``h[:, row0:row0+n] = src`` (base_visual_learner.py:18-23, coop_context_learner.py:124-134).
+
+    Backward hands the slot gradients to ``src`` and cuts the gradient of the values that were replaced.
+    """
+
+    @staticmethod
+    def forward(ctx, h, src, row0):
+        n = src.shape[-2]
+        per_sample = src.dim() == 3
+        hip.rows_overwrite(h, _c(src), n * h.shape[-1] if per_sample else 0, row0, n)
+        ctx.meta = (row0, n, per_sample)
+        ctx.mark_dirty(h)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        row0, n, per_sample = ctx.meta
+        B, T, D = dh.shape
+        dh_in = dh.clone(memory_format=torch.contiguous_format)
+        dsrc = torch.empty((B, n, D) if per_sample else (n, D), device=dh.device, dtype=torch.float32)
+        hip.rows_grad(dh_in, dsrc, row0, n, not per_sample, True)
+        return dh_in, (dsrc if ctx.needs_input_grad[1] else None), None
+
+
+class GatherRowsFn(Fn):
+    """EOS pooling ``x[arange(B), idx]`` (coop_clipseg.py:261-289)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return hip.gather_rows(_c(x), idx)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dx = torch.zeros(ctx.shape, device=dout.device, dtype=torch.float32)
+        hip.scatter_rows_add(_c(dout), idx, dx)
+        return dx, None
+
+
+class FilmFn(Fn):
+    """``film_mul(c) * x + film_add(c)`` over tokens (base_clipseg.py:110-114)."""
+
+    @staticmethod
+    def forward(ctx, x, mul, add):
+        x, mul, add = _c(x), _c(mul), _c(add)
+        ctx.save_for_backward(x, mul)
+        return hip.film_fwd(x, mul, add)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mul = ctx.saved_tensors
+        want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, dmul, dadd = hip.film_bwd(_c(dy), x, mul, want)
+        return (dx if ctx.needs_input_grad[0] else None), dmul, dadd
+
+
+class SegHeadFn(Fn):
+    """Strip CLS/prompt tokens -> ConvTranspose2d(C->1, k=s=ps) [+ new last layer] (base_clipseg.py:132-155,
+    vpt_clipseg.py:287-302).  mix: 0 none, 1 ``logits += f(out)`` (VPT), 2 ``(1-r) logits + r f(out)`` (Base/MaPLe)."""
+
+    @staticmethod
+    def forward(ctx, tokens, wt, bt, conv_w, conv_b, ratio, mix, G, ps):
+        tokens = _c(tokens)
+        B, T, Cc = tokens.shape
+        Mrows = B * G * G
+        amap = hip.RowMap(G * G, T, 1)
+        tok2d = tokens.view(B * T, Cc)
+        wt2d = _c(wt).view(Cc, ps * ps)
+        cols = torch.empty((Mrows, ps * ps), device=tokens.device, dtype=torch.float32)
+        hip.gemm(hip.NN, Mrows, ps * ps, Cc, tok2d, Cc, wt2d, ps * ps, cols, ps * ps, a_map=amap)
+        extra = tconv = None
+        a, r = 1.0, 0.0
+        k = 0
+        if mix:
+            k = conv_w.shape[-1]
+            w2 = _c(conv_w).view(Cc, k * k)
+            taps = torch.empty((Mrows, k * k), device=tokens.device, dtype=torch.float32)
+            hip.gemm(hip.NN, Mrows, k * k, Cc, tok2d, Cc, w2, k * k, taps, k * k, a_map=amap)
+            extra = hip.upconv_taps_fwd(taps, conv_b, B, G, ps, k)
+            if mix == 2:
+                r = float(ratio.item()) if isinstance(ratio, torch.Tensor) else float(ratio)
+                a = 1.0 - r
+                if ctx.needs_input_grad[5]:
+                    tconv = hip.pixel_shuffle_fwd(cols, bt, None, 1.0, 0.0, B, G, ps)
+            else:
+                r = 1.0
+        logits = hip.pixel_shuffle_fwd(cols, bt, extra, a, r, B, G, ps)
+        ctx.save_for_backward(tokens, wt2d, conv_w if mix else None, extra if tconv is not None else None, tconv)
+        ctx.meta = (B, T, Cc, G, ps, k, mix, a, r)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        tokens, wt2d, conv_w, extra, tconv = ctx.saved_tensors
+        B, T, Cc, G, ps, k, mix, a, r = ctx.meta
+        dlogits = _c(dlogits)
+        Mrows = B * G * G
+        amap = hip.RowMap(G * G, T, 1)
+        need = ctx.needs_input_grad
+        dtok = dwt = dbt = dcw = dcb = dratio = None
+        dcols = hip.pixel_unshuffle_bwd(dlogits, a, B, G, ps)
+        if need[0]:
+            dtok = torch.zeros((B * T, Cc), device=dlogits.device, dtype=torch.float32)
+            hip.gemm(hip.NT, Mrows, Cc, ps * ps, dcols, ps * ps, wt2d, ps * ps, dtok, Cc, c_map=amap)
+        if need[1]:
+            dwt = torch.empty((Cc, ps * ps), device=dlogits.device, dtype=torch.float32)
+            hip.gemm(hip.TN, Cc, ps * ps, Mrows, tokens.view(B * T, Cc), Cc, dcols, ps * ps, dwt, ps * ps, a_map=amap)
+            dwt = dwt.view(Cc, 1, ps, ps)
+        if need[2]:
+            dbt = hip.dot(dlogits)
+            if a != 1.0:
+                dbt = dbt * a
+        if mix:
+            dtaps = hip.upconv_taps_bwd(dlogits, B, G, ps, k)  # gradient w.r.t. taps of `extra` (unscaled)
+            w2 = _c(conv_w).view(Cc, k * k)
+            if need[0]:
+                hip.gemm(hip.NT, Mrows, Cc, k * k, dtaps, k * k, w2, k * k, dtok, Cc, residual=dtok, ldr=Cc, alpha=r, c_map=amap)
+            if need[3]:
+                dcw = torch.empty((Cc, k * k), device=dlogits.device, dtype=torch.float32)
+                hip.gemm(hip.TN, Cc, k * k, Mrows, tokens.view(B * T, Cc), Cc, dtaps, k * k, dcw, k * k, alpha=r, a_map=amap)
+                dcw = dcw.view(1, Cc, k, k)
+            if need[4]:
+                dcb = hip.dot(dlogits) * r
+            if mix == 2 and need[5]:
+                dratio = (hip.dot(dlogits, extra) - hip.dot(dlogits, tconv)).view(())
+        if dtok is not None:
+            dtok = dtok.view(B, T, Cc)
+        return dtok, dwt, dbt, dcw, dcb, dratio, None, None, None
+
+
+class DiceCELossFn(Fn):
+    """monai DiceCELoss(sigmoid=True, lambda_dice, lambda_ce) for one channel; also yields the integer confusion counts."""
+
+    @staticmethod
+    def forward(ctx, logits, target, lambda_dice, lambda_ce, threshold):
+        logits, target = _c(logits), _c(target)
+        B = logits.shape[0]
+        N = logits[0].numel()
+        fsum, isum, _ = hip.dicece_stats(logits, target, threshold)
+        ctx.save_for_backward(logits, target, fsum)
+        ctx.lam = (lambda_dice, lambda_ce)
+        snr = sdr = 1e-5
+        dice = (1.0 - (2.0 * fsum[:, 0] + snr) / (fsum[:, 1] + fsum[:, 2] + sdr)).mean()
+        bce = fsum[:, 3].sum() / (B * N)
+        loss = (lambda_dice * dice + lambda_ce * bce).to(torch.float32)
+        ctx.mark_non_differentiable(isum)
+        return loss, isum
+
+    @staticmethod
+    def backward(ctx, dloss, _disum):
+        logits, target, fsum = ctx.saved_tensors
+        gs = _c(dloss.to(torch.float32)).view(1)
+        dl = hip.dicece_bwd(logits, target, fsum, ctx.lam[0], ctx.lam[1], 1e-5, 1e-5, gs)
+        return dl, None, None, None, None
