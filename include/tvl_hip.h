@@ -33,7 +33,7 @@ int tvl_abi_version(void);
 typedef struct { int32_t div, mul, off; } tvlRowMap;
 
 enum { TVL_NT = 0, TVL_NN = 1, TVL_TN = 2 };
-enum { TVL_ACT_NONE = 0, TVL_ACT_QUICK_GELU = 1, TVL_ACT_RELU = 2 };
+enum { TVL_ACT_NONE = 0, TVL_ACT_QUICK_GELU = 1, TVL_ACT_RELU = 2, TVL_ACT_SIGMOID = 3 };
 
 /*
  * C = epilogue(alpha * op(A) . op(B)), exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -109,6 +109,9 @@ int tvl_vision_assemble(const float* patch, const float* cls, const float* pos, 
 /* out[b,t,:] = (map[t] >= 0 ? table[ids[b*L + map[t]]] : ctx[b*ctx_bs + (-map[t]-1)*D]) + pos[t]  (ids int64) */
 int tvl_text_assemble(const int64_t* ids, int32_t L, const int32_t* map, const float* table, const float* ctx, int64_t ctx_bs,
                       const float* pos, float* out, int32_t B, int32_t T, int32_t D, tvlStream_t stream);
+/* out[b,t,:] = map[t] >= 0 ? x[b, map[t], :] : ctx[b*ctx_bs + (-map[t]-1)*D ...]   (x: [B, L, D]) */
+int tvl_splice_rows(const float* x, int32_t L, const int32_t* map, const float* ctx, int64_t ctx_bs, float* out,
+                    int32_t B, int32_t T, int32_t D, tvlStream_t stream);
 /* x[b, row0+j, :] = src[b*src_bs + j*D ...]  for j < n  (src_bs = 0: broadcast one [n,D] block over the batch) */
 int tvl_rows_overwrite(float* x, const float* src, int64_t src_bs, int32_t B, int32_t T, int32_t D, int32_t row0, int32_t n, tvlStream_t stream);
 /* dst[(b*dst_bs) + j*D + c] (+)= sum_b? g[b, row0+j, c]; reduce_batch != 0 sums over b into one [n,D] block;
@@ -164,6 +167,11 @@ int tvl_fill(float* p, float val, int64_t n, tvlStream_t stream);
 int tvl_axpby(const float* x, float a, float* y, float b, int64_t n, tvlStream_t stream);
 /* y[r,c] = act(x[r,c]) or dact: y = dy * act'(x) */
 int tvl_bias_act(const float* x, const float* bias, float* y, int64_t rows, int32_t cols, int32_t act, tvlStream_t stream);
+/* out = dy * act'(pre) */
+int tvl_dact_mul(const float* dy, const float* pre, float* out, int64_t n, int32_t act, tvlStream_t stream);
+/* CoCoOp shifted context (reference cocoop_context_learner.py:50-58): out[b,j,:] = bias[b,:] + cvec[j,:] and its gradients */
+int tvl_outer_add(const float* bias, const float* cvec, float* out, int32_t B, int32_t n, int32_t D, tvlStream_t stream);
+int tvl_outer_add_bwd(const float* dout, float* dbias, float* dcvec, int32_t B, int32_t n, int32_t D, tvlStream_t stream);
 /* l2-normalise rows: y = x / ||x|| ; bwd */
 int tvl_l2norm_fwd(const float* x, float* y, float* inv_norm, int32_t rows, int32_t cols, tvlStream_t stream);
 int tvl_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int32_t rows, int32_t cols, tvlStream_t stream);

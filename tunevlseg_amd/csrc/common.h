@@ -59,10 +59,19 @@ __device__ __forceinline__ float quick_gelu_grad_f(float z) {
 __device__ __forceinline__ float act_f(float v, int act) {
     if (act == TVL_ACT_QUICK_GELU) return quick_gelu_f(v);
     if (act == TVL_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == TVL_ACT_SIGMOID) {
+        const float e = expf(-fabsf(v));
+        return (v >= 0.f ? 1.0f : e) / (1.0f + e);
+    }
     return v;
 }
 __device__ __forceinline__ float dact_f(float z, int act) {
     if (act == TVL_ACT_QUICK_GELU) return quick_gelu_grad_f(z);
     if (act == TVL_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == TVL_ACT_SIGMOID) {
+        const float e = expf(-fabsf(z));
+        const float s = (z >= 0.f ? 1.0f : e) / (1.0f + e);
+        return s * (1.0f - s);
+    }
     return 1.f;
 }

@@ -70,6 +70,19 @@ __global__ void text_assemble_kernel(const long long* __restrict__ ids, int L, c
     }
 }
 
+// ---- generic row splice (API-compat learner.forward paths) -----------------------------------
+__global__ void splice_rows_kernel(const float* __restrict__ x, int L, const int* __restrict__ map, const float* __restrict__ ctx, long ctx_bs,
+                                   float* __restrict__ out, int B, int T, int D) {
+    const long total = (long)B * T * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const long bt = i / D;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const int mp = map[t];
+        out[i] = mp >= 0 ? x[((long)b * L + mp) * D + c] : ctx[b * ctx_bs + (long)(-mp - 1) * D + c];
+    }
+}
+
 // ---- in-place row overwrite / its gradient --------------------------------------------------
 __global__ void rows_overwrite_kernel(float* __restrict__ x, const float* __restrict__ src, long src_bs, int B, int T, int D, int row0, int n) {
     const long total = (long)B * n * D;
@@ -252,6 +265,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     if (rg == 0 && c < cols) atomicAdd(&out[c], (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]));
 }
 
+__global__ void dact_mul_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ out, long n, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = dy[i] * dact_f(pre[i], act);
+}
+// out[b,j,:] = bias[b,:] + cvec[j,:]
+__global__ void outer_add_kernel(const float* __restrict__ bias, const float* __restrict__ cvec, float* __restrict__ out, int B, int n, int D) {
+    const long total = (long)B * n * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D), j = (int)((i / D) % n), b = (int)(i / ((long)D * n));
+        out[i] = bias[(long)b * D + c] + cvec[(long)j * D + c];
+    }
+}
+// dbias[b,:] = sum_j dout[b,j,:] ; dcvec[j,:] = sum_b dout[b,j,:]
+__global__ void outer_add_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dbias, float* __restrict__ dcvec, int B, int n, int D) {
+    const long total = (long)(B + n) * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const int row = (int)(i / D);
+        float acc = 0.f;
+        if (row < B) {
+            for (int j = 0; j < n; ++j) acc += dout[((long)row * n + j) * D + c];
+            dbias[(long)row * D + c] = acc;
+        } else {
+            const int j = row - B;
+            for (int b = 0; b < B; ++b) acc += dout[((long)b * n + j) * D + c];
+            dcvec[(long)j * D + c] = acc;
+        }
+    }
+}
+
 // out[0] (+)= sum_i x[i]*y[i]  (double accumulation inside the block, one float atomic per block)
 __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, long n) {
     __shared__ double s[4];
@@ -426,5 +468,32 @@ extern "C" int tvl_dot(const float* x, const float* y, float* out, int64_t n, in
     if (grid > 512) grid = 512;
     hipLaunchKernelGGL(dot_kernel, dim3((unsigned)grid), dim3(256), 0, S_(stream), x, y, out, (long)n);
     TVL_LAUNCH_CHECK("tvl_dot");
+    return 0;
+}
+
+extern "C" int tvl_dact_mul(const float* dy, const float* pre, float* out, int64_t n, int32_t act, tvlStream_t stream) {
+    TVL_REQUIRE(dy && pre && out && n > 0, "tvl_dact_mul: bad arguments");
+    hipLaunchKernelGGL(dact_mul_kernel, GRID_FOR((long)n), dim3(256), 0, S_(stream), dy, pre, out, (long)n, act);
+    TVL_LAUNCH_CHECK("tvl_dact_mul");
+    return 0;
+}
+extern "C" int tvl_outer_add(const float* bias, const float* cvec, float* out, int32_t B, int32_t n, int32_t D, tvlStream_t stream) {
+    TVL_REQUIRE(bias && cvec && out && B > 0 && n > 0 && D > 0, "tvl_outer_add: bad arguments");
+    hipLaunchKernelGGL(outer_add_kernel, GRID_FOR((long)B * n * D), dim3(256), 0, S_(stream), bias, cvec, out, B, n, D);
+    TVL_LAUNCH_CHECK("tvl_outer_add");
+    return 0;
+}
+extern "C" int tvl_outer_add_bwd(const float* dout, float* dbias, float* dcvec, int32_t B, int32_t n, int32_t D, tvlStream_t stream) {
+    TVL_REQUIRE(dout && dbias && dcvec && B > 0 && n > 0 && D > 0, "tvl_outer_add_bwd: bad arguments");
+    hipLaunchKernelGGL(outer_add_bwd_kernel, GRID_FOR((long)(B + n) * D), dim3(256), 0, S_(stream), dout, dbias, dcvec, B, n, D);
+    TVL_LAUNCH_CHECK("tvl_outer_add_bwd");
+    return 0;
+}
+
+extern "C" int tvl_splice_rows(const float* x, int32_t L, const int32_t* map, const float* ctx, int64_t ctx_bs, float* out, int32_t B,
+                               int32_t T, int32_t D, tvlStream_t stream) {
+    TVL_REQUIRE(x && map && ctx && out && B > 0 && T > 0 && D > 0 && L > 0, "tvl_splice_rows: bad arguments");
+    hipLaunchKernelGGL(splice_rows_kernel, GRID_FOR((long)B * T * D), dim3(256), 0, S_(stream), x, L, map, ctx, (long)ctx_bs, out, B, T, D);
+    TVL_LAUNCH_CHECK("tvl_splice_rows");
     return 0;
 }

@@ -1,0 +1,100 @@
+"""Data-parallel plumbing: one process per GPU, ``torch.distributed`` over RCCL (xGMI) or gloo (CPU tests).
+
+The reference gets DDP from Lightning (``configs/trainer/ddp.yaml:4-9``): every rank runs the same
+net on ``batch_size // world_size`` samples and the gradients of the *trainable* parameters are
+averaged.  Here that is ONE all-reduce per optimiser step over ONE flat fp32 buffer that aliases
+every trainable gradient (9 K floats for VPT-10 ... 772 K for MaPLe depth 9 -- latency-bound, so a
+single small collective instead of per-parameter buckets).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> tuple[int, int, int]:
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_distributed(device_type: str = "cuda") -> tuple[int, int, int]:
+    """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if device_type == "cuda" else "gloo"
+        if device_type == "cuda":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def per_device_batch_size(global_batch_size: int, world: int) -> int:
+    """``data.batch_size`` is the GLOBAL batch (reference image_text_mask_datamodule.py:40-47)."""
+    if global_batch_size % world != 0:
+        raise ValueError(f"Batch size ({global_batch_size}) is not divisible by the number of devices ({world}).")
+    return global_batch_size // world
+
+
+class FlatParams:
+    """Re-homes the trainable parameters (and their ``.grad``) into two contiguous fp32 buffers.
+
+    ``p.data`` / ``p.grad`` become views, so autograd accumulates straight into the flat gradient,
+    one all-reduce covers everything, and the fused AdamW kernel updates all parameters in one launch.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.data = torch.empty(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.data[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.data[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            self.offsets.append((off, k))
+            off += k
+        self.numel = n
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+        for p, (off, k) in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + k].view(p.shape)
+
+    def allreduce_grads(self) -> float:
+        """SUM all-reduce of the flat gradient; returns the scale (1/world) the optimiser must apply."""
+        w = world_size()
+        if w > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+        return 1.0 / w
+
+
+def allreduce_counts(counts: torch.Tensor) -> torch.Tensor:
+    """Integer confusion counts: exact SUM across ranks (torchmetrics JaccardIndex state sync)."""
+    if world_size() > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    return counts
+
+
+def allgather_cat(values: torch.Tensor) -> torch.Tensor:
+    """Per-sample values gathered over ranks (torchmetrics Dice(average='samples') 'cat' state sync)."""
+    w = world_size()
+    if w == 1:
+        return values
+    out = [torch.empty_like(values) for _ in range(w)]
+    dist.all_gather(out, values.contiguous())
+    return torch.cat(out)

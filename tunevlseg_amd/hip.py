@@ -17,8 +17,8 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libtvl_hip.so"
 
 NT, NN, TN = 0, 1, 2
-ACT_NONE, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2
-ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "quick_gelu": ACT_QUICK_GELU, "relu": ACT_RELU}
+ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "quick_gelu": ACT_QUICK_GELU, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID}
 
 
 class RowMap(C.Structure):
@@ -82,6 +82,7 @@ _SIGS = {
     "tvl_im2col_patch": [_P, _P, _I, _I, _I, _I, _I],
     "tvl_vision_assemble": [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I],
     "tvl_text_assemble": [_P, _I, _P, _P, _P, _L, _P, _P, _I, _I, _I],
+    "tvl_splice_rows": [_P, _I, _P, _P, _L, _P, _I, _I, _I],
     "tvl_rows_overwrite": [_P, _P, _L, _I, _I, _I, _I, _I],
     "tvl_rows_grad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I],
     "tvl_gather_rows": [_P, _P, _P, _I, _I, _I],
@@ -98,6 +99,9 @@ _SIGS = {
     "tvl_fill": [_P, _F, _L],
     "tvl_axpby": [_P, _F, _P, _F, _L],
     "tvl_bias_act": [_P, _P, _P, _L, _I, _I],
+    "tvl_dact_mul": [_P, _P, _P, _L, _I],
+    "tvl_outer_add": [_P, _P, _P, _I, _I, _I],
+    "tvl_outer_add_bwd": [_P, _P, _P, _I, _I, _I],
     "tvl_l2norm_fwd": [_P, _P, _P, _I, _I],
     "tvl_l2norm_bwd": [_P, _P, _P, _P, _I, _I],
     "tvl_dot": [_P, _P, _P, _L, _I],
@@ -397,4 +401,34 @@ def colsum(x2d, out=None, accumulate=False):
     if out is None:
         out = torch.empty(x2d.shape[1], device=x2d.device, dtype=torch.float32)
     _call("tvl_colsum", _p(x2d), _p(out), x2d.shape[0], x2d.shape[1], int(accumulate))
+    return out
+
+
+def dact_mul(dy2d, pre, act: int):
+    out = torch.empty_like(dy2d)
+    _call("tvl_dact_mul", _p(dy2d), _p(pre), _p(out), dy2d.numel(), act)
+    return out
+
+
+def outer_add(bias, cvec):
+    B, D = bias.shape
+    n = cvec.shape[0]
+    out = torch.empty((B, n, D), device=bias.device, dtype=torch.float32)
+    _call("tvl_outer_add", _p(bias), _p(cvec), _p(out), B, n, D)
+    return out
+
+
+def outer_add_bwd(dout):
+    B, n, D = dout.shape
+    dbias = torch.empty((B, D), device=dout.device, dtype=torch.float32)
+    dc = torch.empty((n, D), device=dout.device, dtype=torch.float32)
+    _call("tvl_outer_add_bwd", _p(dout), _p(dbias), _p(dc), B, n, D)
+    return dbias, dc
+
+
+def splice_rows(x, tmap, ctx, ctx_bs: int):
+    B, L, D = x.shape
+    T = tmap.shape[0]
+    out = torch.empty((B, T, D), device=x.device, dtype=torch.float32)
+    _call("tvl_splice_rows", _p(x), L, _p(tmap, torch.int32), _p(ctx), ctx_bs, _p(out), B, T, D)
     return out

@@ -1,0 +1,274 @@
+"""Prompt learners with the reference's public surface
+(reference ``src/models/core_models/coop/context_learner/*.py``).
+
+Same class names, constructor keywords, attributes (``context_vectors``, ``num_context``,
+``context_dim``, ``prompt_depth``, ``projection_layers``), methods and ``state_dict`` keys.  The
+``nn.Linear`` / ``nn.LayerNorm`` objects inside ``projection_layers`` are parameter holders only:
+their math runs through the HIP ops of ``tunevlseg_amd.ops``.
+"""
+from __future__ import annotations
+
+import itertools
+from abc import ABC, abstractmethod
+from collections.abc import Iterable, Sequence
+from typing import Final, Literal
+
+import torch
+from torch import nn
+
+from .. import hip, ops
+
+
+def run_projection(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """Evaluate an ``nn.Linear`` / ``nn.Sequential(Linear, ReLU, ..., LayerNorm)`` holder with HIP kernels."""
+    layers = [module] if isinstance(module, nn.Linear) else list(module)
+    i = 0
+    while i < len(layers):
+        m = layers[i]
+        if isinstance(m, nn.Linear):
+            act = hip.ACT_NONE
+            if i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
+                act = hip.ACT_RELU
+                i += 1
+            x = ops.linear(x, m.weight, m.bias, act)
+        elif isinstance(m, nn.LayerNorm):
+            x = ops.layer_norm(x, m.weight, m.bias, m.eps)
+        else:  # pragma: no cover
+            raise TypeError(f"unsupported projection layer {type(m).__name__}")
+        i += 1
+    return x
+
+
+class BaseUnimodalLearner(nn.Module, ABC):
+    """reference ``base_unimodal_learner.py:17-99``"""
+
+    MIN_PROMPT_DEPTH: Final = 1
+
+    def __init__(self, *, max_network_depth: int, prompt_depth: int = MIN_PROMPT_DEPTH, num_context: int | None = None,
+                 context_dim: int | None = None, context_initializer: str | list[str] | None = None, tokenizer=None,
+                 embedding_layer=None, vector_std: float = 0.02, **kwargs) -> None:
+        self.verify_prompt_depth(prompt_depth=prompt_depth, max_network_depth=max_network_depth)
+        context_vectors = self.get_context_vectors(
+            num_context=num_context, context_dim=context_dim, context_initializer=context_initializer, tokenizer=tokenizer,
+            embedding_layer=embedding_layer, prompt_depth=prompt_depth, vector_std=vector_std)
+        if context_vectors.ndim != 3:
+            raise ValueError("The number of dimensions of `context_vectors` must be 3")
+        generated_prompt_depth, num_context, context_dim = context_vectors.shape
+        if generated_prompt_depth != prompt_depth:
+            raise ValueError("The number of rows of `context_vectors` must be `prompt_depth`")
+        super().__init__()
+        self.prompt_depth = prompt_depth
+        self.num_context = num_context
+        self.context_dim = context_dim
+        self.context_vectors = nn.Parameter(context_vectors.detach().clone().to(torch.float32))
+
+    @classmethod
+    def verify_prompt_depth(cls, prompt_depth: int, max_network_depth: int) -> None:
+        if prompt_depth < cls.MIN_PROMPT_DEPTH:
+            raise ValueError(f"{prompt_depth=} must be at least {cls.MIN_PROMPT_DEPTH=}")
+        if prompt_depth > max_network_depth:
+            raise ValueError(f"{prompt_depth=} must be at most {max_network_depth=} for the used network.")
+
+    @staticmethod
+    def init_random_context_vectors(shape: Sequence[int], std: float = 0.02) -> torch.Tensor:
+        context_vectors = torch.empty(tuple(shape))
+        nn.init.normal_(context_vectors, std=std)
+        return context_vectors
+
+    @abstractmethod
+    def get_context_vectors(self, num_context=None, context_dim=None, prompt_depth: int = MIN_PROMPT_DEPTH,
+                            context_initializer=None, tokenizer=None, embedding_layer=None, vector_std: float = 0.02) -> torch.Tensor: ...
+
+
+class BaseVisualLearner(BaseUnimodalLearner):
+    """reference ``base_visual_learner.py:12-23``"""
+
+    @abstractmethod
+    def get_visual_context(self, in_context: torch.Tensor | None = None, index: int = 0) -> torch.Tensor: ...
+
+    def mutate_image_hidden_states(self, hidden_states: torch.Tensor, index: int) -> torch.Tensor:
+        # hidden_states[:, -num_context:] = visual context, in place
+        return ops.RowsOverwriteFn.apply(hidden_states, self.get_visual_context(index=index), hidden_states.shape[1] - self.num_context)
+
+
+class VPTContextLearner(BaseVisualLearner):
+    """reference ``vpt_context_learner.py:15-64``"""
+
+    def __init__(self, **kwargs) -> None:
+        kwargs["context_initializer"] = None
+        kwargs["tokenizer"] = None
+        kwargs["embedding_layer"] = None
+        super().__init__(**kwargs)
+
+    def get_context_vectors(self, num_context=None, context_dim=None, prompt_depth: int = BaseVisualLearner.MIN_PROMPT_DEPTH,
+                            context_initializer=None, tokenizer=None, embedding_layer=None, vector_std: float = 0.02) -> torch.Tensor:
+        if num_context is None or context_dim is None:
+            raise ValueError("`num_context` and `context_dim` must be specified for VPT")
+        return self.init_random_context_vectors((prompt_depth, num_context, context_dim), std=vector_std)
+
+    def get_visual_context(self, in_context: torch.Tensor | None = None, index: int = 0) -> torch.Tensor:
+        return self.context_vectors[index]
+
+    def forward(self, *, input_embeddings: torch.Tensor, max_length: int | None = None, image_features=None,
+                context_vectors: torch.Tensor | None = None, index: int = 0) -> torch.Tensor:
+        if context_vectors is None:
+            context_vectors = self.context_vectors[index]
+        return ops.concat_rows(input_embeddings, context_vectors)
+
+
+class CoOpContextLearner(BaseUnimodalLearner):
+    """reference ``coop_context_learner.py:15-181``"""
+
+    def get_context_vectors(self, num_context=None, context_dim=None, prompt_depth: int = BaseUnimodalLearner.MIN_PROMPT_DEPTH,
+                            context_initializer=None, tokenizer=None, embedding_layer=None, vector_std: float = 0.02) -> torch.Tensor:
+        if context_initializer is None:
+            if num_context is None or context_dim is None:
+                raise ValueError("`num_context` and `context_dim` must be specified if `context_initializer` is None")
+            return self.init_random_context_vectors((prompt_depth, num_context, context_dim), std=vector_std)
+        if tokenizer is None or embedding_layer is None:
+            raise ValueError("If `context_initializer` is not None, `tokenizer` and `embedding_layer` must be specified")
+        truncated = context_initializer if isinstance(context_initializer, str) else context_initializer[:prompt_depth]
+        initialized = self.get_context_vectors_from_initializer(truncated, embedding_layer, tokenizer)
+        initialized_depth, num_context, context_dim = initialized.shape
+        remaining = prompt_depth - initialized_depth
+        if remaining == 0:
+            return initialized
+        random_vectors = self.init_random_context_vectors((remaining, num_context, context_dim), std=vector_std)
+        return torch.cat((initialized.cpu(), random_vectors))
+
+    @staticmethod
+    def get_context_vectors_from_initializer(context_initializer, embedding_layer, tokenizer) -> torch.Tensor:
+        input_ids = tokenizer(context_initializer, return_tensors="pt", return_attention_mask=False, truncation=True,
+                              add_special_tokens=False).input_ids
+        with torch.no_grad():
+            w = getattr(embedding_layer, "weight", None)
+            if w is not None:
+                input_ids = input_ids.to(w.device)
+            return embedding_layer(input_ids)
+
+    def _update_mask_for_context(self, mask: torch.Tensor, constructor: Literal["zeros", "ones"], max_length: int | None = None):
+        extra = getattr(torch, constructor)(mask.shape[0], self.num_context, dtype=mask.dtype, device=mask.device)
+        return torch.cat((extra, mask), dim=1)[:, :max_length]
+
+    def update_attention_mask_for_context(self, attention_mask: torch.Tensor, max_length: int | None = None) -> torch.Tensor:
+        return self._update_mask_for_context(attention_mask, "ones", max_length)
+
+    def update_pad_mask_for_context(self, pad_mask: torch.Tensor, max_length: int | None = None) -> torch.Tensor:
+        return self._update_mask_for_context(pad_mask, "zeros", max_length)
+
+    def get_textual_context(self, in_context: torch.Tensor | None = None, image_features: torch.Tensor | None = None,
+                            index: int = 0) -> torch.Tensor:
+        return self.context_vectors[index]
+
+    def mutate_text_hidden_states(self, hidden_states: torch.Tensor, index: int, image_features: torch.Tensor | None = None):
+        # hidden_states[:, 1:num_context+1] = textual context, in place
+        return ops.RowsOverwriteFn.apply(hidden_states, self.get_textual_context(image_features=image_features, index=index), 1)
+
+    def splice_map(self, seq_len: int, max_length: int | None) -> list[int]:
+        """Row map of ``forward``: entry >= 0 = source token position, -(j+1) = context vector j."""
+        n = self.num_context
+        last_idx = -1 if max_length is None else min(max_length - n, seq_len) - 1
+        mid = list(range(seq_len))[1:last_idx]
+        return [0, *[-(j + 1) for j in range(n)], *mid, seq_len - 1]
+
+    def forward(self, *, input_embeddings: torch.Tensor, max_length: int | None = None, image_features: torch.Tensor | None = None,
+                context_vectors: torch.Tensor | None = None, index: int = 0) -> torch.Tensor:
+        if context_vectors is None:
+            context_vectors = self.get_textual_context(image_features=image_features, index=index)
+        return ops.splice_rows(input_embeddings, context_vectors, self.splice_map(input_embeddings.size(1), max_length))
+
+
+class BaseProjectorLearner(CoOpContextLearner):
+    """reference ``base_projector_learner.py:10-139``"""
+
+    def __init__(self, *, proj_in_dim: int | None, proj_out_dim: int | None, prompt_depth: int = CoOpContextLearner.MIN_PROMPT_DEPTH,
+                 use_unified_projection: bool = True, intermediate_dim: int | Iterable[int] | None = None, use_proj_norm: bool = False,
+                 use_lora_proj: bool = False, use_final_bias: bool = True, **kwargs) -> None:
+        if use_lora_proj and intermediate_dim is not None and not isinstance(intermediate_dim, int):
+            raise ValueError("Lora projection is only available for a single layer.")
+        super().__init__(prompt_depth=prompt_depth, **kwargs)
+        init_kwargs = {
+            "in_dim": proj_in_dim if proj_in_dim is not None else self.context_dim,
+            "out_dim": proj_out_dim if proj_out_dim is not None else self.context_dim,
+            "intermediate_dim": intermediate_dim,
+            "use_final_norm": use_proj_norm,
+            "use_final_bias": use_final_bias,
+        }
+        getter = self.get_lora_projection if use_lora_proj and intermediate_dim is not None else self.get_mlp_projection
+        self.projection_layers = nn.ModuleList(
+            (getter(**init_kwargs),) * prompt_depth if use_unified_projection else (getter(**init_kwargs) for _ in range(prompt_depth)))
+
+    def get_transformed_context(self, in_context: torch.Tensor | None = None, index: int = 0) -> torch.Tensor:
+        if in_context is None:
+            in_context = self.context_vectors[index]
+        return run_projection(self.projection_layers[index], in_context)
+
+    @staticmethod
+    def get_lora_projection(in_dim: int, out_dim: int, intermediate_dim: int, use_final_norm: bool, use_final_bias: bool = True) -> nn.Sequential:
+        layers = nn.Sequential()
+        min_dim = min(out_dim, intermediate_dim)
+        layers.append(nn.Linear(in_dim, min_dim, bias=False))
+        if intermediate_dim <= out_dim:
+            layers.append(nn.Linear(intermediate_dim, out_dim, bias=(not use_final_norm) and use_final_bias))
+        if use_final_norm:
+            layers.append(nn.LayerNorm(out_dim, bias=use_final_bias))
+        return layers
+
+    @staticmethod
+    def get_mlp_projection(in_dim: int, out_dim: int, intermediate_dim, use_final_norm: bool, use_final_bias: bool = True):
+        if intermediate_dim is None:
+            return nn.Linear(in_dim, out_dim)
+        intermediate_dim = (intermediate_dim,) if isinstance(intermediate_dim, int) else tuple(intermediate_dim)
+        layers = nn.Sequential(nn.Linear(in_dim, intermediate_dim[0]), nn.ReLU(inplace=True))
+        for i, o in itertools.pairwise(intermediate_dim):
+            layers.extend((nn.Linear(i, o), nn.ReLU(inplace=True)))
+        for layer in layers:
+            if isinstance(layer, nn.Linear):
+                nn.init.kaiming_normal_(layer.weight.data, nonlinearity="relu")
+        layers.append(nn.Linear(intermediate_dim[-1], out_dim, bias=(not use_final_norm) and use_final_bias))
+        if use_final_norm:
+            layers.append(nn.LayerNorm(out_dim, bias=use_final_bias))
+        return layers
+
+
+class CoCoOpContextLearner(BaseProjectorLearner):
+    """reference ``cocoop_context_learner.py:7-77``"""
+
+    def __init__(self, *, visual_dim: int, norm_image_features: bool = True, **kwargs) -> None:
+        kwargs["proj_in_dim"] = visual_dim
+        kwargs["proj_out_dim"] = None
+        kwargs["use_final_bias"] = False
+        super().__init__(**kwargs)
+        self.norm_image_features = norm_image_features
+        self.image_features_normalizer_or_identity = self._normalize_features if norm_image_features else nn.Identity()
+
+    @staticmethod
+    def _normalize_features(features: torch.Tensor, p="fro", dim: int = -1) -> torch.Tensor:
+        return ops.L2NormFn.apply(features)
+
+    def get_textual_context(self, in_context: torch.Tensor | None = None, image_features: torch.Tensor | None = None,
+                            index: int = 0) -> torch.Tensor:
+        if image_features is None:
+            raise ValueError("`image_features` must be provided when `context_vectors` is None for CoCoOp")
+        image_features = self.image_features_normalizer_or_identity(image_features)
+        bias = self.get_transformed_context(image_features, index)  # (batch, context_dim)
+        if in_context is None:
+            in_context = self.context_vectors[index]
+        return ops.OuterAddFn.apply(bias, in_context)  # (batch, num_context, context_dim)
+
+    def forward(self, *, input_embeddings: torch.Tensor, max_length: int | None = None, image_features: torch.Tensor | None = None,
+                context_vectors: torch.Tensor | None = None, index: int = 0) -> torch.Tensor:
+        context_vectors = self.get_textual_context(in_context=context_vectors, image_features=image_features, index=index)
+        return super().forward(input_embeddings=input_embeddings, max_length=max_length, context_vectors=context_vectors)
+
+
+class MapleContextLearner(BaseProjectorLearner, BaseVisualLearner):
+    """reference ``maple_context_learner.py:7-20``"""
+
+    def __init__(self, *, visual_dim: int, **kwargs) -> None:
+        kwargs["proj_in_dim"] = None
+        kwargs["proj_out_dim"] = visual_dim
+        super().__init__(**kwargs)
+
+    def get_visual_context(self, *args, **kwargs) -> torch.Tensor:
+        return self.get_transformed_context(*args, **kwargs)

@@ -1,0 +1,47 @@
+"""reference ``src/models/core_models/coop/base_multimodal_clipseg.py:21-629`` and ``maple_clipseg.py:11-25``"""
+from __future__ import annotations
+
+import torch
+
+from . import towers
+from .base_clipseg import BaseCLIPSeg
+from .hf_clipseg_wrapper import SegOutput
+
+
+class BaseMultimodalCLIPSeg(BaseCLIPSeg):
+    def get_vision_outputs(self, pixel_values: torch.Tensor):
+        acts, _ = towers.vision_tower(self.model, pixel_values, self.context_learner)
+        return acts
+
+    def get_conditional_embeddings(self, batch_size, input_ids, attention_mask):
+        if input_ids is None:
+            raise ValueError("Invalid conditional, should be either provided as `input_ids` or `conditional_pixel_values`")
+        if len(input_ids) != batch_size:
+            raise ValueError("Make sure to pass as many prompt texts as there are query images")
+        return towers.text_tower(self.model, input_ids, attention_mask, self.context_learner)
+
+    def model_forward(self, input_ids=None, pixel_values=None, attention_mask=None, position_ids=None,
+                      conditional_embeddings=None, **_unused) -> SegOutput:
+        if pixel_values is None:
+            raise ValueError("You have to specify pixel_values to use `CLIPSegForImageSegmentation`")
+        # vision first, then text (base_multimodal_clipseg.py:577-596)
+        activations = self.get_vision_outputs(pixel_values)
+        if conditional_embeddings is None:
+            conditional_embeddings = self.get_conditional_embeddings(pixel_values.shape[0], input_ids, attention_mask)
+        elif conditional_embeddings.shape[0] != pixel_values.shape[0]:
+            raise ValueError("Make sure to pass as many conditional embeddings as there are query images in the batch")
+        out = self.decoder_forward(activations, conditional_embeddings)
+        out.conditional_embeddings = conditional_embeddings
+        return out
+
+
+class MapleCLIPSeg(BaseMultimodalCLIPSeg):
+    def __init__(self, context_learner, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        cfg = self.model.config
+        self.context_learner = context_learner(
+            visual_dim=cfg.vision_config.hidden_size,
+            max_network_depth=min(cfg.text_config.num_hidden_layers, cfg.vision_config.num_hidden_layers),
+            context_dim=cfg.text_config.hidden_size,
+            embedding_layer=self.model.clip.text_model.embeddings.token_embedding,
+        )

@@ -1,0 +1,151 @@
+"""The three sub-networks of CLIPSeg, orchestrated over HIP kernels.
+
+Each function restates the *orchestration* the reference keeps in its nets (layer loops, prompt
+splicing, pooling, decoder loop) and issues HIP launches for all arithmetic:
+
+* :func:`vision_tower`  -- reference ``vpt_clipseg.py:36-235`` / ``base_multimodal_clipseg.py:310-484`` (prompt path)
+                           and the HF vision model as used by ``coop_clipseg.py:341-371`` (full path)
+* :func:`text_tower`    -- reference ``coop_clipseg.py:40-339`` / ``base_multimodal_clipseg.py:24-300``;
+                           without a learner: HF ``get_text_features`` (modeling_clipseg.py:594-686)
+* :func:`decoder_tokens` / :func:`seg_head` -- reference ``base_clipseg.py:82-172``, ``vpt_clipseg.py:237-319``,
+                           HF ``CLIPSegDecoder.forward`` (modeling_clipseg.py:549-586)
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import hip, ops
+from ..backbone import CLIPSegBackbone
+
+_ACT = hip.ACT_IDS
+
+
+def patch_embeddings(model: CLIPSegBackbone, pixel_values: torch.Tensor) -> torch.Tensor:
+    """16x16/s16 patch conv as im2col + GEMM (HF:195-197).  Frozen, image carries no grad -> no autograd node."""
+    prep = model.prepared()
+    B, _, H, W = pixel_values.shape
+    ps = prep["patch_size"]
+    if H % ps or W % ps:
+        raise ValueError(f"image size {H}x{W} is not a multiple of the patch size {ps}")
+    with torch.no_grad():
+        cols = hip.im2col_patch(ops._c(pixel_values.to(torch.float32)), ps)
+        patch = hip.linear_fwd(cols, prep["patch_w"])
+    return patch.view(B, (H // ps) * (W // ps), -1)
+
+
+def vision_tower(model: CLIPSegBackbone, pixel_values: torch.Tensor, learner=None, full: bool = False):
+    """Returns ``(activations at extract_layers, pooled)``; ``pooled`` = visual_projection(post_layernorm(CLS)) when ``full``."""
+    cfg = model.config
+    v = cfg.vision_config
+    prep = model.prepared()
+    vm = model.clip.vision_model
+    B, _, H, W = pixel_values.shape
+    patch = patch_embeddings(model, pixel_values)
+    pos = model.vision_pos(H, W)
+    prompts = None
+    depth = 1
+    if learner is not None and not full:
+        prompts = learner.get_visual_context(index=0)
+        depth = learner.prompt_depth
+    x = ops.VisionAssembleFn.apply(patch, vm.embeddings.class_embedding.detach(), pos, prompts)
+    # NB concat happens BEFORE pre_layrnorm (vpt_clipseg.py:178-181)
+    x = ops.layer_norm(x, vm.pre_layrnorm.weight.detach(), vm.pre_layrnorm.bias.detach(), v.layer_norm_eps)
+    spec = ops.AttnSpec(v.num_attention_heads, _ACT[v.hidden_act], v.layer_norm_eps)
+    max_idx = max(model.extract_layers)
+    states = [x]
+    for idx in range(1, v.num_hidden_layers + 1):
+        x = ops.EncoderLayerFn.apply(x, prep["vision_layers"][idx - 1], spec)
+        if prompts is not None and idx < depth:
+            x = learner.mutate_image_hidden_states(x, index=idx)
+        states.append(x)
+        if not full and idx > max_idx:  # "No need to run the vision transformer for more layers" (vpt_clipseg.py:129-131)
+            break
+    acts = tuple(states[i + 1] for i in model.extract_layers)
+    pooled = None
+    if full:
+        cls_idx = torch.zeros(B, dtype=torch.int32, device=x.device)
+        cls = ops.GatherRowsFn.apply(x, cls_idx)
+        cls = ops.layer_norm(cls, vm.post_layernorm.weight.detach(), vm.post_layernorm.bias.detach(), v.layer_norm_eps)
+        pooled = ops.linear(cls, model.clip.visual_projection.weight.detach())
+    return acts, pooled
+
+
+def text_tower(model: CLIPSegBackbone, input_ids: torch.Tensor, attention_mask: torch.Tensor | None, learner=None,
+               image_features: torch.Tensor | None = None) -> torch.Tensor:
+    """``text_projection(pooled EOS state)`` -> [B, projection_dim]."""
+    cfg = model.config
+    t = cfg.text_config
+    prep = model.prepared()
+    tm = model.clip.text_model
+    dev = tm.embeddings.token_embedding.weight.device
+    input_ids = input_ids.view(-1, input_ids.shape[-1]).to(dev)
+    B, L = input_ids.shape
+    n, depth, ctx0 = 0, 1, None
+    if learner is not None:
+        n, depth = learner.num_context, learner.prompt_depth
+        tmap_list = learner.splice_map(L, t.max_position_embeddings)
+        ctx0 = learner.get_textual_context(image_features=image_features, index=0)
+    else:
+        tmap_list = list(range(L))
+    T = len(tmap_list)
+    if T > t.max_position_embeddings:
+        raise ValueError(f"Sequence length must be less than max_position_embeddings (got {T} > {t.max_position_embeddings})")
+    tmap = torch.tensor(tmap_list, dtype=torch.int32, device=dev)
+    x = ops.TextAssembleFn.apply(input_ids.contiguous(), tmap, tm.embeddings.token_embedding.weight.detach(), ctx0,
+                                 tm.embeddings.position_embedding.weight.detach(), n)
+    key_mask = None
+    if attention_mask is not None:
+        am = attention_mask.to(dev)
+        if learner is not None:
+            am = learner.update_attention_mask_for_context(am, t.max_position_embeddings)
+        key_mask = am.to(torch.int32).contiguous()
+    spec = ops.AttnSpec(t.num_attention_heads, _ACT[t.hidden_act], t.layer_norm_eps, causal=True, key_mask=key_mask)
+    for idx in range(1, t.num_hidden_layers + 1):
+        x = ops.EncoderLayerFn.apply(x, prep["text_layers"][idx - 1], spec)
+        if n and idx < depth:
+            x = learner.mutate_text_hidden_states(x, index=idx, image_features=image_features)
+    x = ops.layer_norm(x, tm.final_layer_norm.weight.detach(), tm.final_layer_norm.bias.detach(), t.layer_norm_eps)
+    ids32 = input_ids.to(torch.int)
+    if t.eos_token_id == 2:
+        pre = ids32  # legacy checkpoints: EOT is the highest id in each row (HF:630-642)
+    else:
+        pre = (ids32 == t.eos_token_id).int()
+    pool = torch.clamp(pre.argmax(dim=-1) + n, max=t.max_position_embeddings - 1).to(torch.int32)
+    pooled = ops.GatherRowsFn.apply(x, pool)
+    return ops.linear(pooled, model.clip.text_projection.weight.detach())
+
+
+def decoder_tokens(model: CLIPSegBackbone, activations, conditional_embeddings: torch.Tensor) -> torch.Tensor:
+    """3 x [reduce + running sum; FiLM at conditional_layer; post-LN layer] -> tokens [B, T, reduce_dim]."""
+    cfg = model.config
+    dec = model.decoder
+    prep = model.prepared()
+    spec = ops.AttnSpec(cfg.decoder_num_attention_heads, hip.ACT_RELU, cfg.vision_config.layer_norm_eps)
+    out = None
+    for i, act in enumerate(activations[::-1]):
+        red = dec.reduces[i]
+        out = ops.linear(act, red.weight.detach(), red.bias.detach(), hip.ACT_NONE, out)
+        if i == dec.conditional_layer:
+            mul = ops.linear(conditional_embeddings, dec.film_mul.weight.detach(), dec.film_mul.bias.detach())
+            add = ops.linear(conditional_embeddings, dec.film_add.weight.detach(), dec.film_add.bias.detach())
+            out = ops.FilmFn.apply(out, mul, add)
+        out = ops.DecoderLayerFn.apply(out, prep["decoder_layers"][i], spec)
+    return out
+
+
+def seg_head(model: CLIPSegBackbone, tokens: torch.Tensor, n_strip: int, additive_layer=None, residual_ratio=None, mix: int = 0):
+    """Drop CLS (+ the trailing prompt tokens), ConvTranspose2d, optional new last layer -> logits [B, H, W]."""
+    B, T, _ = tokens.shape
+    N = T - 1 - n_strip
+    G = math.isqrt(N)
+    if G * G != N:
+        raise ValueError(f"{N} patch tokens do not form a square grid")
+    tc = model.decoder.transposed_convolution
+    ps = model.config.vision_config.patch_size
+    if additive_layer is None:
+        mix = 0
+    conv = additive_layer[1] if additive_layer is not None else None
+    return ops.SegHeadFn.apply(tokens, tc.weight, tc.bias, conv.weight if conv is not None else None,
+                               conv.bias if conv is not None else None, residual_ratio, mix, G, ps)

@@ -70,11 +70,13 @@ class EncoderLayerFn(Fn):
         else:
             a, z = hip.linear_fwd(x2, lw.w1, lw.b1, act=spec.act), None
         del x2
-        out = hip.linear_fwd(a, lw.w2, lw.b2, residual=h2)
+        # the result must be a base tensor, not a view: deep prompts overwrite its rows in place afterwards
+        out = torch.empty((B, T, D), device=h.device, dtype=torch.float32)
+        hip.linear_fwd(a, lw.w2, lw.b2, residual=h2, out=out.view(M, D))
         if need:
             ctx.save_for_backward(h2d, mean1, rstd1, qkv, o, lse, h2, mean2, rstd2, z)
             ctx.lw, ctx.spec, ctx.shape = lw, spec, (B, T, D)
-        return out.view(B, T, D)
+        return out
 
     @staticmethod
     def backward(ctx, dout):
@@ -174,8 +176,7 @@ class LinearFn(Fn):
         x2d, W, pre = ctx.saved_tensors
         dy2d = _c(dy).view(-1, W.shape[0])
         if ctx.act != hip.ACT_NONE:
-            # dz = dy * act'(pre): epilogue of an identity-free path -> reuse bias_act-style kernel through the GEMM dact hook
-            dz = _dact_mul(dy2d, pre, ctx.act)
+            dz = hip.dact_mul(dy2d, pre, ctx.act)  # tiny tensors only (meta-nets, FiLM inputs)
         else:
             dz = dy2d
         dx = dW = db = dres = None
@@ -188,13 +189,6 @@ class LinearFn(Fn):
         if ctx.needs_input_grad[4]:
             dres = dy
         return dx, dW, db, None, dres
-
-
-def _dact_mul(dy2d, pre, act):
-    """dy * act'(pre) with the FiLM kernel shape trick avoided: tiny tensors only (meta-nets)."""
-    # One GEMM-free elementwise pass: out = dy * act'(pre).  Expressed with the GEMM epilogue on an identity would
-    # waste FLOPs; these tensors are at most [B*n, 128], so use the dedicated bias_act-derivative kernel.
-    return hip.dact_mul(dy2d, pre, act)
 
 
 def linear(x, W, b=None, act=hip.ACT_NONE, residual=None):
@@ -456,3 +450,47 @@ class DiceCELossFn(Fn):
         gs = _c(dloss.to(torch.float32)).view(1)
         dl = hip.dicece_bwd(logits, target, fsum, ctx.lam[0], ctx.lam[1], 1e-5, 1e-5, gs)
         return dl, None, None, None, None
+
+
+class SpliceRowsFn(Fn):
+    """out[b,t] = x[b, map[t]] or ctx[-map[t]-1]; the API-compatible ``learner.forward`` paths
+    (vpt_context_learner.py:46-64, coop_context_learner.py:136-181).  The nets use the fused assemble kernels instead."""
+
+    @staticmethod
+    def forward(ctx, x, cvec, tmap_list):
+        x, cvec = _c(x), _c(cvec)
+        B, L, D = x.shape
+        n = cvec.shape[-2]
+        per_sample = cvec.dim() == 3
+        tmap = torch.tensor(tmap_list, dtype=torch.int32, device=x.device)
+        ctx.meta = (B, L, D, n, per_sample, tuple(tmap_list))
+        return hip.splice_rows(x, tmap, cvec, n * D if per_sample else 0)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, L, D, n, per_sample, tmap_list = ctx.meta
+        dout = _c(dout)
+        dx = dc = None
+        if ctx.needs_input_grad[0]:
+            inv = [-1] * L
+            for t, m in enumerate(tmap_list):
+                if m >= 0:
+                    inv[m] = t
+            zero = torch.zeros((1, D), device=dout.device, dtype=torch.float32)
+            dx = hip.splice_rows(dout, torch.tensor(inv, dtype=torch.int32, device=dout.device), zero, 0)
+        if ctx.needs_input_grad[1]:
+            rows = [t for t, m in enumerate(tmap_list) if m < 0]
+            if rows != list(range(rows[0], rows[0] + n)) or [tmap_list[t] for t in rows] != [-(j + 1) for j in range(n)]:
+                raise NotImplementedError("context rows must form one contiguous ascending block")
+            dc = torch.empty((B, n, D) if per_sample else (n, D), device=dout.device, dtype=torch.float32)
+            hip.rows_grad(dout, dc, rows[0], n, not per_sample, False)
+        return dx, dc, None
+
+
+def splice_rows(x, cvec, tmap_list):
+    return SpliceRowsFn.apply(x, cvec, list(tmap_list))
+
+
+def concat_rows(x, cvec):
+    L, n = x.shape[1], cvec.shape[-2]
+    return SpliceRowsFn.apply(x, cvec, [*range(L), *[-(j + 1) for j in range(n)]])

@@ -1,0 +1,263 @@
+"""Task module with the reference's ``ImageTextMaskModule`` surface, minus Lightning
+(reference ``src/models/image_text_mask_module.py:23-395``).
+
+``model_step`` / ``get_logits`` / ``get_optim_groups`` / ``configure_optimizers`` / the ``*_step`` methods and the
+metric names (``train_loss``, ``train_dice_step``, ``val_dice``, ``val_iou``, ``val_loss`` ...) are kept.  The loss and
+the metric statistics come from ONE fused HIP pass over logits and mask (``tvl_dicece_stats``).
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Mapping
+
+import torch
+from torch import nn
+
+from . import dist as tdist
+from . import hip, ops
+
+
+class DiceCELoss(nn.Module):
+    """``monai.losses.DiceCELoss`` for the configuration the reference uses (``configs/model/*.yaml:21-25``:
+    ``sigmoid=True, lambda_dice=1, lambda_ce=0.2``; one output channel -> BCE-with-logits as the CE term)."""
+
+    def __init__(self, sigmoid: bool = True, lambda_dice: float = 1.0, lambda_ce: float = 1.0, threshold: float = 0.5, **unsupported):
+        super().__init__()
+        if not sigmoid or any(v for v in unsupported.values()):
+            raise NotImplementedError(f"only DiceCELoss(sigmoid=True, lambda_dice, lambda_ce) is on the hot path, got {unsupported}")
+        self.lambda_dice, self.lambda_ce, self.threshold = float(lambda_dice), float(lambda_ce), float(threshold)
+        self.last_counts: torch.Tensor | None = None  # int64 [B,4] TP/FP/FN/TN of the last call
+
+    def forward(self, logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        loss, counts = ops.DiceCELossFn.apply(logits, target, self.lambda_dice, self.lambda_ce, self.threshold)
+        self.last_counts = counts
+        return loss
+
+
+class SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return hip.bias_act(ops._c(x).view(-1, x.shape[-1]), None, hip.ACT_SIGMOID).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):  # pragma: no cover - predictions are never differentiated in the reference
+        raise NotImplementedError
+
+
+def sigmoid(x: torch.Tensor) -> torch.Tensor:
+    return SigmoidFn.apply(x.detach())
+
+
+class DiceSamples:
+    """``torchmetrics.Dice(threshold, zero_division=1, average="samples")``: mean over samples of 2TP/(2TP+FP+FN)."""
+
+    def __init__(self, zero_division: float = 1.0):
+        self.zero_division = zero_division
+        self.reset()
+
+    def reset(self):
+        self.values: list[torch.Tensor] = []
+
+    def update(self, counts: torch.Tensor):
+        c = counts.to(torch.float64)
+        den = 2 * c[:, 0] + c[:, 1] + c[:, 2]
+        self.values.append(torch.where(den > 0, 2 * c[:, 0] / den.clamp(min=1), torch.full_like(den, self.zero_division)))
+
+    def compute(self) -> float:
+        v = tdist.allgather_cat(torch.cat(self.values))
+        return float(v.mean().item())
+
+
+class JaccardBinary:
+    """``torchmetrics.JaccardIndex(task="binary", threshold, zero_division=1)``: global TP/(TP+FP+FN), int64 state."""
+
+    def __init__(self, zero_division: float = 1.0):
+        self.zero_division = zero_division
+        self.reset()
+
+    def reset(self):
+        self.counts: torch.Tensor | None = None
+
+    def update(self, counts: torch.Tensor):
+        s = counts.sum(0)
+        self.counts = s if self.counts is None else self.counts + s
+
+    def compute(self) -> float:
+        c = tdist.allreduce_counts(self.counts.clone())
+        tp, fp, fn = (float(c[i].item()) for i in range(3))
+        den = tp + fp + fn
+        return tp / den if den > 0 else self.zero_division
+
+
+class ImageTextMaskModule(nn.Module):
+    def __init__(self, net: nn.Module, loss_fn: nn.Module, optimizer: Callable | None = None, scheduler: Callable | None = None,
+                 compile: bool = False, task: str = "binary", threshold: float = 0.5, weight_decay: float = 0.0,
+                 log_image_num: int = 8, lr_scheduler_config: Mapping[str, Any] | None = None,
+                 activation_fn: Callable | None = sigmoid, cache_outputs: bool = False, *args, **kwargs) -> None:
+        super().__init__()
+        if task != "binary":
+            raise NotImplementedError("only task='binary' is used by the reference configs")
+        self.hparams = dict(compile=compile, task=task, threshold=threshold, weight_decay=weight_decay, log_image_num=log_image_num,
+                            lr_scheduler_config=lr_scheduler_config, cache_outputs=cache_outputs)
+        self.net = net
+        self.loss_fn = loss_fn
+        if hasattr(loss_fn, "threshold"):
+            loss_fn.threshold = float(threshold)
+        self.optimizer = optimizer
+        self.scheduler = scheduler
+        self.activation_fn = (lambda x: x) if activation_fn is None else activation_fn
+        self.metrics: dict[str, Any] = {}
+        self.logged: dict[str, float] = {}
+
+    def forward(self, *args, **kwargs) -> torch.Tensor:
+        return self.net(*args, **kwargs)
+
+    def setup(self, stage: str) -> None:
+        """reference ``setup`` (``image_text_mask_module.py:272-302``)."""
+        stages = {"fit": ("train", "val"), "validate": ("val",), "test": ("test",)}.get(stage, ())
+        for s in stages:
+            self.metrics[f"{s}_dice"] = DiceSamples()
+            self.metrics[f"{s}_iou"] = JaccardBinary()
+
+    def get_logits(self, batch: Mapping[str, Any]) -> torch.Tensor:
+        text_input = {k: batch[k] for k in ("input_ids", "attention_mask")}
+        if self.hparams.get("cache_outputs"):
+            text_input["cache_name"] = batch["cache_name"]
+        return self(image_input=batch["image"], text_input=text_input)
+
+    def model_step(self, batch: Mapping[str, Any]):
+        logits = self.get_logits(batch)
+        mask = batch["mask"]
+        loss = self.loss_fn(logits, mask)
+        preds = self.activation_fn(logits)
+        return loss, preds, mask.long()
+
+    def _step(self, stage: str, batch):
+        loss, preds, targets = self.model_step(batch)
+        counts = getattr(self.loss_fn, "last_counts", None)
+        if counts is None:  # foreign loss: statistics from a dedicated pass
+            _, counts, _ = hip.dicece_stats(ops._c(preds.detach()), ops._c(targets.to(torch.float32)), self.hparams["threshold"])
+        if f"{stage}_dice" in self.metrics:
+            self.metrics[f"{stage}_dice"].update(counts)
+            self.metrics[f"{stage}_iou"].update(counts)
+        return loss, preds, targets
+
+    def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        loss, _, _ = self._step("train", batch)
+        return loss
+
+    def validation_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        with torch.no_grad():
+            loss, _, _ = self._step("val", batch)
+        return loss
+
+    def test_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        with torch.no_grad():
+            loss, _, _ = self._step("test", batch)
+        return loss
+
+    def predict_step(self, batch, batch_idx: int = 0):
+        with torch.no_grad():
+            return self.activation_fn(self.get_logits(batch))
+
+    def epoch_metrics(self, stage: str, reset: bool = True) -> dict[str, float]:
+        out = {f"{stage}_dice": self.metrics[f"{stage}_dice"].compute(), f"{stage}_iou": self.metrics[f"{stage}_iou"].compute()}
+        if reset:
+            self.metrics[f"{stage}_dice"].reset()
+            self.metrics[f"{stage}_iou"].reset()
+        return out
+
+    # ---- optimiser groups: reference ``get_optim_groups`` (image_text_mask_module.py:304-361) ----
+    def get_optim_groups(self):
+        if self.hparams["weight_decay"] <= 0:
+            return self.parameters()
+        decay, no_decay = set(), set()
+        whitelist = (nn.Linear, nn.modules.conv._ConvNd)
+        blacklist = (nn.Embedding, nn.GroupNorm, nn.LayerNorm, nn.modules.batchnorm._NormBase)
+        for mn, m in self.named_modules():
+            for pn, _ in m.named_parameters():
+                fpn = f"{mn}.{pn}" if mn else pn
+                if pn.endswith("proj_weight"):
+                    decay.add(fpn)
+                elif pn.endswith("weight"):
+                    if isinstance(m, whitelist):
+                        decay.add(fpn)
+                    elif isinstance(m, blacklist):
+                        no_decay.add(fpn)
+                else:
+                    no_decay.add(fpn)
+        param_dict = dict(self.named_parameters())
+        # frozen backbone tensors live in plain containers (not nn.Linear): they never decay and never train
+        for fpn, p in param_dict.items():
+            if fpn not in decay and fpn not in no_decay:
+                no_decay.add(fpn)
+        inter = decay & no_decay
+        if inter:
+            raise ValueError(f"parameters {inter} made it into both decay/no_decay sets!")
+        return [
+            {"params": [param_dict[pn] for pn in sorted(decay)], "weight_decay": self.hparams["weight_decay"]},
+            {"params": [param_dict[pn] for pn in sorted(no_decay)], "weight_decay": 0.0},
+        ]
+
+    def configure_optimizers(self) -> dict[str, Any]:
+        optimizer = self.optimizer(self.get_optim_groups())
+        if self.scheduler is not None:
+            scheduler = self.scheduler(optimizer=optimizer)
+            return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "monitor": "val_loss", "interval": "epoch",
+                                                             "frequency": 1, **(self.hparams["lr_scheduler_config"] or {})}}
+        return {"optimizer": optimizer}
+
+
+class FusedAdamW:
+    """``torch.optim.AdamW`` semantics over :class:`tunevlseg_amd.dist.FlatParams` (one HIP launch per group per step).
+
+    Parameter groups keep their own ``weight_decay`` (decay / no-decay split of ``get_optim_groups``); frozen
+    parameters passed in by the reference-style ``self.parameters()`` call are skipped, as AdamW skips grad-less ones.
+    """
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        groups = list(params)
+        if groups and not isinstance(groups[0], dict):
+            groups = [{"params": groups}]
+        self.param_groups = []
+        for g in groups:
+            ps = [p for p in g["params"] if p.requires_grad]
+            if not ps:
+                continue
+            flat = tdist.FlatParams(ps)
+            self.param_groups.append({"flat": flat, "params": ps, "lr": g.get("lr", lr), "betas": g.get("betas", betas),
+                                      "eps": g.get("eps", eps), "weight_decay": g.get("weight_decay", weight_decay),
+                                      "m": torch.zeros_like(flat.data), "v": torch.zeros_like(flat.data)})
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        for g in self.param_groups:
+            g["flat"].zero_grad()
+
+    def step(self) -> None:
+        self.step_count += 1
+        for g in self.param_groups:
+            flat = g["flat"]
+            scale = flat.allreduce_grads()  # DDP: SUM over ranks, averaged inside the update kernel
+            hip.adamw(flat.data, flat.grad, g["m"], g["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                      self.step_count, scale)
+
+
+class ReduceLROnPlateau:
+    """``torch.optim.lr_scheduler.ReduceLROnPlateau(mode="min", factor, patience)`` for :class:`FusedAdamW`
+    (reference ``configs/model/vpt_clipseg.yaml:43-48``; threshold 1e-4 rel, as torch's default)."""
+
+    def __init__(self, optimizer, mode: str = "min", factor: float = 0.1, patience: int = 10, threshold: float = 1e-4, min_lr: float = 0.0):
+        if mode != "min":
+            raise NotImplementedError("mode='min' only")
+        self.optimizer, self.factor, self.patience, self.threshold, self.min_lr = optimizer, factor, patience, threshold, min_lr
+        self.best, self.num_bad = float("inf"), 0
+
+    def step(self, metric: float) -> None:
+        if metric < self.best * (1.0 - self.threshold):
+            self.best, self.num_bad = metric, 0
+        else:
+            self.num_bad += 1
+        if self.num_bad > self.patience:
+            for g in self.optimizer.param_groups:
+                g["lr"] = max(g["lr"] * self.factor, self.min_lr)
+            self.num_bad = 0
