@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the prompt-tuning TRAIN STEP (forward + DiceCE + backward + AdamW on the
+prompt parameters) for CLIPSeg ViT-B/16 + VPT-shallow (10 visual prompts), 352x352, bs=32 per GPU
+(BASELINE.json configs[1]); weak scaling over the GPUs of one node (one process per GPU, RCCL).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Synthetic data (images N(0,1), masks U(0,1)>0.7, fixed token rows),
+seeded random weights of the named architecture (no checkpoint is reachable offline).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from functools import partial
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+GFLOP_PER_IMAGE_TRAIN = 167.1  # VPT-10 shallow 352^2, fwd 80.6 + bwd 86.5 (FlopCounterMode on the reference)
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
+
+
+def make_batch(B: int, size: int, seed: int, device):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 3, size, size, generator=g)
+    L = 8
+    ids = torch.full((B, L), 1, dtype=torch.long)
+    am = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n_words = 2 + (b % 4)
+        row = [49406, *torch.randint(320, 40000, (n_words,), generator=g).tolist(), 49407]
+        ids[b, : len(row)] = torch.tensor(row)
+        am[b, : len(row)] = 1
+    mask = (torch.rand(B, 1, size, size, generator=g) > 0.7).float()
+    return {"image": img.to(device), "input_ids": ids.to(device), "attention_mask": am.to(device), "mask": mask.to(device)}
+
+
+def build_module(device, num_context: int = 10, prompt_depth: int = 1, seed: int = 0):
+    from tunevlseg_amd import nets
+    from tunevlseg_amd.nets.context_learner import VPTContextLearner
+    from tunevlseg_amd.task import DiceCELoss, FusedAdamW, ImageTextMaskModule
+
+    torch.manual_seed(12345)  # configs/experiment/coop/clipseg.yaml:19
+    net = nets.VPTCLIPSeg(
+        context_learner=partial(VPTContextLearner, prompt_depth=prompt_depth, num_context=num_context, vector_std=0.02),
+        model_cfg={"pretrained_model_name_or_path": f"random:rd64:seed={seed}", "freeze_encoder": False, "freeze_decoder": False},
+        freeze_all=True, no_freeze_last_layer=False, use_new_last_layer=False)  # authors' setting (scripts/schedule_vpt.sh:14,21)
+    module = ImageTextMaskModule(net=net, loss_fn=DiceCELoss(sigmoid=True, lambda_dice=1, lambda_ce=0.2),
+                                 optimizer=partial(FusedAdamW, lr=2e-4), scheduler=None, compile=False, task="binary",
+                                 threshold=0.5, weight_decay=0.0).to(device)
+    module.setup("fit")
+    opt = module.configure_optimizers()["optimizer"]
+    return module, opt
+
+
+def cpu_baseline(batch_size: int, steps: int) -> dict:
+    """The CPU oracle (a port of the reference's trainer=cpu path, pinned by the golden fixtures) timed on the host cores."""
+    from oracle import clipseg_oracle as O
+    from tunevlseg_amd.config import CLIPSegConfig
+    from tunevlseg_amd.weights import init_clipseg_state_dict
+
+    torch.set_float32_matmul_precision("medium")  # reference src/models/__init__.py:6
+    cores = torch.get_num_threads()
+    cfg = CLIPSegConfig.rd64()
+    sd = init_clipseg_state_dict(cfg, 0)
+    ctx = (torch.randn(1, 10, 768) * 0.02).requires_grad_(True)
+    opt = torch.optim.AdamW([ctx], lr=2e-4)
+    b = make_batch(batch_size, 352, 7, "cpu")
+
+    def step():
+        opt.zero_grad()
+        logits = O.vpt_forward(sd, cfg, {"kind": "vpt", "ctx": ctx}, b["image"], b["input_ids"], b["attention_mask"])
+        O.dice_ce_loss(logits, b["mask"]).backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    torch.set_float32_matmul_precision("highest")
+    return {"value": round(batch_size * steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} train steps of the same VPT-10 352x352 workload at bs={batch_size} (1 warm-up), fp32 torch CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    from tunevlseg_amd import dist as tdist
+    from tunevlseg_amd import hip
+
+    rank, local_rank, world = tdist.init_distributed("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    hip.load()
+
+    module, opt = build_module(device)
+    batch = make_batch(args.batch, 352, 100 + rank, device)
+
+    def step():
+        opt.zero_grad()
+        loss = module.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    metrics = module.epoch_metrics("train")
+
+    # ---- roofline of the dominant kernel: HIP events around every GEMM launch of 2 extra (untimed) steps ----
+    hip.gemm_profile_start()
+    for _ in range(2):
+        step()
+    prof = hip.gemm_profile_stop()
+    roofline = None
+    if prof:
+        name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        gemm_ms = sum(v["ms"] for v in prof.values()) / 2
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": name,
+                    "launches_per_step": d["launches"] // 2, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1),
+                    "flops_per_launch": round(d["flops"] / d["launches"]), "all_gemm_ms_per_step": round(gemm_ms, 2),
+                    "all_gemm_tflops": round(sum(v["flops"] for v in prof.values()) / 2 / (gemm_ms * 1e-3) / 1e12, 2)}
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = world * args.batch * args.steps / elapsed
+        out = {
+            "metric": "images/sec, train step (fwd + DiceCE + bwd + AdamW on prompts), CLIPSeg ViT-B/16 + VPT-10 shallow, 352x352",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "per_gpu": round(value / world, 2),
+            "config": {"workload": "CLIPSeg ViT-B/16 + VPT-shallow (10 visual prompts), 352x352, bs=32/GPU (BASELINE configs[1])",
+                       "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
+                       "weights": "seeded random init (rd64 geometry)", "use_new_last_layer": False},
+            "step_tflops": round(value * GFLOP_PER_IMAGE_TRAIN / 1e3, 2),
+            "step_frac_of_f32_mfma_peak": round(value / world * GFLOP_PER_IMAGE_TRAIN / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+            "loss": round(float(loss.item()), 6), "train_dice": round(metrics["train_dice"], 6), "train_iou": round(metrics["train_iou"], 6),
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -159,10 +159,48 @@ def _ident():
 # --------------------------------------------------------------------------------------
 # GEMM
 # --------------------------------------------------------------------------------------
+_gemm_prof: list | None = None  # bench.py: (kernel key, flops, start event, stop event) per launch
+
+
+def gemm_profile_start():
+    global _gemm_prof
+    _gemm_prof = []
+
+
+def gemm_profile_stop() -> dict:
+    """Per kernel instantiation: launches, algorithmic FLOPs (2*M*N*K) and summed device time (ms, HIP events)."""
+    global _gemm_prof
+    rec, _gemm_prof = _gemm_prof or [], None
+    torch.cuda.synchronize()
+    out: dict[str, dict] = {}
+    for key, flops, e0, e1 in rec:
+        d = out.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        d["launches"] += 1
+        d["flops"] += flops
+        d["ms"] += e0.elapsed_time(e1)
+    return out
+
+
+def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True) -> str:
+    """Name of the template instantiation ``tvl_gemm_f32`` picks (same rule as csrc/gemm.hip)."""
+    big = N >= 128 and M >= 128 and ((M + 127) // 128) * ((N + 127) // 128) >= 200
+    t = 128 if big else 64
+    ak, bk = {NT: ("true", "true"), NN: ("true", "false"), TN: ("false", "false")}[layout]
+    return f"gemm_f32_kernel<{t}, {t}, {ak}, {bk}, {'true' if vec else 'false'}>"
+
+
 def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias=None, residual=None, ldr=0, act=ACT_NONE,
          pre_out=None, dact_aux=None, ld_aux=0, dact=ACT_NONE, alpha=1.0, a_map=None, c_map=None):
     args = GemmArgs(layout, M, N, K, _p(A), lda, _p(B), ldb, _p(Cout), ldc, _p(bias), _p(residual), ldr, act, _p(pre_out),
                     _p(dact_aux), ld_aux, dact, alpha, a_map or _ident(), c_map or _ident())
+    if _gemm_prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call("tvl_gemm_f32", C.byref(args))
+        e1.record()
+        vec = lda % 4 == 0 and ldb % 4 == 0
+        _gemm_prof.append((gemm_kernel_key(layout, M, N, vec), 2.0 * M * N * K, e0, e1))
+        return Cout
     _call("tvl_gemm_f32", C.byref(args))
     return Cout
 
