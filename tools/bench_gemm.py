@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""GEMM micro-benchmark on the ViT-B/16 shapes of the hot path (M = 32*495 = 15840). Interleaved rounds, HIP events."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from tunevlseg_amd import hip  # noqa: E402
+
+M = 15840
+SHAPES = [("qkv  NT", hip.NT, M, 2304, 768), ("out  NT", hip.NT, M, 768, 768), ("fc1  NT", hip.NT, M, 3072, 768),
+          ("fc2  NT", hip.NT, M, 768, 3072), ("dz   NN", hip.NN, M, 3072, 768), ("dx2  NN", hip.NN, M, 768, 3072),
+          ("do   NN", hip.NN, M, 768, 768), ("dx1  NN", hip.NN, M, 768, 2304), ("sq4k NT", hip.NT, 4096, 4096, 4096)]
+
+
+def main():
+    hip.load()
+    torch.manual_seed(0)
+    bufs = {}
+    for name, layout, m, n, k in SHAPES:
+        A = torch.randn(m, k, device="cuda")
+        B = torch.randn(n, k, device="cuda") if layout == hip.NT else torch.randn(k, n, device="cuda")
+        C = torch.empty(m, n, device="cuda")
+        bufs[name] = (A, B, C)
+    rounds = 5
+    times = {s[0]: [] for s in SHAPES}
+    for r in range(rounds + 1):
+        for name, layout, m, n, k in SHAPES:
+            A, B, C = bufs[name]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                hip.gemm(layout, m, n, k, A, A.shape[1], B, B.shape[1], C, n)
+            e1.record()
+            torch.cuda.synchronize()
+            if r:
+                times[name].append(e0.elapsed_time(e1) / 3)
+    tot_f = tot_t = 0
+    for name, layout, m, n, k in SHAPES:
+        t = sorted(times[name])[len(times[name]) // 2]
+        fl = 2.0 * m * n * k
+        if not name.startswith("sq"):
+            tot_f += fl
+            tot_t += t
+        print(f"{name} M={m} N={n} K={k}: {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TF/s  {hip.gemm_kernel_key(layout, m, n)}")
+    print(f"layer GEMMs total: {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()

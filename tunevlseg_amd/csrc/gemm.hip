@@ -116,9 +116,11 @@ __device__ __forceinline__ void sstore_mnmajor(const StageRegs<COLS>& s, float* 
     for (int i = 0; i < COLS / 32; ++i) *reinterpret_cast<float4*>(&lds[(kr0 + KSTEP * i) * COLS + 4 * c]) = s.v[i];
 }
 
-template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR, bool VEC>
+template <int BM, int BN, int WGM, bool A_KMAJOR, bool B_KMAJOR, bool VEC>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WGN = 4 / WGM;  // 4 waves arranged WGM x WGN over the tile
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int A_TILE = A_KMAJOR ? BM * LDK : BK * BM;
     constexpr int B_TILE = B_KMAJOR ? BN * LDK : BK * BN;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, h = lane >> 5;
 
     f32x16 acc[TM][TN];
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
-template <int BM, int BN, bool AK, bool BKM, bool VEC>
+template <int BM, int BN, int WGM, bool AK, bool BKM, bool VEC>
 int launch(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -245,7 +247,7 @@ int launch(const GemmParams& p0, hipStream_t s) {
     constexpr int B_TILE = BKM ? BN * LDK : BK * BN;
     constexpr size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
     static bool attr_set = false;
-    auto kern = gemm_f32_kernel<BM, BN, AK, BKM, VEC>;
+    auto kern = gemm_f32_kernel<BM, BN, WGM, AK, BKM, VEC>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
@@ -255,13 +257,36 @@ int launch(const GemmParams& p0, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, int WGM, bool VEC>
 int launch_layout(int layout, const GemmParams& p, hipStream_t s) {
     switch (layout) {
-        case TVL_NT: return launch<BM, BN, true, true, VEC>(p, s);
-        case TVL_NN: return launch<BM, BN, true, false, VEC>(p, s);
-        default: return launch<BM, BN, false, false, VEC>(p, s);
+        case TVL_NT: return launch<BM, BN, WGM, true, true, VEC>(p, s);
+        case TVL_NN: return launch<BM, BN, WGM, true, false, VEC>(p, s);
+        default:
+            if constexpr (BM % 128 == 0 || BM == 64) return launch<BM, BN, WGM, false, false, VEC>(p, s);
+            else return 1;  // MN-major A staging needs BM/4 to divide 256
     }
+}
+
+// Tile choice = least per-CU time under wave quantisation: ceil(tiles / resident slots) * WGs-per-CU * BM*BN.
+// 128x128 and 96x128 run 2 workgroups per CU (LDS 72 / 64.5 KiB), 64x64 runs 4.  M = 15840 = 165 * 96 makes
+// 96x128 the balanced choice for the ViT-B/16 shapes (990 tiles over 512 slots at N = 768, vs 744 for 128x128).
+struct TileChoice { int bm, bn; };
+TileChoice choose_tile(int layout, long M, long N) {
+    const long cus = 256;
+    struct Cand { int bm, bn, per_cu; } cands[3] = {{128, 128, 2}, {96, 128, 2}, {64, 64, 4}};
+    double best = 1e300;
+    TileChoice out = {64, 64};
+    for (const Cand& c : cands) {
+        if (c.bm == 96 && layout == TVL_TN) continue;
+        const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+        const long slots = cus * c.per_cu;
+        const long rounds = (tiles + slots - 1) / slots;
+        // small tiles pay more staging traffic per FLOP: 12% handicap keeps them for genuinely small problems
+        const double cost = (double)rounds * c.per_cu * c.bm * c.bn * (c.bm == 64 ? 1.12 : 1.0);
+        if (cost < best) { best = cost; out = {c.bm, c.bn}; }
+    }
+    return out;
 }
 
 }  // namespace
@@ -286,14 +311,13 @@ extern "C" int tvl_gemm_f32(const tvlGemmArgs* a, tvlStream_t stream) {
     p.a_map = a->a_map; p.c_map = a->c_map; p.tiles_m = p.tiles_n = 0;
 
     const bool vec = tvl_aligned16(a->A) && tvl_aligned16(a->B) && (a->lda % 4 == 0) && (a->ldb % 4 == 0);
-    // 128x128 tiles when they still fill the 256 CUs, else 64x64 (small N / small M problems)
-    const long big_tiles = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
-    const bool big = a->N >= 128 && a->M >= 128 && big_tiles >= 200;
+    const TileChoice tc = choose_tile(a->layout, a->M, a->N);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
-    if (big) rc = vec ? launch_layout<128, 128, true>(a->layout, p, s) : launch_layout<128, 128, false>(a->layout, p, s);
-    else rc = vec ? launch_layout<64, 64, true>(a->layout, p, s) : launch_layout<64, 64, false>(a->layout, p, s);
-    if (rc) return rc;
+    if (tc.bm == 128) rc = vec ? launch_layout<128, 128, 2, true>(a->layout, p, s) : launch_layout<128, 128, 2, false>(a->layout, p, s);
+    else if (tc.bm == 96) rc = vec ? launch_layout<96, 128, 1, true>(a->layout, p, s) : launch_layout<96, 128, 1, false>(a->layout, p, s);
+    else rc = vec ? launch_layout<64, 64, 2, true>(a->layout, p, s) : launch_layout<64, 64, 2, false>(a->layout, p, s);
+    TVL_REQUIRE(rc == 0, "tvl_gemm_f32: no kernel for this layout/tile");
     TVL_LAUNCH_CHECK("tvl_gemm_f32");
     return 0;
 }

@@ -183,10 +183,17 @@ def gemm_profile_stop() -> dict:
 
 def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True) -> str:
     """Name of the template instantiation ``tvl_gemm_f32`` picks (same rule as csrc/gemm.hip)."""
-    big = N >= 128 and M >= 128 and ((M + 127) // 128) * ((N + 127) // 128) >= 200
-    t = 128 if big else 64
+    best, tile = None, (64, 64, 2)
+    for bm, bn, per_cu, wgm in ((128, 128, 2, 2), (96, 128, 2, 1), (64, 64, 4, 2)):
+        if bm == 96 and layout == TN:
+            continue
+        tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+        slots = 256 * per_cu
+        cost = ((tiles + slots - 1) // slots) * per_cu * bm * bn * (1.12 if bm == 64 else 1.0)
+        if best is None or cost < best:
+            best, tile = cost, (bm, bn, wgm)
     ak, bk = {NT: ("true", "true"), NN: ("true", "false"), TN: ("false", "false")}[layout]
-    return f"gemm_f32_kernel<{t}, {t}, {ak}, {bk}, {'true' if vec else 'false'}>"
+    return f"gemm_f32_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {ak}, {bk}, {'true' if vec else 'false'}>"
 
 
 def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias=None, residual=None, ldr=0, act=ACT_NONE,
