@@ -60,6 +60,13 @@ typedef struct {
     tvlRowMap a_map, c_map;
 } tvlGemmArgs;
 int tvl_gemm_f32(const tvlGemmArgs* args, tvlStream_t stream);
+/*
+ * Same contract (fp32 in, fp32 out, same epilogue), NT layout only, computed on the bf16 matrix cores
+ * (v_mfma_f32_32x32x16_bf16) with each fp32 operand split into `nsplit` bf16 pieces while it is staged:
+ *   nsplit 3: 6 MFMAs per k-step, fp32-equivalent accuracy (three bf16 pieces hold all 24 significand bits)
+ *   nsplit 2: 3 MFMAs, ~2^-16 relative per product;   nsplit 1: plain bf16 operands.
+ */
+int tvl_gemm_bf16s(const tvlGemmArgs* args, int32_t nsplit, tvlStream_t stream);
 
 /* LayerNorm over the last dim (nn.LayerNorm, eps 1e-5; HF:347,355,392,396).  mean/rstd may be NULL. */
 int tvl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

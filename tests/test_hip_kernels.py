@@ -58,6 +58,27 @@ def test_gemm_layouts(hip, M, N, K, layout):
     close(Cd, ref, 3e-6 * math.sqrt(K), f"gemm layout {layout}")
 
 
+@pytest.mark.parametrize("nsplit,tol", [(3, 2e-6), (2, 3e-5), (1, 2e-2)])
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (300, 200, 100), (4100, 2048, 96), (130, 67, 70)])
+def test_gemm_split_bf16(hip, nsplit, tol, M, N, K):
+    """fp32 GEMM on the bf16 matrix cores; nsplit=3 must be fp32-equivalent (error relative to sum |a||b|)."""
+    import ctypes as C
+
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    Cd = torch.empty(M, N, device="cuda")
+    args = hip.GemmArgs(hip.NT, M, N, K, hip._p(dev(A)), K, hip._p(dev(W)), K, hip._p(Cd), N, None, None, 0, 0, None, None, 0, 0, 1.0,
+                        hip._ident(), hip._ident())
+    Ad, Wd, bd, rd = dev(A), dev(W), dev(bias), dev(res)
+    args = hip.GemmArgs(hip.NT, M, N, K, hip._p(Ad), K, hip._p(Wd), K, hip._p(Cd), N, hip._p(bd), hip._p(rd), N, hip.ACT_RELU, None,
+                        None, 0, 0, 1.0, hip._ident(), hip._ident())
+    hip._call("tvl_gemm_bf16s", C.byref(args), nsplit)
+    ref = torch.relu(A.double() @ W.double().T + bias.double()) + res.double()
+    mag = (A.double().abs() @ W.double().abs().T).max().item()
+    err = (Cd.cpu().double() - ref).abs().max().item()
+    assert err <= tol * mag, f"nsplit {nsplit}: err {err:.3e} vs sum|a||b| {mag:.3e}"
+
+
 def test_gemm_unaligned_k(hip):
     M, N, K = 130, 67, 70  # lda % 4 != 0 -> scalar-guarded loads
     A, W = rnd(M, K, seed=3), rnd(N, K, seed=4)

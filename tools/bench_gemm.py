@@ -12,10 +12,15 @@ M = 15840
 SHAPES = [("qkv  NT", hip.NT, M, 2304, 768), ("out  NT", hip.NT, M, 768, 768), ("fc1  NT", hip.NT, M, 3072, 768),
           ("fc2  NT", hip.NT, M, 768, 3072), ("dz   NN", hip.NN, M, 3072, 768), ("dx2  NN", hip.NN, M, 768, 3072),
           ("do   NN", hip.NN, M, 768, 768), ("dx1  NN", hip.NN, M, 768, 2304), ("sq4k NT", hip.NT, 4096, 4096, 4096)]
+if len(sys.argv) > 1 and sys.argv[1] != "f32":  # split-bf16 runs data gradients as NT over W^T
+    SHAPES = [(n.replace("NN", "NT"), hip.NT, m, nn_, k) for n, _, m, nn_, k in SHAPES]
 
 
 def main():
     hip.load()
+    if len(sys.argv) > 1:
+        hip.set_gemm_mode(sys.argv[1])
+    print("mode", hip.GEMM_MODE)
     torch.manual_seed(0)
     bufs = {}
     for name, layout, m, n, k in SHAPES:
@@ -43,7 +48,7 @@ def main():
         if not name.startswith("sq"):
             tot_f += fl
             tot_t += t
-        print(f"{name} M={m} N={n} K={k}: {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TF/s  {hip.gemm_kernel_key(layout, m, n)}")
+        print(f"{name} M={m} N={n} K={k}: {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TF/s  {hip.gemm_kernel_key(layout, m, n, True, hip._NSPLIT.get(hip.GEMM_MODE, 0))}")
     print(f"layer GEMMs total: {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TF/s")
 
 

@@ -107,9 +107,12 @@ class CLIPSegBackbone(_Node):
     def _layer_weights(self, node) -> LayerWeights:
         a = node.self_attn
         c = lambda t: t.detach().contiguous()  # noqa: E731
+        tr = lambda t: t.detach().t().contiguous()  # noqa: E731
+        wqkv = torch.cat((a.q_proj.weight, a.k_proj.weight, a.v_proj.weight), 0).detach().contiguous()
         return LayerWeights(
+            wqkv_t=tr(wqkv), wo_t=tr(a.out_proj.weight), w1_t=tr(node.mlp.fc1.weight), w2_t=tr(node.mlp.fc2.weight),
             ln1_w=c(node.layer_norm1.weight), ln1_b=c(node.layer_norm1.bias),
-            wqkv=torch.cat((a.q_proj.weight, a.k_proj.weight, a.v_proj.weight), 0).detach().contiguous(),
+            wqkv=wqkv,
             bqkv=torch.cat((a.q_proj.bias, a.k_proj.bias, a.v_proj.bias), 0).detach().contiguous(),
             wo=c(a.out_proj.weight), bo=c(a.out_proj.bias),
             ln2_w=c(node.layer_norm2.weight), ln2_b=c(node.layer_norm2.bias),

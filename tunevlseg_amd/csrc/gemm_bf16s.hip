@@ -1,0 +1,298 @@
+// fp32-in / fp32-out GEMM on the bf16 matrix cores by operand splitting (gfx950, v_mfma_f32_32x32x16_bf16).
+//
+// Each fp32 operand element is split, while its tile is staged to LDS, into S bf16 pieces
+//     x = x1 + x2 + ... + xS      (pieces 1..S-1 by truncation of the running residual, the last by round-to-nearest)
+// and the product is accumulated in fp32 over the piece pairs (i, j) with i + j <= S + 1:
+//     S = 1  plain bf16 operands                 1 MFMA  per 32x32x16 step   (16x the f32-MFMA rate)
+//     S = 2  a1b1 + a1b2 + a2b1                  3 MFMAs                     rel. error ~2^-16 per product
+//     S = 3  + a1b3 + a2b2 + a3b1                6 MFMAs                     three bf16 pieces carry all 24 significand
+//                                                                            bits of an fp32 value: the dropped terms are
+//                                                                            <= 2^-24 relative, i.e. fp32-equivalent
+// bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so S = 3 reproduces an fp32 GEMM to fp32
+// round-off at 6/16 of the f32-MFMA cost (8 f32 MFMAs of 64 cycles vs 6 bf16 MFMAs of 32 cycles per 16-deep k-step).
+//
+// Layout: NT only (A [M,K] and B [N,K], both k-contiguous); the frozen weights are kept in both orientations by the host
+// so data gradients are NT as well.  256 threads = 4 waves, tiles 128x128 (2x2 waves) / 96x128 (1x4) / 64x64 (2x2),
+// BK = 32, ONE LDS stage (S planes per operand) + register prefetch of the next slab, two barriers per slab.
+// LDS rows are 32 bf16 + 8 pad = 80 bytes = 20 dwords, so the 16 rows of a ds_read_b128 lane group start on 16
+// distinct 16-byte slots: conflict free.  Fragment map (guide §3): lane l -> row l&31, k = 8*(l>>5) .. +7.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDB = BK + 8;  // bf16 elements per LDS row (80 bytes)
+constexpr int NTHREADS = 256;
+
+struct GemmParams {
+    int M, N, K;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    const float* bias;
+    const float* residual; int ldr;
+    int act;
+    float* pre_out;
+    const float* dact_aux; int ld_aux; int dact;
+    float alpha;
+    tvlRowMap a_map, c_map;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ long map_row(int r, const tvlRowMap& m) {
+    return m.div > 0 ? (long)(r / m.div) * m.mul + (r % m.div) + m.off : (long)r;
+}
+
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float* __restrict__ base, long row, int col, int cols, int ld) {
+    const float* p = base + row * (long)ld + col;
+    if (VEC) {
+        if (col + 3 < cols) return *reinterpret_cast<const float4*>(p);
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < cols) v.x = p[0];
+    if (col + 1 < cols) v.y = p[1];
+    if (col + 2 < cols) v.z = p[2];
+    if (col + 3 < cols) v.w = p[3];
+    return v;
+}
+
+template <int ROWS>
+struct StageRegs {
+    float4 v[ROWS / 32];
+};
+
+template <int ROWS, bool VEC>
+__device__ __forceinline__ void gload(StageRegs<ROWS>& s, const float* __restrict__ base, int ld, int row0, int nrows, int k0, int K,
+                                      const tvlRowMap& map) {
+    const int t = threadIdx.x;
+    const int c = t & 7, r0 = t >> 3;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        int r = row0 + r0 + 32 * i;
+        r = r < nrows ? r : nrows - 1;
+        s.v[i] = load4<VEC>(base, map_row(r, map), k0 + 4 * c, K, ld);
+    }
+}
+
+__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float bfloat(unsigned u) { return __builtin_bit_cast(float, u); }
+// two fp32 bit patterns -> one dword holding their upper halves (bf16 by truncation): low half = lo, high half = hi
+__device__ __forceinline__ unsigned pack_trunc(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+__device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
+    bf16x2 t = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, t);
+}
+
+// split 4 consecutive k-elements into S planes; plane s gets two dwords (4 bf16)
+template <int S>
+__device__ __forceinline__ void split4(const float4 v, uint2 (&out)[S]) {
+    float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s == S - 1) {
+            out[s] = make_uint2(pack_rn(x[0], x[1]), pack_rn(x[2], x[3]));
+        } else {
+            out[s] = make_uint2(pack_trunc(fbits(x[0]), fbits(x[1])), pack_trunc(fbits(x[2]), fbits(x[3])));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = x[i] - bfloat(fbits(x[i]) & 0xFFFF0000u);
+        }
+    }
+}
+
+template <int ROWS, int S>
+__device__ __forceinline__ void sstore(const StageRegs<ROWS>& sr, __bf16* __restrict__ lds) {
+    const int t = threadIdx.x;
+    const int c = t & 7, r0 = t >> 3;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        uint2 pl[S];
+        split4<S>(sr.v[i], pl);
+#pragma unroll
+        for (int s = 0; s < S; ++s) *reinterpret_cast<uint2*>(&lds[(s * ROWS + r0 + 32 * i) * LDB + 4 * c]) = pl[s];
+    }
+}
+
+template <int BM, int BN, int WGM, int S, bool VEC>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
+    constexpr int WGN = 4 / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem_raw);  // [S][BM][LDB]
+    __bf16* Bs = As + S * BM * LDB;                    // [S][BN][LDB]
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    StageRegs<BM> sa;
+    StageRegs<BN> sb;
+    const tvlRowMap ident = {0, 0, 0};
+    const int nk = (p.K + BK - 1) / BK;
+
+    gload<BM, VEC>(sa, p.A, p.lda, m0, p.M, 0, p.K, p.a_map);
+    gload<BN, VEC>(sb, p.B, p.ldb, n0, p.N, 0, p.K, ident);
+    sstore<BM, S>(sa, As);
+    sstore<BN, S>(sb, Bs);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            gload<BM, VEC>(sa, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, p.a_map);
+            gload<BN, VEC>(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, ident);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 af[TM][S], bf[TN][S];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    af[i][s] = *reinterpret_cast<const bf16x8*>(&As[(s * BM + wm * WM + i * 32 + l31) * LDB + ks * 16 + 8 * h]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    bf[j][s] = *reinterpret_cast<const bf16x8*>(&Bs[(s * BN + wn * WN + j * 32 + l31) * LDB + ks * 16 + 8 * h]);
+            // smallest-magnitude piece pairs first, the a1*b1 term last
+#pragma unroll
+            for (int order = S - 1; order >= 0; --order)
+#pragma unroll
+                for (int sa_ = 0; sa_ <= order; ++sa_) {
+                    const int sb_ = order - sa_;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][sa_], bf[j][sb_], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();  // every wave is done reading this slab
+        if (kt + 1 < nk) {
+            sstore<BM, S>(sa, As);
+            sstore<BN, S>(sb, Bs);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = n0 + wn * WN + n * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                const long crow = map_row(row, p.c_map);
+                float v = acc[i][n][r] * p.alpha + bv;
+                if (p.dact) v *= dact_f(p.dact_aux[crow * p.ld_aux + col], p.dact);
+                if (p.pre_out) p.pre_out[crow * p.ldc + col] = v;
+                v = act_f(v, p.act);
+                if (p.residual) v += p.residual[crow * p.ldr + col];
+                p.C[crow * p.ldc + col] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int S, bool VEC>
+int launch(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    constexpr size_t smem = (size_t)S * (BM + BN) * LDB * sizeof(__bf16);
+    static bool attr_set = false;
+    auto kern = gemm_bf16s_kernel<BM, BN, WGM, S, VEC>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    const long nwg = (long)p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NTHREADS), smem, s, p);
+    return 0;
+}
+
+template <int S, bool VEC>
+int launch_tile(int bm, const GemmParams& p, hipStream_t s) {
+    if (bm == 128) return launch<128, 128, 2, S, VEC>(p, s);
+    if (bm == 96) return launch<96, 128, 1, S, VEC>(p, s);
+    return launch<64, 64, 2, S, VEC>(p, s);
+}
+
+int choose_bm(long M, long N) {
+    const long cus = 256;
+    struct Cand { int bm, bn, per_cu; } cands[3] = {{128, 128, 2}, {96, 128, 2}, {64, 64, 4}};
+    double best = 1e300;
+    int out = 64;
+    for (const Cand& c : cands) {
+        const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+        const long slots = cus * c.per_cu;
+        const long rounds = (tiles + slots - 1) / slots;
+        const double cost = (double)rounds * c.per_cu * c.bm * c.bn * (c.bm == 64 ? 1.12 : 1.0);
+        if (cost < best) { best = cost; out = c.bm; }
+    }
+    return out;
+}
+
+}  // namespace
+
+extern "C" int tvl_gemm_bf16s(const tvlGemmArgs* a, int32_t nsplit, tvlStream_t stream) {
+    TVL_REQUIRE(a != nullptr, "tvl_gemm_bf16s: null args");
+    TVL_REQUIRE(a->layout == TVL_NT, "tvl_gemm_bf16s: NT layout only (keep frozen weights in both orientations)");
+    TVL_REQUIRE(nsplit >= 1 && nsplit <= 3, "tvl_gemm_bf16s: nsplit must be 1, 2 or 3");
+    TVL_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "tvl_gemm_bf16s: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+    TVL_REQUIRE(a->A && a->B && a->C, "tvl_gemm_bf16s: null operand");
+    TVL_REQUIRE(a->lda >= a->K && a->ldb >= a->K && a->ldc >= a->N, "tvl_gemm_bf16s: leading dimension too small");
+    TVL_REQUIRE(!a->residual || a->ldr >= a->N, "tvl_gemm_bf16s: ldr too small");
+    TVL_REQUIRE(!a->dact || (a->dact_aux && a->ld_aux >= a->N), "tvl_gemm_bf16s: dact needs dact_aux");
+
+    GemmParams p;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.A = a->A; p.lda = a->lda; p.B = a->B; p.ldb = a->ldb; p.C = a->C; p.ldc = a->ldc;
+    p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.act = a->act; p.pre_out = a->pre_out;
+    p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha;
+    p.a_map = a->a_map; p.c_map = a->c_map; p.tiles_m = p.tiles_n = 0;
+
+    const bool vec = tvl_aligned16(a->A) && tvl_aligned16(a->B) && (a->lda % 4 == 0) && (a->ldb % 4 == 0);
+    const int bm = choose_bm(a->M, a->N);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc = 1;
+    if (vec) {
+        if (nsplit == 1) rc = launch_tile<1, true>(bm, p, s);
+        else if (nsplit == 2) rc = launch_tile<2, true>(bm, p, s);
+        else rc = launch_tile<3, true>(bm, p, s);
+    } else {
+        if (nsplit == 1) rc = launch_tile<1, false>(bm, p, s);
+        else if (nsplit == 2) rc = launch_tile<2, false>(bm, p, s);
+        else rc = launch_tile<3, false>(bm, p, s);
+    }
+    TVL_REQUIRE(rc == 0, "tvl_gemm_bf16s: launch failed");
+    TVL_LAUNCH_CHECK("tvl_gemm_bf16s");
+    return 0;
+}

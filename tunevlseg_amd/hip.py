@@ -75,6 +75,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 # name -> argtypes (stream appended automatically); mirrors include/tvl_hip.h one to one
 _SIGS = {
     "tvl_gemm_f32": [C.POINTER(GemmArgs)],
+    "tvl_gemm_bf16s": [C.POINTER(GemmArgs), _I],
     "tvl_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F],
     "tvl_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
     "tvl_attn_fwd": [C.POINTER(AttnFwdArgs)],
@@ -159,6 +160,23 @@ def _ident():
 # --------------------------------------------------------------------------------------
 # GEMM
 # --------------------------------------------------------------------------------------
+# Arithmetic of the large NT GEMMs (fp32 in, fp32 out either way):
+#   "bf16x6" (default) bf16 MFMA, every fp32 operand split exactly into 3 bf16 pieces inside the kernel, 6 MFMAs per
+#            k-step, fp32 accumulate: fp32-equivalent results (measured 3e-6 on full-size logits) at 1.4x the f32-MFMA speed
+#   "f32"    v_mfma_f32_32x32x2_f32, exact fp32
+#   "bf16x3" 2 pieces / 3 MFMAs (~2^-16 per product; fails the 1e-3 gradient gate on the full-size fixtures)
+#   "bf16"   plain bf16 operands (fails the 1e-3 logit gate) -- both kept only as measured, documented reduced-precision modes
+GEMM_MODE = os.environ.get("TVL_GEMM_MODE", "bf16x6")
+_NSPLIT = {"bf16x6": 3, "bf16x3": 2, "bf16": 1}
+
+
+def set_gemm_mode(mode: str) -> None:
+    global GEMM_MODE
+    if mode != "f32" and mode not in _NSPLIT:
+        raise ValueError(f"unknown GEMM mode {mode!r}")
+    GEMM_MODE = mode
+
+
 _gemm_prof: list | None = None  # bench.py: (kernel key, flops, start event, stop event) per launch
 
 
@@ -181,7 +199,7 @@ def gemm_profile_stop() -> dict:
     return out
 
 
-def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True) -> str:
+def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True, split: int = 0) -> str:
     """Name of the template instantiation ``tvl_gemm_f32`` picks (same rule as csrc/gemm.hip)."""
     best, tile = None, (64, 64, 2)
     for bm, bn, per_cu, wgm in ((128, 128, 2, 2), (96, 128, 2, 1), (64, 64, 4, 2)):
@@ -192,6 +210,8 @@ def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True) -> str:
         cost = ((tiles + slots - 1) // slots) * per_cu * bm * bn * (1.12 if bm == 64 else 1.0)
         if best is None or cost < best:
             best, tile = cost, (bm, bn, wgm)
+    if split:
+        return f"gemm_bf16s_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {split}, {'true' if vec else 'false'}>"
     ak, bk = {NT: ("true", "true"), NN: ("true", "false"), TN: ("false", "false")}[layout]
     return f"gemm_f32_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {ak}, {bk}, {'true' if vec else 'false'}>"
 
@@ -200,15 +220,18 @@ def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias
          pre_out=None, dact_aux=None, ld_aux=0, dact=ACT_NONE, alpha=1.0, a_map=None, c_map=None):
     args = GemmArgs(layout, M, N, K, _p(A), lda, _p(B), ldb, _p(Cout), ldc, _p(bias), _p(residual), ldr, act, _p(pre_out),
                     _p(dact_aux), ld_aux, dact, alpha, a_map or _ident(), c_map or _ident())
+    split = _NSPLIT.get(GEMM_MODE, 0) if (layout == NT and M >= 256) else 0
     if _gemm_prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if split:
+        _call("tvl_gemm_bf16s", C.byref(args), split)
+    else:
         _call("tvl_gemm_f32", C.byref(args))
+    if _gemm_prof is not None:
         e1.record()
         vec = lda % 4 == 0 and ldb % 4 == 0
-        _gemm_prof.append((gemm_kernel_key(layout, M, N, vec), 2.0 * M * N * K, e0, e1))
-        return Cout
-    _call("tvl_gemm_f32", C.byref(args))
+        _gemm_prof.append((gemm_kernel_key(layout, M, N, vec, split), 2.0 * M * N * K, e0, e1))
     return Cout
 
 
@@ -226,13 +249,17 @@ def linear_fwd(x2d: torch.Tensor, W: torch.Tensor, b=None, *, act=ACT_NONE, resi
 
 
 def linear_dgrad(dy2d: torch.Tensor, W: torch.Tensor, *, dact=ACT_NONE, dact_aux=None, residual=None, out=None, c_map=None,
-                 out_rows=None, M=None):
-    """dx = (dy W) * act'(aux) + residual ; dy2d [M,N], W [N,K] -> [M,K]."""
+                 out_rows=None, M=None, Wt: torch.Tensor | None = None):
+    """dx = (dy W) * act'(aux) + residual ; dy2d [M,N], W [N,K] -> [M,K].  ``Wt`` = W^T [K,N] (kept for frozen weights)
+    turns the data gradient into an NT GEMM, which is what the split-bf16 kernel runs."""
     Mx = dy2d.shape[0] if M is None else M
     N, K = W.shape
     rows = Mx if out_rows is None else out_rows
     dx = out if out is not None else torch.empty((rows, K), device=dy2d.device, dtype=torch.float32)
-    gemm(NN, Mx, K, N, dy2d, N, W, K, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map)
+    if Wt is not None and GEMM_MODE != "f32":
+        gemm(NT, Mx, K, N, dy2d, N, Wt, N, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map)
+    else:
+        gemm(NN, Mx, K, N, dy2d, N, W, K, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map)
     return dx
 
 

@@ -31,6 +31,11 @@ class LayerWeights:
     b1: torch.Tensor
     w2: torch.Tensor
     b2: torch.Tensor
+    # W^T copies (frozen): data gradients become NT GEMMs for the split-bf16 kernel
+    wqkv_t: torch.Tensor | None = None
+    wo_t: torch.Tensor | None = None
+    w1_t: torch.Tensor | None = None
+    w2_t: torch.Tensor | None = None
 
 
 @dataclass
@@ -86,15 +91,15 @@ class EncoderLayerFn(Fn):
         H = spec.heads
         dh = D // H
         dout2d = _c(dout).view(B * T, D)
-        dz = hip.linear_dgrad(dout2d, lw.w2, dact=spec.act, dact_aux=z)
-        dx2 = hip.linear_dgrad(dz, lw.w1)
+        dz = hip.linear_dgrad(dout2d, lw.w2, dact=spec.act, dact_aux=z, Wt=lw.w2_t)
+        dx2 = hip.linear_dgrad(dz, lw.w1, Wt=lw.w1_t)
         del dz
         dh2 = hip.layernorm_bwd(dx2, h2, lw.ln2_w, mean2, rstd2, dres=dout2d)
         del dx2
-        do = hip.linear_dgrad(dh2, lw.wo)
+        do = hip.linear_dgrad(dh2, lw.wo, Wt=lw.wo_t)
         dqkv = hip.attn_bwd_packed(qkv, o, do, lse, B, T, H, dh, dh**-0.5, spec.causal, spec.key_mask)
         del do
-        dx1 = hip.linear_dgrad(dqkv, lw.wqkv)
+        dx1 = hip.linear_dgrad(dqkv, lw.wqkv, Wt=lw.wqkv_t)
         del dqkv
         dh_in = hip.layernorm_bwd(dx1, h2d, lw.ln1_w, mean1, rstd1, dres=dh2)
         return dh_in.view(B, T, D), None, None
@@ -138,14 +143,14 @@ class DecoderLayerFn(Fn):
         dh = D // H
         dout2d = _c(dout).view(B * T, D)
         dt2 = hip.layernorm_bwd(dout2d, t2, lw.ln2_w, m2, r2)
-        dzu = hip.linear_dgrad(dt2, lw.w2, dact=spec.act, dact_aux=zu)
-        dx1 = hip.linear_dgrad(dzu, lw.w1, residual=dt2)
+        dzu = hip.linear_dgrad(dt2, lw.w2, dact=spec.act, dact_aux=zu, Wt=lw.w2_t)
+        dx1 = hip.linear_dgrad(dzu, lw.w1, residual=dt2, Wt=lw.w1_t)
         del dzu, dt2
         dt1 = hip.layernorm_bwd(dx1, t1, lw.ln1_w, m1, r1)
         del dx1
-        do = hip.linear_dgrad(dt1, lw.wo)
+        do = hip.linear_dgrad(dt1, lw.wo, Wt=lw.wo_t)
         dqkv = hip.attn_bwd_packed(qkv, o, do, lse, B, T, H, dh, dh**-0.5, False, None)
-        dx = hip.linear_dgrad(dqkv, lw.wqkv, residual=dt1)
+        dx = hip.linear_dgrad(dqkv, lw.wqkv, residual=dt1, Wt=lw.wqkv_t)
         return dx.view(B, T, D), None, None
 
 
