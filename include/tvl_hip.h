@@ -174,6 +174,9 @@ int tvl_fill(float* p, float val, int64_t n, tvlStream_t stream);
 int tvl_axpby(const float* x, float a, float* y, float b, int64_t n, tvlStream_t stream);
 /* y[r,c] = act(x[r,c]) or dact: y = dy * act'(x) */
 int tvl_bias_act(const float* x, const float* bias, float* y, int64_t rows, int32_t cols, int32_t act, tvlStream_t stream);
+/* y[i] = keep(seed, i) ? x[i] / (1 - p) : 0 ; keep is a pure function of (seed, i): call again on dy for the backward
+ * (nn.Dropout inside the SharedAttn learner's TransformerEncoderLayer, reference configs/model/shared_attn_clipseg.yaml:21) */
+int tvl_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, tvlStream_t stream);
 /* out = dy * act'(pre) */
 int tvl_dact_mul(const float* dy, const float* pre, float* out, int64_t n, int32_t act, tvlStream_t stream);
 /* CoCoOp shifted context (reference cocoop_context_learner.py:50-58): out[b,j,:] = bias[b,:] + cvec[j,:] and its gradients */

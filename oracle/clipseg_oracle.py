@@ -147,9 +147,52 @@ def run_projection(ops: Sequence[tuple], x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def transformer_encoder_layer(tp: Mapping[str, Any], x: torch.Tensor) -> torch.Tensor:
+    """torch.nn.TransformerEncoderLayer (batch_first=False, eval/dropout-free), restated for x [S, N, E].
+
+    tp: in_proj_weight/bias, out_proj.weight/bias, linear1/2.weight/bias, norm1/2.weight/bias, nhead, norm_first, eps.
+    """
+    S, N, E = x.shape
+    H = tp["nhead"]
+    dh = E // H
+
+    def sa(t):
+        qkv = F.linear(t, tp["self_attn.in_proj_weight"], tp["self_attn.in_proj_bias"])
+        q, k, v = qkv.chunk(3, dim=-1)
+        q = q.reshape(S, N * H, dh).transpose(0, 1)
+        k = k.reshape(S, N * H, dh).transpose(0, 1)
+        v = v.reshape(S, N * H, dh).transpose(0, 1)
+        w = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), dim=-1)
+        o = (w @ v).transpose(0, 1).reshape(S, N, E)
+        return F.linear(o, tp["self_attn.out_proj.weight"], tp["self_attn.out_proj.bias"])
+
+    def ff(t):
+        return F.linear(F.relu(F.linear(t, tp["linear1.weight"], tp["linear1.bias"])), tp["linear2.weight"], tp["linear2.bias"])
+
+    n1 = lambda t: F.layer_norm(t, (E,), tp["norm1.weight"], tp["norm1.bias"], tp.get("eps", 1e-5))  # noqa: E731
+    n2 = lambda t: F.layer_norm(t, (E,), tp["norm2.weight"], tp["norm2.bias"], tp.get("eps", 1e-5))  # noqa: E731
+    if tp.get("norm_first", False):
+        x = x + sa(n1(x))
+        return x + ff(n2(x))
+    x = n1(x + sa(x))
+    return n2(x + ff(x))
+
+
+def shared_attn_halves(learner: Mapping[str, Any], index: int):
+    """shared_attn_learner.py:49-104: ctx[index].unsqueeze(0) is fed to a batch_first=False layer, i.e. as a length-1
+    sequence of n_ctx batch items; the result is split into (textual, visual) column blocks."""
+    out = transformer_encoder_layer(learner["tlayers"][index], learner["ctx"][index].unsqueeze(0)).squeeze(0)
+    td = learner["textual_dim"]
+    return out[:, :td], out[:, td:]
+
+
 def textual_context(learner: Mapping[str, Any], index: int, image_features: torch.Tensor | None) -> torch.Tensor:
-    """coop_context_learner.py:115-122 / cocoop_context_learner.py:33-58."""
+    """coop_context_learner.py:115-122 / cocoop_context_learner.py:33-58 / shared_*_learner.py."""
     ctx = learner["ctx"][index]
+    if learner["kind"] == "shared_separate":
+        return run_projection(learner["tproj"][index], ctx)
+    if learner["kind"] == "shared_attn":
+        return shared_attn_halves(learner, index)[0]
     if learner["kind"] == "cocoop":
         feats = image_features
         if learner.get("norm_image_features", True):
@@ -163,6 +206,10 @@ def visual_context(learner: Mapping[str, Any], index: int) -> torch.Tensor:
     """vpt_context_learner.py:41-44 / maple_context_learner.py:19-20."""
     if learner["kind"] == "maple":
         return run_projection(learner["proj"][index], learner["ctx"][index])
+    if learner["kind"] == "shared_separate":
+        return run_projection(learner["vproj"][index], learner["ctx"][index])
+    if learner["kind"] == "shared_attn":
+        return shared_attn_halves(learner, index)[1]
     return learner["ctx"][index]
 
 
@@ -192,7 +239,7 @@ def text_features(sd: SD, cfg, input_ids, attention_mask, learner=None, image_fe
     B = input_ids.shape[0]
     emb = F.embedding(input_ids, sd["clip.text_model.embeddings.token_embedding.weight"])
     n = 0
-    if learner is not None and learner["kind"] in ("coop", "cocoop", "maple"):
+    if learner is not None and learner["kind"] in ("coop", "cocoop", "maple", "shared_separate", "shared_attn"):
         n = learner["ctx"].shape[1]
         emb = coop_splice(emb, textual_context(learner, 0, image_features), t.max_position_embeddings)
         if attention_mask is not None:
@@ -227,7 +274,7 @@ def vision_tower(sd: SD, cfg, pixel_values, learner=None, full: bool = False):
     v = cfg.vision_config
     x = vision_embeddings(sd, cfg, pixel_values)
     n, depth = 0, 1
-    if learner is not None and learner["kind"] in ("vpt", "maple") and not full:
+    if learner is not None and learner["kind"] in ("vpt", "maple", "shared_separate", "shared_attn") and not full:
         n = learner["ctx"].shape[1]
         depth = learner["ctx"].shape[0]
         x = torch.cat((x, visual_context(learner, 0).expand(x.shape[0], -1, -1)), dim=1)

@@ -169,10 +169,16 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
     sd = init_clipseg_state_dict(cfg, wseed)
     HFCLIPSegWrapper.get_pretrained_model = staticmethod(lambda *a, **k: hf_model_from_state(cfg, sd))
 
-    net_cls = {"vpt": R.VPTCLIPSeg, "coop": R.COOPCLIPSeg, "cocoop": R.COOPCLIPSeg, "maple": R.MapleCLIPSeg}[net_kind]
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        return
+    net_cls = {"vpt": R.VPTCLIPSeg, "coop": R.COOPCLIPSeg, "cocoop": R.COOPCLIPSeg, "maple": R.MapleCLIPSeg,
+               "shared_separate": R.SharedSeparateCLIPSeg, "shared_attn": R.SharedAttnCLIPSeg}[net_kind]
     learner_cls = {"vpt": CL.VPTContextLearner, "coop": CL.CoOpContextLearner,
-                   "cocoop": CL.CoCoOpContextLearner, "maple": CL.MapleContextLearner}[net_kind]
+                   "cocoop": CL.CoCoOpContextLearner, "maple": CL.MapleContextLearner,
+                   "shared_separate": CL.SharedSeparateLearner, "shared_attn": CL.SharedAttnLearner}[net_kind]
     lkw = dict(learner_kw)
+    if "_tlayer" in lkw:  # SharedAttn: the config's partial(nn.TransformerEncoderLayer, ...)
+        lkw["unified_projector"] = partial(torch.nn.TransformerEncoderLayer, **lkw.pop("_tlayer"))
     if lkw.get("context_initializer") is not None:
         lkw["tokenizer"] = StubTokenizer(lkw.pop("_init_ids"))
     torch.manual_seed(1000 + iseed)
@@ -189,7 +195,7 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
                 p.copy_(torch.randn(p.shape, generator=g) * 0.02)
             elif k == "residual_ratio":
                 pass
-            elif p.dim() == 1 and "projection_layers" in k and not k.endswith(".bias"):
+            elif p.dim() == 1 and "projection_layers" in k and not k.endswith(".bias") and "in_proj" not in k:
                 p.copy_(1 + 0.05 * torch.randn(p.shape, generator=g))
             elif k.endswith(".bias"):
                 p.copy_(0.05 * torch.randn(p.shape, generator=g))
@@ -217,6 +223,9 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
     print(f"{name}: logits mean {logits.mean():+.4f} std {logits.std():.4f} |max| {logits.abs().max():.3f} "
           f"pos-frac {(logits > 0).float().mean():.3f} loss {loss.item():.6f} "
           f"grads {[(k, float(p.grad.abs().max())) for k, p in params.items() if p.grad is not None][:3]} none={grads_none}")
+
+
+ONLY = sys.argv[1:]  # optional name prefixes: regenerate only those fixtures
 
 
 def main():
@@ -255,6 +264,16 @@ def main():
              learner_kw=dict(prompt_depth=1, num_context=4, context_initializer="a photo of a", _init_ids=[5, 9, 7, 5],
                              vector_std=0.02, use_unified_projection=True, intermediate_dim=None, use_proj_norm=False),
              net_kw=base_old, **T)
+    # --- tiny: shared learners (row A16) ----------------------------------------
+    run_case("tiny_sharedsep_d2_i8", eos=2, wseed=11, net_kind="shared_separate", iseed=11,
+             learner_kw=dict(prompt_depth=2, num_context=3, vector_std=0.02, shared_dim=8, use_unified_projection=False,
+                             intermediate_dim=8, use_proj_norm=True, use_lora_proj=False), net_kw=base_new, **T)
+    run_case("tiny_sharedattn_d2", eos=2, wseed=11, net_kind="shared_attn", iseed=12,
+             learner_kw=dict(prompt_depth=2, num_context=3, vector_std=0.02, use_unified_projection=False,
+                             _tlayer=dict(nhead=4, dim_feedforward=48, dropout=0.0, norm_first=True)), net_kw=base_old, **T)
+    run_case("tiny_sharedattn_d3_unified_postnorm", eos=63, wseed=12, net_kind="shared_attn", iseed=13,
+             learner_kw=dict(prompt_depth=3, num_context=2, vector_std=0.02, use_unified_projection=True,
+                             _tlayer=dict(nhead=2, dim_feedforward=32, dropout=0.0, norm_first=False)), net_kw=base_new, **T)
     # --- full size (ViT-B/16 rd64 geometry), B=1 ------------------------------
     F_ = dict(preset="rd64", B=1, H=352, L=8, M=M)
     run_case("rd64_vpt_n10_d1", eos=2, wseed=21, net_kind="vpt", iseed=21,

@@ -60,6 +60,43 @@ def oracle_learner(fx, params: dict[str, torch.Tensor]) -> dict:
         if mm:
             li, sub, wb = int(mm.group(1)), int(mm.group(2) or 0), mm.group(3)
             layers.setdefault(li, {}).setdefault(sub, {})[wb] = t
+    def ops_list(prefix):
+        pat2 = re.compile(re.escape(prefix) + r"\.(\d+)\.(?:(\d+)\.)?(weight|bias)$")
+        lay: dict[int, dict[int, dict[str, torch.Tensor]]] = {}
+        for k, t in params.items():
+            mm = pat2.match(k)
+            if mm:
+                lay.setdefault(int(mm.group(1)), {}).setdefault(int(mm.group(2) or 0), {})[mm.group(3)] = t
+        out = []
+        for d in range(depth):
+            src = lay[d if d in lay else 0]
+            ops = []
+            for sub in range(max(src) + 1):
+                if sub not in src:
+                    ops.append(("relu",))
+                    continue
+                w, b = src[sub]["weight"], src[sub].get("bias")
+                ops.append(("linear", w, b) if w.dim() == 2 else ("layernorm", w, b, 1e-5))
+            out.append(ops)
+        return out
+
+    if kind == "shared_separate":
+        learner["tproj"] = ops_list("context_learner.textual_projection_layers")
+        learner["vproj"] = ops_list("context_learner.visual_projection_layers")
+        return learner
+    if kind == "shared_attn":
+        tl = m["learner_kw"]["_tlayer"]
+        cfg = config_of(fx)
+        tlayers = []
+        for d in range(depth):
+            dd = d if f"context_learner.projection_layers.{d}.linear1.weight" in params else 0
+            pre = f"context_learner.projection_layers.{dd}."
+            tp = {k[len(pre):]: v for k, v in params.items() if k.startswith(pre)}
+            tp.update(nhead=tl["nhead"], norm_first=tl.get("norm_first", False), eps=1e-5)
+            tlayers.append(tp)
+        learner["tlayers"] = tlayers
+        learner["textual_dim"] = cfg.text_config.hidden_size
+        return learner
     if layers:
         proj = []
         for d in range(depth):

@@ -38,9 +38,12 @@ def build_net(fx, device="cuda"):
                 return r
 
         lkw["tokenizer"] = Tok()
-    net_cls = {"vpt": nets.VPTCLIPSeg, "coop": nets.COOPCLIPSeg, "cocoop": nets.COOPCLIPSeg, "maple": nets.MapleCLIPSeg}[kind]
+    if "_tlayer" in lkw:
+        lkw["unified_projector"] = partial(torch.nn.TransformerEncoderLayer, **lkw.pop("_tlayer"))
+    net_cls = {"vpt": nets.VPTCLIPSeg, "coop": nets.COOPCLIPSeg, "cocoop": nets.COOPCLIPSeg, "maple": nets.MapleCLIPSeg,
+               "shared_separate": nets.SharedSeparateCLIPSeg, "shared_attn": nets.SharedAttnCLIPSeg}[kind]
     learner_cls = {"vpt": CL.VPTContextLearner, "coop": CL.CoOpContextLearner, "cocoop": CL.CoCoOpContextLearner,
-                   "maple": CL.MapleContextLearner}[kind]
+                   "maple": CL.MapleContextLearner, "shared_separate": CL.SharedSeparateLearner, "shared_attn": CL.SharedAttnLearner}[kind]
     spec = f"random:{m['preset']}:seed={m['weight_seed']}:eos={m['eos_token_id']}"
     net = net_cls(context_learner=partial(learner_cls, **lkw),
                   model_cfg={"pretrained_model_name_or_path": spec, "freeze_encoder": False, "freeze_decoder": False}, **m["net_kw"])

@@ -23,7 +23,7 @@ def run_oracle(fx):
         logits = O.vpt_forward(sd, cfg, learner, pix, ids, am, new_last_of(fx, params))
     elif kind in ("coop", "cocoop"):
         logits = O.coop_forward(sd, cfg, learner, pix, ids, am)
-    else:
+    else:  # maple / shared_*: BaseMultimodalCLIPSeg.model_forward
         logits = O.maple_forward(sd, cfg, learner, pix, ids, am, new_last_of(fx, params))
     loss = O.dice_ce_loss(logits, mask)
     loss.backward()

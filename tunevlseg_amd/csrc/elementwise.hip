@@ -294,6 +294,21 @@ __global__ void outer_add_bwd_kernel(const float* __restrict__ dout, float* __re
     }
 }
 
+// counter-based dropout: keep(i) is a pure function of (seed, i), so the backward pass regenerates the same mask
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p, float scale, unsigned long long seed) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const unsigned long long r = mix64(seed ^ mix64((unsigned long long)i));
+        const float u = (float)(r >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0,1)
+        y[i] = u >= p ? x[i] * scale : 0.f;
+    }
+}
+
 // out[0] (+)= sum_i x[i]*y[i]  (double accumulation inside the block, one float atomic per block)
 __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, long n) {
     __shared__ double s[4];
@@ -495,5 +510,12 @@ extern "C" int tvl_splice_rows(const float* x, int32_t L, const int32_t* map, co
     TVL_REQUIRE(x && map && ctx && out && B > 0 && T > 0 && D > 0 && L > 0, "tvl_splice_rows: bad arguments");
     hipLaunchKernelGGL(splice_rows_kernel, GRID_FOR((long)B * T * D), dim3(256), 0, S_(stream), x, L, map, ctx, (long)ctx_bs, out, B, T, D);
     TVL_LAUNCH_CHECK("tvl_splice_rows");
+    return 0;
+}
+
+extern "C" int tvl_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, tvlStream_t stream) {
+    TVL_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "tvl_dropout: bad arguments (p=%f)", (double)p);
+    hipLaunchKernelGGL(dropout_kernel, GRID_FOR((long)n), dim3(256), 0, S_(stream), x, y, (long)n, p, 1.0f / (1.0f - p), (unsigned long long)seed);
+    TVL_LAUNCH_CHECK("tvl_dropout");
     return 0;
 }

@@ -100,6 +100,7 @@ _SIGS = {
     "tvl_fill": [_P, _F, _L],
     "tvl_axpby": [_P, _F, _P, _F, _L],
     "tvl_bias_act": [_P, _P, _P, _L, _I, _I],
+    "tvl_dropout": [_P, _P, _L, _F, C.c_uint64],
     "tvl_dact_mul": [_P, _P, _P, _L, _I],
     "tvl_outer_add": [_P, _P, _P, _I, _I, _I],
     "tvl_outer_add_bwd": [_P, _P, _P, _I, _I, _I],
@@ -504,3 +505,9 @@ def splice_rows(x, tmap, ctx, ctx_bs: int):
     out = torch.empty((B, T, D), device=x.device, dtype=torch.float32)
     _call("tvl_splice_rows", _p(x), L, _p(tmap, torch.int32), _p(ctx), ctx_bs, _p(out), B, T, D)
     return out
+
+
+def dropout(x, p: float, seed: int):
+    y = torch.empty_like(x)
+    _call("tvl_dropout", _p(x), _p(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF)
+    return y

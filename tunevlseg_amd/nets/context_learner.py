@@ -8,6 +8,7 @@ their math runs through the HIP ops of ``tunevlseg_amd.ops``.
 """
 from __future__ import annotations
 
+import copy
 import itertools
 from abc import ABC, abstractmethod
 from collections.abc import Iterable, Sequence
@@ -272,3 +273,122 @@ class MapleContextLearner(BaseProjectorLearner, BaseVisualLearner):
 
     def get_visual_context(self, *args, **kwargs) -> torch.Tensor:
         return self.get_transformed_context(*args, **kwargs)
+
+
+class BaseSharedLearner(CoOpContextLearner, BaseVisualLearner):
+    """reference ``base_shared_learner.py:5-11``"""
+
+    def __init__(self, **kwargs):
+        kwargs["context_initializer"] = None
+        kwargs["tokenizer"] = None
+        kwargs["embedding_layer"] = None
+        super().__init__(**kwargs)
+
+
+class SharedSeparateLearner(BaseSharedLearner):
+    """reference ``shared_separate_learner.py:11-98``: one shared prompt, two MLPs (textual / visual)."""
+
+    def __init__(self, *, textual_dim: int, visual_dim: int, shared_dim: int = 64, prompt_depth: int = BaseSharedLearner.MIN_PROMPT_DEPTH,
+                 use_unified_projection: bool = True, intermediate_dim: int | Iterable[int] | None = None, use_proj_norm: bool = False,
+                 use_lora_proj: bool = False, **kwargs) -> None:
+        if use_lora_proj and intermediate_dim is not None and not isinstance(intermediate_dim, int):
+            raise ValueError("Lora projection is only available for a single layer.")
+        kwargs["context_dim"] = shared_dim
+        super().__init__(prompt_depth=prompt_depth, **kwargs)
+        getter = (BaseProjectorLearner.get_lora_projection if use_lora_proj and intermediate_dim is not None
+                  else BaseProjectorLearner.get_mlp_projection)
+        init_kwargs = {"in_dim": shared_dim, "out_dim": textual_dim, "intermediate_dim": intermediate_dim, "use_final_norm": use_proj_norm}
+        self.textual_projection_layers = self.get_projection_layers(getter(**init_kwargs), prompt_depth, use_unified_projection)
+        init_kwargs["out_dim"] = visual_dim
+        self.visual_projection_layers = self.get_projection_layers(getter(**init_kwargs), prompt_depth, use_unified_projection)
+
+    @staticmethod
+    def get_projection_layers(single_layer: nn.Module, prompt_depth: int, use_unified_projection) -> nn.ModuleList:
+        return nn.ModuleList((single_layer,) * prompt_depth if use_unified_projection
+                             else (copy.deepcopy(single_layer) for _ in range(prompt_depth)))
+
+    def get_textual_context(self, in_context: torch.Tensor | None = None, image_features: torch.Tensor | None = None, index: int = 0):
+        if in_context is None:
+            in_context = self.context_vectors[index]
+        return run_projection(self.textual_projection_layers[index], in_context)
+
+    def get_visual_context(self, in_context: torch.Tensor | None = None, index: int = 0) -> torch.Tensor:
+        if in_context is None:
+            in_context = self.context_vectors[index]
+        return run_projection(self.visual_projection_layers[index], in_context)
+
+
+class SharedAttnLearner(BaseSharedLearner):
+    """reference ``shared_attn_learner.py:9-104``: shared prompt (textual_dim + visual_dim wide) through an
+    ``nn.TransformerEncoderLayer``, split into its textual / visual column blocks; the cross-modal half is cached between
+    the vision pass and the text pass (kept on the device here; the reference parks it on the CPU).
+
+    The reference feeds ``ctx[index].unsqueeze(0)`` = [1, n, E] to a ``batch_first=False`` layer, i.e. n independent
+    length-1 sequences: softmax over one key is 1, so self-attention reduces exactly to ``out_proj(v_proj(x))`` (the q/k
+    rows of ``in_proj`` receive zero gradient, as in the reference).  The torch layer object only holds the parameters.
+    """
+
+    def __init__(self, *, textual_dim: int, visual_dim: int, unified_projector, prompt_depth: int = BaseSharedLearner.MIN_PROMPT_DEPTH,
+                 use_unified_projection: bool = True, **kwargs) -> None:
+        if unified_projector is None:
+            raise NotImplementedError("You need to provide a transformer encoder layer for the unified projection layer from the config.")
+        context_dim = textual_dim + visual_dim
+        kwargs["context_dim"] = context_dim
+        super().__init__(prompt_depth=prompt_depth, **kwargs)
+        transformer_layer = unified_projector(d_model=context_dim)
+        if getattr(transformer_layer.self_attn, "batch_first", False):
+            raise NotImplementedError("batch_first=True (real attention over the prompt tokens) is not used by the reference configs")
+        act = getattr(transformer_layer, "activation", None)
+        if getattr(act, "__name__", "relu") != "relu":
+            raise NotImplementedError("only the default relu activation of nn.TransformerEncoderLayer is implemented")
+        self.projection_layers = nn.ModuleList((transformer_layer,) * prompt_depth if use_unified_projection
+                                               else (copy.deepcopy(transformer_layer) for _ in range(prompt_depth)))
+        self._computed_textual_context_cache: dict[int, torch.Tensor] = {}
+        self._computed_visual_context_cache: dict[int, torch.Tensor] = {}
+        self.textual_dim = textual_dim
+        self.visual_dim = visual_dim
+
+    def _run_layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor) -> torch.Tensor:
+        E = x.shape[-1]
+        attn = layer.self_attn
+        wv, bv = attn.in_proj_weight[2 * E:], (attn.in_proj_bias[2 * E:] if attn.in_proj_bias is not None else None)
+        tr = layer.training
+
+        def sa(t):
+            v = ops.linear(t, wv, bv)
+            return ops.dropout(ops.linear(v, attn.out_proj.weight, attn.out_proj.bias), layer.dropout1.p, tr)
+
+        def ff(t):
+            h1 = ops.dropout(ops.linear(t, layer.linear1.weight, layer.linear1.bias, hip.ACT_RELU), layer.dropout.p, tr)
+            return ops.dropout(ops.linear(h1, layer.linear2.weight, layer.linear2.bias), layer.dropout2.p, tr)
+
+        n1 = lambda t: ops.layer_norm(t, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)  # noqa: E731
+        n2 = lambda t: ops.layer_norm(t, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)  # noqa: E731
+        if layer.norm_first:
+            x = ops.add(x, sa(n1(x)))
+            return ops.add(x, ff(n2(x)))
+        x = n1(ops.add(x, sa(x)))
+        return n2(ops.add(x, ff(x)))
+
+    def _get_combined_transformed_context(self, is_curr_branch_textual: bool, in_context: torch.Tensor | None = None, index: int = 0):
+        read_cache = self._computed_textual_context_cache if is_curr_branch_textual else self._computed_visual_context_cache
+        cached = read_cache.pop(index, None)
+        if cached is not None:
+            return cached
+        if in_context is None:
+            in_context = self.context_vectors[index].unsqueeze(0)
+        if in_context.ndim != 3:
+            raise ValueError("The tensor needs to have 3 dimensions: (batch, context_len, hidden_dim)")
+        out = self._run_layer(self.projection_layers[index], in_context.squeeze(0))
+        textual, visual = ops.split_cols(out, self.textual_dim)
+        if is_curr_branch_textual:
+            self._computed_visual_context_cache[index] = visual
+            return textual
+        self._computed_textual_context_cache[index] = textual
+        return visual
+
+    def get_textual_context(self, image_features: torch.Tensor | None = None, *args, **kwargs) -> torch.Tensor:
+        return self._get_combined_transformed_context(*args, is_curr_branch_textual=True, **kwargs)
+
+    def get_visual_context(self, *args, **kwargs) -> torch.Tensor:
+        return self._get_combined_transformed_context(*args, is_curr_branch_textual=False, **kwargs)

@@ -45,3 +45,25 @@ class MapleCLIPSeg(BaseMultimodalCLIPSeg):
             context_dim=cfg.text_config.hidden_size,
             embedding_layer=self.model.clip.text_model.embeddings.token_embedding,
         )
+
+
+class _SharedCLIPSeg(BaseMultimodalCLIPSeg):
+    """reference ``shared_attn_learner_clipseg.py:11-25`` / ``shared_separate_learner_clipseg.py:11-26``"""
+
+    def __init__(self, context_learner, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        cfg = self.model.config
+        self.context_learner = context_learner(
+            textual_dim=cfg.text_config.hidden_size,
+            visual_dim=cfg.vision_config.hidden_size,
+            max_network_depth=min(cfg.text_config.num_hidden_layers, cfg.vision_config.num_hidden_layers),
+            context_dim=cfg.text_config.hidden_size,
+        )
+
+
+class SharedAttnCLIPSeg(_SharedCLIPSeg):
+    pass
+
+
+class SharedSeparateCLIPSeg(_SharedCLIPSeg):
+    pass

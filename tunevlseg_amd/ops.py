@@ -499,3 +499,51 @@ def splice_rows(x, cvec, tmap_list):
 def concat_rows(x, cvec):
     L, n = x.shape[1], cvec.shape[-2]
     return SpliceRowsFn.apply(x, cvec, [*range(L), *[-(j + 1) for j in range(n)]])
+
+
+_dropout_calls = 0
+
+
+class DropoutFn(Fn):
+    """nn.Dropout (training): counter-based mask, regenerated in backward from the same (seed, call index)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        global _dropout_calls
+        _dropout_calls += 1
+        ctx.p = p
+        ctx.seed = (torch.initial_seed() * 0x9E3779B1 + _dropout_calls) & 0xFFFFFFFFFFFFFFFF
+        return hip.dropout(_c(x), p, ctx.seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return hip.dropout(_c(dy), ctx.p, ctx.seed), None
+
+
+def dropout(x, p: float, training: bool):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, p)
+
+
+class AddFn(Fn):
+    """a + b (residual adds inside the SharedAttn learner's transformer layer)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = _c(b).clone()
+        hip.axpby(_c(a), 1.0, out, 1.0)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+def split_cols(x, k: int):
+    """Column split of a small [n, E] tensor -- pure data movement (autograd slice views), no arithmetic."""
+    return x[:, :k], x[:, k:]
