@@ -1,0 +1,81 @@
+"""Update path on the GPU: two fused-AdamW train steps against the CPU oracle + torch.optim.AdamW, and the fit loop."""
+from functools import partial
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny_module(depth=2, n=4, new_last=True, lr=2e-3, weight_decay=0.0, seed=11):
+    from tunevlseg_amd import nets
+    from tunevlseg_amd.nets.context_learner import VPTContextLearner
+    from tunevlseg_amd.task import DiceCELoss, FusedAdamW, ImageTextMaskModule, ReduceLROnPlateau
+
+    torch.manual_seed(0)
+    net = nets.VPTCLIPSeg(context_learner=partial(VPTContextLearner, prompt_depth=depth, num_context=n),
+                          model_cfg={"pretrained_model_name_or_path": f"random:tiny:seed={seed}"}, use_new_last_layer=new_last)
+    return ImageTextMaskModule(net, DiceCELoss(sigmoid=True, lambda_dice=1, lambda_ce=0.2), optimizer=partial(FusedAdamW, lr=lr),
+                               scheduler=partial(ReduceLROnPlateau, mode="min", factor=0.2, patience=5), weight_decay=weight_decay).cuda()
+
+
+def test_two_adamw_steps_match_oracle():
+    from oracle import clipseg_oracle as O
+    from tunevlseg_amd.config import CLIPSegConfig
+    from tunevlseg_amd.weights import init_clipseg_state_dict
+
+    module = tiny_module(weight_decay=0.01)
+    net = module.net
+    g = torch.Generator().manual_seed(3)
+    pix = torch.randn(3, 3, 64, 64, generator=g)
+    ids = torch.tensor([[62, 5, 9, 63, 1, 1], [62, 7, 11, 13, 63, 1], [62, 8, 63, 1, 1, 1]])
+    am = (ids != 1).long()
+    mask = (torch.rand(3, 1, 64, 64, generator=g) > 0.7).float()
+    # CPU reference: oracle forward + torch AdamW with the same decay / no-decay split
+    cfg, sd = CLIPSegConfig.tiny(), init_clipseg_state_dict(CLIPSegConfig.tiny(), 11)
+    ctx = net.context_learner.context_vectors.detach().cpu().clone().requires_grad_(True)
+    conv = net.additive_decoder_layer[1]
+    cw, cb = conv.weight.detach().cpu().clone().requires_grad_(True), conv.bias.detach().cpu().clone().requires_grad_(True)
+    ropt = torch.optim.AdamW([{"params": [cw], "weight_decay": 0.01}, {"params": [ctx, cb], "weight_decay": 0.0}], lr=2e-3)
+    module.setup("fit")
+    opt = module.configure_optimizers()["optimizer"]
+    batch = {"image": pix.cuda(), "input_ids": ids.cuda(), "attention_mask": am.cuda(), "mask": mask.cuda()}
+    for _ in range(2):
+        opt.zero_grad()
+        module.training_step(batch).backward()
+        opt.step()
+        ropt.zero_grad()
+        logits = O.vpt_forward(sd, cfg, {"kind": "vpt", "ctx": ctx}, pix, ids, am, (cw, cb, torch.tensor(0.5)))
+        O.dice_ce_loss(logits, mask).backward()
+        ropt.step()
+    for mine, ref, name in ((net.context_learner.context_vectors, ctx, "ctx"), (conv.weight, cw, "conv_w"), (conv.bias, cb, "conv_b")):
+        err = (mine.detach().cpu() - ref.detach()).abs().max().item()
+        # Adam's first steps move every entry by ~lr regardless of gradient scale: compare against lr
+        assert err <= 2e-3 * 2e-2, f"{name}: {err:.3e}"
+    m = module.epoch_metrics("train")
+    assert 0.0 <= m["train_dice"] <= 1.0 and 0.0 <= m["train_iou"] <= 1.0
+
+
+def test_fit_reduces_loss_and_checkpoints_round_trip(tmp_path):
+    from tunevlseg_amd.trainer import SyntheticImageTextMaskLoader, Trainer
+
+    module = tiny_module(depth=3, n=4, new_last=True, lr=5e-3)
+    tr = SyntheticImageTextMaskLoader(4, 4, 64, "cuda", seed=1, vocab=64, bos=62, eos=63, pad=1, max_len=6)
+    va = SyntheticImageTextMaskLoader(2, 4, 64, "cuda", seed=2, vocab=64, bos=62, eos=63, pad=1, max_len=6)
+    logs = []
+    trainer = Trainer(max_epochs=6, min_epochs=1, default_root_dir=str(tmp_path), log_fn=logs.append)
+    final = trainer.fit(module, tr, va)
+    first = float(logs[0].split("train_loss=")[1].split()[0])
+    assert final["train_loss"] < first - 0.01, (first, final)
+    assert trainer.best_path is not None and (tmp_path / "last.ckpt").exists()
+    before = {k: p.detach().clone() for k, p in module.named_parameters() if p.requires_grad}
+    with torch.no_grad():
+        for p in module.parameters():
+            if p.requires_grad:
+                p.add_(1.0)
+    Trainer.load(module, tmp_path / "last.ckpt")
+    for k, p in module.named_parameters():
+        if p.requires_grad:
+            assert torch.equal(p.detach(), before[k]), k
+    test_metrics = trainer.test(module, va, ckpt_path="best")
+    assert set(test_metrics) == {"test_dice", "test_iou", "test_loss"}
