@@ -27,6 +27,7 @@ void tvl_set_error(const char* fmt, ...);
     } while (0)
 
 static inline bool tvl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__device__ __forceinline__ bool tvl_dev_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

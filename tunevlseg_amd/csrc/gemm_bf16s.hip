@@ -16,6 +16,7 @@
 // BK = 32, ONE LDS stage (S planes per operand) + register prefetch of the next slab, two barriers per slab.
 // LDS rows are 32 bf16 + 8 pad = 80 bytes = 20 dwords, so the 16 rows of a ds_read_b128 lane group start on 16
 // distinct 16-byte slots: conflict free.  Fragment map (guide §3): lane l -> row l&31, k = 8*(l>>5) .. +7.
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -24,8 +25,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDB = BK + 8;  // bf16 elements per LDS row (80 bytes)
 constexpr int NTHREADS = 256;
 
 struct GemmParams {
@@ -61,21 +60,26 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ base, long row
     return v;
 }
 
-template <int ROWS>
+// one operand slab = ROWS x BK fp32 = ROWS*BK/4 float4, dealt round-robin over the 256 threads
+template <int ROWS, int BK>
 struct StageRegs {
-    float4 v[ROWS / 32];
+    static constexpr int TOTAL = ROWS * BK / 4;
+    static constexpr int N = (TOTAL + NTHREADS - 1) / NTHREADS;
+    float4 v[N];
 };
 
-template <int ROWS, bool VEC>
-__device__ __forceinline__ void gload(StageRegs<ROWS>& s, const float* __restrict__ base, int ld, int row0, int nrows, int k0, int K,
+template <int ROWS, int BK, bool VEC>
+__device__ __forceinline__ void gload(StageRegs<ROWS, BK>& s, const float* __restrict__ base, int ld, int row0, int nrows, int k0, int K,
                                       const tvlRowMap& map) {
-    const int t = threadIdx.x;
-    const int c = t & 7, r0 = t >> 3;
+    constexpr int F4 = BK / 4;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        int r = row0 + r0 + 32 * i;
-        r = r < nrows ? r : nrows - 1;
-        s.v[i] = load4<VEC>(base, map_row(r, map), k0 + 4 * c, K, ld);
+    for (int i = 0; i < StageRegs<ROWS, BK>::N; ++i) {
+        const int idx = threadIdx.x + NTHREADS * i;
+        if (StageRegs<ROWS, BK>::TOTAL % NTHREADS == 0 || idx < StageRegs<ROWS, BK>::TOTAL) {
+            int r = row0 + idx / F4;
+            r = r < nrows ? r : nrows - 1;
+            s.v[i] = load4<VEC>(base, map_row(r, map), k0 + 4 * (idx % F4), K, ld);
+        }
     }
 }
 
@@ -104,28 +108,86 @@ __device__ __forceinline__ void split4(const float4 v, uint2 (&out)[S]) {
     }
 }
 
-template <int ROWS, int S>
-__device__ __forceinline__ void sstore(const StageRegs<ROWS>& sr, __bf16* __restrict__ lds) {
-    const int t = threadIdx.x;
-    const int c = t & 7, r0 = t >> 3;
+template <int ROWS, int BK, int S>
+__device__ __forceinline__ void sstore(const StageRegs<ROWS, BK>& sr, __bf16* __restrict__ lds) {
+    constexpr int F4 = BK / 4;
+    constexpr int LDB = BK + 8;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        uint2 pl[S];
-        split4<S>(sr.v[i], pl);
+    for (int i = 0; i < StageRegs<ROWS, BK>::N; ++i) {
+        const int idx = threadIdx.x + NTHREADS * i;
+        if (StageRegs<ROWS, BK>::TOTAL % NTHREADS == 0 || idx < StageRegs<ROWS, BK>::TOTAL) {
+            uint2 pl[S];
+            split4<S>(sr.v[i], pl);
 #pragma unroll
-        for (int s = 0; s < S; ++s) *reinterpret_cast<uint2*>(&lds[(s * ROWS + r0 + 32 * i) * LDB + 4 * c]) = pl[s];
+            for (int s = 0; s < S; ++s) *reinterpret_cast<uint2*>(&lds[(s * ROWS + idx / F4) * LDB + 4 * (idx % F4)]) = pl[s];
+        }
     }
 }
 
-template <int BM, int BN, int WGM, int S, bool VEC>
+// epilogue of a transposed-product accumulator tile: lane -> row l31, registers 4g..4g+3 -> columns 8g+4h .. 8g+4h+3
+template <int TM, int TN, bool VEC>
+__device__ __forceinline__ void epilogue_t(const GemmParams& p, f32x16 (&acc)[TM][TN], int row_base, int col_base, int l31, int h) {
+    const bool vec_c = VEC && (p.ldc % 4 == 0) && tvl_dev_aligned16(p.C) && (!p.pre_out || tvl_dev_aligned16(p.pre_out)) &&
+                       (!p.residual || (p.ldr % 4 == 0 && tvl_dev_aligned16(p.residual))) &&
+                       (!p.dact || (p.ld_aux % 4 == 0 && tvl_dev_aligned16(p.dact_aux))) && (!p.bias || tvl_dev_aligned16(p.bias));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = row_base + i * 32 + l31;
+        if (row >= p.M) continue;
+        const long crow = map_row(row, p.c_map);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = col_base + j * 32 + 8 * g + 4 * h;
+                if (col >= p.N) continue;
+                float v[4] = {acc[i][j][4 * g] * p.alpha, acc[i][j][4 * g + 1] * p.alpha, acc[i][j][4 * g + 2] * p.alpha,
+                              acc[i][j][4 * g + 3] * p.alpha};
+                if (vec_c && col + 3 < p.N) {
+                    if (p.bias) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col);
+                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                    }
+                    if (p.dact) {
+                        const float4 z4 = *reinterpret_cast<const float4*>(p.dact_aux + crow * p.ld_aux + col);
+                        v[0] *= dact_f(z4.x, p.dact); v[1] *= dact_f(z4.y, p.dact); v[2] *= dact_f(z4.z, p.dact); v[3] *= dact_f(z4.w, p.dact);
+                    }
+                    if (p.pre_out) *reinterpret_cast<float4*>(p.pre_out + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+                    if (p.residual) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + crow * p.ldr + col);
+                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                    }
+                    *reinterpret_cast<float4*>(p.C + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = col + e;
+                        if (c >= p.N) continue;
+                        float x = v[e] + (p.bias ? p.bias[c] : 0.f);
+                        if (p.dact) x *= dact_f(p.dact_aux[crow * p.ld_aux + c], p.dact);
+                        if (p.pre_out) p.pre_out[crow * p.ldc + c] = x;
+                        x = act_f(x, p.act);
+                        if (p.residual) x += p.residual[crow * p.ldr + c];
+                        p.C[crow * p.ldc + c] = x;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
+    constexpr int LDB = BK + 8;  // bf16 elements per LDS row: 80 B (BK 32) / 48 B (BK 16), both conflict free for ds_read_b128
+    constexpr int STAGE_ELEMS = S * (BM + BN) * LDB;
     constexpr int WGN = 4 / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __bf16* As = reinterpret_cast<__bf16*>(smem_raw);  // [S][BM][LDB]
-    __bf16* Bs = As + S * BM * LDB;                    // [S][BN][LDB]
+    __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);  // per stage: A [S][BM][LDB] then B [S][BN][LDB]
 
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
@@ -148,36 +210,45 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    StageRegs<BM> sa;
-    StageRegs<BN> sb;
+    StageRegs<BM, BK> sa;
+    StageRegs<BN, BK> sb;
     const tvlRowMap ident = {0, 0, 0};
     const int nk = (p.K + BK - 1) / BK;
 
-    gload<BM, VEC>(sa, p.A, p.lda, m0, p.M, 0, p.K, p.a_map);
-    gload<BN, VEC>(sb, p.B, p.ldb, n0, p.N, 0, p.K, ident);
-    sstore<BM, S>(sa, As);
-    sstore<BN, S>(sb, Bs);
+    gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, 0, p.K, p.a_map);
+    gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, 0, p.K, ident);
+    sstore<BM, BK, S>(sa, smem);
+    sstore<BN, BK, S>(sb, smem + S * BM * LDB);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
+        const int cur = STAGES == 2 ? (kt & 1) : 0;
+        const __bf16* As = smem + cur * STAGE_ELEMS;
+        const __bf16* Bs = As + S * BM * LDB;
         if (kt + 1 < nk) {
-            gload<BM, VEC>(sa, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, p.a_map);
-            gload<BN, VEC>(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, ident);
+            gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, p.a_map);
+            gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, ident);
         }
+        // all fragment reads of the slab are issued before its first MFMA; the compiler then waits with counted
+        // lgkmcnt(N) so the later reads land underneath the earlier MFMAs
+        bf16x8 af[BK / 16][TM][S], bf[BK / 16][TN][S];
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 af[TM][S], bf[TN][S];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int s = 0; s < S; ++s)
-                    af[i][s] = *reinterpret_cast<const bf16x8*>(&As[(s * BM + wm * WM + i * 32 + l31) * LDB + ks * 16 + 8 * h]);
+                    af[ks][i][s] = *reinterpret_cast<const bf16x8*>(&As[(s * BM + wm * WM + i * 32 + l31) * LDB + ks * 16 + 8 * h]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int s = 0; s < S; ++s)
-                    bf[j][s] = *reinterpret_cast<const bf16x8*>(&Bs[(s * BN + wn * WN + j * 32 + l31) * LDB + ks * 16 + 8 * h]);
-            // smallest-magnitude piece pairs first, the a1*b1 term last
+                    bf[ks][j][s] = *reinterpret_cast<const bf16x8*>(&Bs[(s * BN + wn * WN + j * 32 + l31) * LDB + ks * 16 + 8 * h]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            // smallest-magnitude piece pairs first, the a1*b1 term last; mfma(b, a) = transposed product, so that a lane's
+            // 4 consecutive accumulator registers are 4 consecutive COLUMNS of one row of C (16-byte epilogue accesses)
 #pragma unroll
             for (int order = S - 1; order >= 0; --order)
 #pragma unroll
@@ -187,48 +258,28 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][sa_], bf[j][sb_], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j][sb_], af[ks][i][sa_], acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();  // every wave is done reading this slab
+        if (STAGES == 1) __syncthreads();  // every wave is done reading this slab before it is overwritten
         if (kt + 1 < nk) {
-            sstore<BM, S>(sa, As);
-            sstore<BN, S>(sb, Bs);
+            __bf16* dst = smem + (STAGES == 2 ? (cur ^ 1) * STAGE_ELEMS : 0);
+            sstore<BM, BK, S>(sa, dst);
+            sstore<BN, BK, S>(sb, dst + S * BM * LDB);
         }
         __syncthreads();
     }
-
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int n = 0; n < TN; ++n) {
-            const int col = n0 + wn * WN + n * 32 + l31;
-            if (col >= p.N) continue;
-            const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                const long crow = map_row(row, p.c_map);
-                float v = acc[i][n][r] * p.alpha + bv;
-                if (p.dact) v *= dact_f(p.dact_aux[crow * p.ld_aux + col], p.dact);
-                if (p.pre_out) p.pre_out[crow * p.ldc + col] = v;
-                v = act_f(v, p.act);
-                if (p.residual) v += p.residual[crow * p.ldr + col];
-                p.C[crow * p.ldc + col] = v;
-            }
-        }
-    }
+    epilogue_t<TM, TN, VEC>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
 }
 
-template <int BM, int BN, int WGM, int S, bool VEC>
-int launch(const GemmParams& p0, hipStream_t s) {
+template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES>
+int launch_v(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    constexpr size_t smem = (size_t)S * (BM + BN) * LDB * sizeof(__bf16);
+    constexpr size_t smem = (size_t)STAGES * S * (BM + BN) * (BK + 8) * sizeof(__bf16);
     static bool attr_set = false;
-    auto kern = gemm_bf16s_kernel<BM, BN, WGM, S, VEC>;
+    auto kern = gemm_bf16s_kernel<BM, BN, WGM, S, VEC, BK, STAGES>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
@@ -236,6 +287,11 @@ int launch(const GemmParams& p0, hipStream_t s) {
     const long nwg = (long)p.tiles_m * p.tiles_n;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NTHREADS), smem, s, p);
     return 0;
+}
+
+template <int BM, int BN, int WGM, int S, bool VEC>
+int launch(const GemmParams& p, hipStream_t s) {
+    return launch_v<BM, BN, WGM, S, VEC, 32, 1>(p, s);
 }
 
 template <int S, bool VEC>

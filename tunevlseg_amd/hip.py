@@ -212,7 +212,7 @@ def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True, split: int = 
         if best is None or cost < best:
             best, tile = cost, (bm, bn, wgm)
     if split:
-        return f"gemm_bf16s_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {split}, {'true' if vec else 'false'}>"
+        return f"gemm_bf16s_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {split}, {'true' if vec else 'false'}, 32, 1>"
     ak, bk = {NT: ("true", "true"), NN: ("true", "false"), TN: ("false", "false")}[layout]
     return f"gemm_f32_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {ak}, {bk}, {'true' if vec else 'false'}>"
 
