@@ -15,6 +15,7 @@
 // Both recompute P from Q, K and the forward's LSE.
 //
 // kappa(r,h) = (r&3) + 8*(r>>2) + 4*h : row of a 32x32 accumulator held in register r of lane half h.
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -546,9 +547,24 @@ extern "C" int tvl_attn_fwd(const tvlAttnFwdArgs* a, tvlStream_t stream) {
     p.B = a->B; p.H = a->H; p.T = a->T; p.causal = a->causal; p.scale = a->scale;
     dim3 grid((a->T + 127) / 128, a->H, a->B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a->dh == 64 && !a->causal && !a->key_mask && tvl_attn_mode_bf16s()) {
+        tvl_attn_fwd_bf16s_impl(a, s);
+        TVL_LAUNCH_CHECK("tvl_attn_fwd(bf16s)");
+        return 0;
+    }
     TVL_DH_DISPATCH(a->dh, hipLaunchKernelGGL(attn_fwd_kernel<DH>, grid, dim3(256), 0, s, p));
     TVL_LAUNCH_CHECK("tvl_attn_fwd");
     return 0;
+}
+
+// TVL_ATTN_MODE=f32 keeps every attention on the exact-fp32 MFMA kernels; default: 3xbf16-split kernels where they apply
+int tvl_attn_mode_bf16s(void) {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("TVL_ATTN_MODE");
+        mode = (e && e[0] == 'f') ? 0 : 1;
+    }
+    return mode;
 }
 
 extern "C" int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream) {
