@@ -592,6 +592,11 @@ extern "C" int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream) {
                                                   a->delta, a->B, a->H, a->T));
         TVL_LAUNCH_CHECK("tvl_attn_bwd(delta)");
     }
+    if (a->dh == 64 && !a->causal && !a->key_mask && tvl_attn_mode_bf16s()) {
+        tvl_attn_bwd_bf16s_impl(a, s);
+        TVL_LAUNCH_CHECK("tvl_attn_bwd(bf16s)");
+        return 0;
+    }
     dim3 grid((a->T + 127) / 128, a->H, a->B);
     TVL_DH_DISPATCH(a->dh, hipLaunchKernelGGL(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p));
     TVL_LAUNCH_CHECK("tvl_attn_bwd(dq)");

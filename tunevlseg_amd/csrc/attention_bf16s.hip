@@ -227,6 +227,289 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward, same two-kernel split as attention.hip (dQ: query on the lane; dK/dV: key on the lane), P recomputed from
+// Q, K and the forward LSE.  Tiles that are read both by rows (first products) and transposed (second products) use
+// the 144-byte row stride: conflict free for ds_read_b128, 2-way for half of the transposed reads.
+// ------------------------------------------------------------------------------------------------------------------
+struct BwdParams {
+    const float *q, *k, *v; long q_bs, k_bs, v_bs; int q_ts, k_ts, v_ts;
+    const float* d_o; int ldo; const float* lse; const float* delta;
+    float *dq, *dk, *dv; long dq_bs, dk_bs, dv_bs; int dq_ts, dk_ts, dv_ts;
+    int B, H, T; float scale;
+};
+
+// 8 consecutive fp32 of one row -> three bf16x8 fragments (optionally scaled)
+__device__ __forceinline__ void row_frags(const float* __restrict__ src, float sc, bf16x8 (&out)[S]) {
+    const float4 a = *reinterpret_cast<const float4*>(src);
+    const float4 c = *reinterpret_cast<const float4*>(src + 4);
+    float x[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, c.x * sc, c.y * sc, c.z * sc, c.w * sc};
+    unsigned p0[4], p1[4], p2[4];
+    split3<8>(x, p0, p1, p2);
+    out[0] = frag_of(p0[0], p0[1], p0[2], p0[3]);
+    out[1] = frag_of(p1[0], p1[1], p1[2], p1[3]);
+    out[2] = frag_of(p2[0], p2[1], p2[2], p2[3]);
+}
+// row fragments of k16-step s from an LDS tile [3][32][LDKB]
+__device__ __forceinline__ void lds_row_frags(const __bf16* __restrict__ t, int l31, int h, int s, bf16x8 (&out)[S]) {
+#pragma unroll
+    for (int pl = 0; pl < S; ++pl) out[pl] = *reinterpret_cast<const bf16x8*>(&t[(pl * 32 + l31) * LDKB + 16 * s + 8 * h]);
+}
+// transposed fragments (A[i = column d][k = row]) of k-step s2 / 32-column block d from an LDS tile [3][32][LD]
+template <int LD>
+__device__ __forceinline__ void lds_tr_frags(const __bf16* __restrict__ t, int tr_row, int tr_col, int h, int s2, int d, bf16x8 (&out)[S]) {
+#pragma unroll
+    for (int pl = 0; pl < S; ++pl) {
+        const __bf16* base = t + (pl * 32 + 16 * s2 + 4 * h + tr_row) * LD + d * 32 + tr_col;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 8 * LD));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        out[pl] = frag_of(l2.x, l2.y, h2.x, h2.y);
+    }
+}
+__device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[S], const bf16x8 (&b)[S], f32x16 acc) {
+#pragma unroll
+    for (int order = S - 1; order >= 0; --order)
+#pragma unroll
+        for (int i = 0; i <= order; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[order - i], acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16s_kernel(BwdParams p) {
+    constexpr int TSZ = S * 32 * LDKB;
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[2][TSZ];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[2][TSZ];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int T = p.T;
+    const int qi = blockIdx.x * 128 + wave * 32 + l31;
+    const int qrow = qi < T ? qi : T - 1;
+    const float* qb = p.q + b * p.q_bs + head * DH;
+    const float* kb = p.k + b * p.k_bs + head * DH;
+    const float* vb = p.v + b * p.v_bs + head * DH;
+    const float* dob = p.d_o + ((long)b * T) * p.ldo + head * DH;
+
+    bf16x8 qf[4][S], dof[4][S];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        row_frags(qb + (long)qrow * p.q_ts + 16 * s + 8 * h, p.scale * LOG2E, qf[s]);
+        row_frags(dob + (long)qrow * p.ldo + 16 * s + 8 * h, 1.0f, dof[s]);
+    }
+    const long stat = ((long)b * p.H + head) * T + qrow;
+    const float lse2 = p.lse[stat] * LOG2E;
+    const float dl = p.delta[stat];
+
+    f32x16 acc_dq[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_dq[d][r] = 0.f;
+    const int li = lane & 15;
+    const int tr_row = li >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+
+    const int nkt = (T + 31) / 32;
+    TileRegs sk, sv;
+    tile_gload(sk, kb, p.k_ts, 0, T);
+    tile_gload(sv, vb, p.v_ts, 0, T);
+    tile_sstore<LDKB>(sk, Ks[0]);
+    tile_sstore<LDKB>(sv, Vs[0]);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) {
+            tile_gload(sk, kb, p.k_ts, (kt + 1) * 32, T);
+            tile_gload(sv, vb, p.v_ts, (kt + 1) * 32, T);
+        }
+        const __bf16* ks = Ks[cur];
+        const __bf16* vs = Vs[cur];
+        f32x16 sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 kf[S], vf[S];
+            lds_row_frags(ks, l31, h, s, kf);
+            lds_row_frags(vs, l31, h, s, vf);
+            sc = mma6(kf, qf[s], sc);
+            dp = mma6(vf, dof[s], dp);
+        }
+        float ds[16];
+        const int kbase = kt * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kbase + (r & 3) + 8 * (r >> 2);
+            const float pv = key < T ? __builtin_amdgcn_exp2f(sc[r] - lse2) : 0.f;
+            ds[r] = pv * (dp[r] - dl);
+        }
+        unsigned d0[8], d1[8], d2[8];
+        split3<16>(ds, d0, d1, d2);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 df[S] = {frag_of(d0[4 * s2], d0[4 * s2 + 1], d0[4 * s2 + 2], d0[4 * s2 + 3]),
+                                  frag_of(d1[4 * s2], d1[4 * s2 + 1], d1[4 * s2 + 2], d1[4 * s2 + 3]),
+                                  frag_of(d2[4 * s2], d2[4 * s2 + 1], d2[4 * s2 + 2], d2[4 * s2 + 3])};
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                bf16x8 ktf[S];
+                lds_tr_frags<LDKB>(ks, tr_row, tr_col, h, s2, d, ktf);
+                acc_dq[d] = mma6(ktf, df, acc_dq[d]);
+            }
+        }
+        if (kt + 1 < nkt) {
+            tile_sstore<LDKB>(sk, Ks[cur ^ 1]);
+            tile_sstore<LDKB>(sv, Vs[cur ^ 1]);
+        }
+        __syncthreads();
+    }
+    if (qi < T) {
+        float* ob = p.dq + b * p.dq_bs + (long)qi * p.dq_ts + head * DH;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(ob + d * 32 + 8 * g + 4 * h) =
+                    make_float4(acc_dq[d][4 * g] * p.scale, acc_dq[d][4 * g + 1] * p.scale, acc_dq[d][4 * g + 2] * p.scale,
+                                acc_dq[d][4 * g + 3] * p.scale);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p) {
+    constexpr int TSZ = S * 32 * LDKB;
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[2][TSZ];
+    __shared__ __attribute__((aligned(16))) __bf16 Ds[2][TSZ];
+    __shared__ __attribute__((aligned(16))) float lse_s[2][32];
+    __shared__ __attribute__((aligned(16))) float del_s[2][32];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int T = p.T;
+    const int ki = blockIdx.x * 128 + wave * 32 + l31;
+    const int krow = ki < T ? ki : T - 1;
+    const bool key_ok = ki < T;
+    const float* qb = p.q + b * p.q_bs + head * DH;
+    const float* kb = p.k + b * p.k_bs + head * DH;
+    const float* vb = p.v + b * p.v_bs + head * DH;
+    const float* dob = p.d_o + ((long)b * T) * p.ldo + head * DH;
+    const float* lseb = p.lse + ((long)b * p.H + head) * T;
+    const float* delb = p.delta + ((long)b * p.H + head) * T;
+
+    bf16x8 kf[4][S], vf[4][S];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        row_frags(kb + (long)krow * p.k_ts + 16 * s + 8 * h, p.scale * LOG2E, kf[s]);
+        row_frags(vb + (long)krow * p.v_ts + 16 * s + 8 * h, 1.0f, vf[s]);
+    }
+    f32x16 acc_dk[2], acc_dv[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_dk[d][r] = 0.f; acc_dv[d][r] = 0.f; }
+    const int li = lane & 15;
+    const int tr_row = li >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+
+    const int nqt = (T + 31) / 32;
+    TileRegs sq, sd;
+    float lse_reg = 0.f, del_reg = 0.f;
+    auto gload = [&](int qt) {
+        tile_gload(sq, qb, p.q_ts, qt * 32, T);
+        tile_gload(sd, dob, p.ldo, qt * 32, T);
+        if (threadIdx.x < 32) {
+            int q = qt * 32 + threadIdx.x;
+            q = q < T ? q : T - 1;
+            lse_reg = lseb[q] * LOG2E;
+            del_reg = delb[q];
+        }
+    };
+    auto sstore = [&](int buf) {
+        tile_sstore<LDKB>(sq, Qs[buf]);
+        tile_sstore<LDKB>(sd, Ds[buf]);
+        if (threadIdx.x < 32) { lse_s[buf][threadIdx.x] = lse_reg; del_s[buf][threadIdx.x] = del_reg; }
+    };
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int qt = 0; qt < nqt; ++qt) {
+        const int cur = qt & 1;
+        if (qt + 1 < nqt) gload(qt + 1);
+        const __bf16* qs = Qs[cur];
+        const __bf16* ds_t = Ds[cur];
+        f32x16 sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 qrf[S], drf[S];
+            lds_row_frags(qs, l31, h, s, qrf);
+            lds_row_frags(ds_t, l31, h, s, drf);
+            sc = mma6(qrf, kf[s], sc);
+            dp = mma6(drf, vf[s], dp);
+        }
+        // rows of S / dP are queries kappa(r,h)
+        float pv[16], dsv[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[cur][8 * g + 4 * h]);
+            const float4 d4 = *reinterpret_cast<const float4*>(&del_s[cur][8 * g + 4 * h]);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+            const float dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g + i;
+                const bool ok = key_ok && (qt * 32 + 8 * g + 4 * h + i) < T;
+                pv[r] = ok ? __builtin_amdgcn_exp2f(sc[r] - lv[i]) : 0.f;
+                dsv[r] = pv[r] * (dp[r] - dv4[i]);
+            }
+        }
+        unsigned a0[8], a1[8], a2[8];
+        split3<16>(pv, a0, a1, a2);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf[S] = {frag_of(a0[4 * s2], a0[4 * s2 + 1], a0[4 * s2 + 2], a0[4 * s2 + 3]),
+                                  frag_of(a1[4 * s2], a1[4 * s2 + 1], a1[4 * s2 + 2], a1[4 * s2 + 3]),
+                                  frag_of(a2[4 * s2], a2[4 * s2 + 1], a2[4 * s2 + 2], a2[4 * s2 + 3])};
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                bf16x8 dtf[S];
+                lds_tr_frags<LDKB>(ds_t, tr_row, tr_col, h, s2, d, dtf);
+                acc_dv[d] = mma6(dtf, pf, acc_dv[d]);
+            }
+        }
+        split3<16>(dsv, a0, a1, a2);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 sf[S] = {frag_of(a0[4 * s2], a0[4 * s2 + 1], a0[4 * s2 + 2], a0[4 * s2 + 3]),
+                                  frag_of(a1[4 * s2], a1[4 * s2 + 1], a1[4 * s2 + 2], a1[4 * s2 + 3]),
+                                  frag_of(a2[4 * s2], a2[4 * s2 + 1], a2[4 * s2 + 2], a2[4 * s2 + 3])};
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                bf16x8 qtf[S];
+                lds_tr_frags<LDKB>(qs, tr_row, tr_col, h, s2, d, qtf);
+                acc_dk[d] = mma6(qtf, sf, acc_dk[d]);
+            }
+        }
+        if (qt + 1 < nqt) sstore(cur ^ 1);
+        __syncthreads();
+    }
+    if (ki < T) {
+        float* okb = p.dk + b * p.dk_bs + (long)ki * p.dk_ts + head * DH;
+        float* ovb = p.dv + b * p.dv_bs + (long)ki * p.dv_ts + head * DH;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = d * 32 + 8 * g + 4 * h;
+                *reinterpret_cast<float4*>(okb + col) = make_float4(acc_dk[d][4 * g] * p.scale, acc_dk[d][4 * g + 1] * p.scale,
+                                                                    acc_dk[d][4 * g + 2] * p.scale, acc_dk[d][4 * g + 3] * p.scale);
+                *reinterpret_cast<float4*>(ovb + col) = make_float4(acc_dv[d][4 * g], acc_dv[d][4 * g + 1], acc_dv[d][4 * g + 2],
+                                                                    acc_dv[d][4 * g + 3]);
+            }
+    }
+}
+
 }  // namespace
 
 // internal entry (dispatched from tvl_attn_fwd): d_h = 64, no causal / key mask
@@ -237,5 +520,18 @@ int tvl_attn_fwd_bf16s_impl(const tvlAttnFwdArgs* a, hipStream_t s) {
     p.B = a->B; p.H = a->H; p.T = a->T; p.scale = a->scale;
     dim3 grid((a->T + 127) / 128, a->H, a->B);
     hipLaunchKernelGGL(attn_fwd_bf16s_kernel, grid, dim3(256), 0, s, p);
+    return 0;
+}
+
+// dQ + dK/dV kernels (delta is computed by the caller's pre-pass)
+int tvl_attn_bwd_bf16s_impl(const tvlAttnBwdArgs* a, hipStream_t s) {
+    BwdParams p;
+    p.q = a->q; p.k = a->k; p.v = a->v; p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs;
+    p.q_ts = a->q_ts; p.k_ts = a->k_ts; p.v_ts = a->v_ts; p.d_o = a->d_o; p.ldo = a->ldo; p.lse = a->lse; p.delta = a->delta;
+    p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.dq_bs = a->dq_bs; p.dk_bs = a->dk_bs; p.dv_bs = a->dv_bs;
+    p.dq_ts = a->dq_ts; p.dk_ts = a->dk_ts; p.dv_ts = a->dv_ts; p.B = a->B; p.H = a->H; p.T = a->T; p.scale = a->scale;
+    dim3 grid((a->T + 127) / 128, a->H, a->B);
+    hipLaunchKernelGGL(attn_bwd_dq_bf16s_kernel, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dkdv_bf16s_kernel, grid, dim3(256), 0, s, p);
     return 0;
 }

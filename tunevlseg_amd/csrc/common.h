@@ -10,6 +10,7 @@
 void tvl_set_error(const char* fmt, ...);
 // split-bf16 attention (attention_bf16s.hip), dispatched from tvl_attn_fwd / tvl_attn_bwd for d_h = 64 without masks
 int tvl_attn_fwd_bf16s_impl(const tvlAttnFwdArgs* a, hipStream_t s);
+int tvl_attn_bwd_bf16s_impl(const tvlAttnBwdArgs* a, hipStream_t s);
 int tvl_attn_mode_bf16s(void);
 
 #define TVL_REQUIRE(cond, ...)                \
