@@ -11,6 +11,11 @@
 // bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so S = 3 reproduces an fp32 GEMM to fp32
 // round-off at 6/16 of the f32-MFMA cost (8 f32 MFMAs of 64 cycles vs 6 bf16 MFMAs of 32 cycles per 16-deep k-step).
 //
+// Tuning log (profiles/r1_gemm_experiments.md): warp-specialised producer/consumer waves, a two-tile ping-pong workgroup,
+// source-level MFMA/VALU interleaving (sched_group_barrier) and a 3-deep register prefetch ring were all measured on
+// MI355X and landed within +-4 % of this simple structure (146-151 TFLOP/s fp32-equivalent on the ViT-B/16 shapes); the
+// PMC counters show 5.2 VALU instructions per MFMA and a 42 % busy matrix pipe at a ~2.3 GHz reported clock.
+//
 // Layout: NT only (A [M,K] and B [N,K], both k-contiguous); the frozen weights are kept in both orientations by the host
 // so data gradients are NT as well.  256 threads = 4 waves, tiles 128x128 (2x2 waves) / 96x128 (1x4) / 64x64 (2x2),
 // BK = 32, ONE LDS stage (S planes per operand) + register prefetch of the next slab, two barriers per slab.
