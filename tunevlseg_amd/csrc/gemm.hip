@@ -135,7 +135,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+    // grouped order: consecutive tile ids walk GROUP_M row-tiles of one column-tile before moving to the next column, so
+    // the ~64 tiles resident on an XCD cover an ~8 x 8 block: 8 A panels + 8 W slices instead of 3 A panels + all of W
+    // (rocprofv3: FETCH_SIZE of the fc1 GEMM was 19x its algorithmic bytes with the row-major order)
+    constexpr int GROUP_M = 8;
+    const int gsize_full = GROUP_M * p.tiles_n;
+    const int group = bid / gsize_full;
+    const int gm0 = group * GROUP_M;
+    const int gm = p.tiles_m - gm0 < GROUP_M ? p.tiles_m - gm0 : GROUP_M;
+    const int in_group = bid - group * gsize_full;
+    const int tile_m = gm0 + in_group % gm, tile_n = in_group / gm;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

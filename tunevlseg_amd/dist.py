@@ -25,9 +25,11 @@ def init_distributed(device_type: str = "cuda") -> tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        # RCCL ("nccl" on ROCm) for GPUs; TVL_DIST_BACKEND=gloo lets the N>1 code path be rehearsed with several ranks on ONE
+        # device (RCCL refuses duplicate devices), gloo staging the tiny gradient buffer through the host
+        backend = os.environ.get("TVL_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(0 if backend == "gloo" else local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
