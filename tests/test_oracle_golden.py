@@ -9,11 +9,20 @@ import pytest
 import torch
 
 from oracle import clipseg_oracle as O
-from tests.golden_util import (config_of, golden_names, inputs_of, load_golden, new_last_of, oracle_learner,
-                               state_of, trainable_of)
+from oracle import cris_oracle as OC
+from tests.golden_util import (config_of, cris_config_of, cris_new_last_of, cris_state_of, golden_names, inputs_of,
+                               load_golden, new_last_of, oracle_learner, state_of, trainable_of)
 
 
 def run_oracle(fx):
+    if fx["meta"].get("family") == "cris":
+        cfg, sd = cris_config_of(fx), cris_state_of(fx)
+        params = trainable_of(fx)
+        pix, ids, am, mask = inputs_of(fx)
+        logits = OC.cris_forward(sd, cfg, oracle_learner(fx, params), pix, ids, am, cris_new_last_of(params))
+        loss = O.dice_ce_loss(logits, mask)
+        loss.backward()
+        return logits.detach(), loss.detach(), params
     cfg, sd = config_of(fx), state_of(fx)
     params = trainable_of(fx)
     learner = oracle_learner(fx, params)
@@ -57,4 +66,15 @@ def test_oracle_matches_reference_tiny(name):
 @pytest.mark.slow
 @pytest.mark.parametrize("name", golden_names("rd64_"))
 def test_oracle_matches_reference_full_size(name):
+    check(load_golden(name))
+
+
+@pytest.mark.parametrize("name", golden_names("cris_tiny_"))
+def test_cris_oracle_matches_reference_tiny(name):
+    check(load_golden(name))
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", golden_names("cris_rn50_"))
+def test_cris_oracle_matches_reference_full_size(name):
     check(load_golden(name))

@@ -18,6 +18,7 @@ from typing import Iterator
 import torch
 
 from .config import CLIPSegConfig
+from .cris_config import CRISConfig
 
 
 def _layer_specs(prefix: str, hidden: int, inter: int, n_layers_for_scale: int) -> Iterator[tuple[str, tuple[int, ...], str, float]]:
@@ -77,16 +78,11 @@ def clipseg_param_specs(cfg: CLIPSegConfig) -> Iterator[tuple[str, tuple[int, ..
         yield from _layer_specs(f"decoder.layers.{i}", r, cfg.decoder_intermediate_size, len(cfg.extract_layers))
 
 
-def init_clipseg_state_dict(cfg: CLIPSegConfig, seed: int = 0, dtype: torch.dtype = torch.float32) -> dict[str, torch.Tensor]:
-    """Seeded CPU draw of every backbone tensor (fp32), HF key names.
-
-    Biases and LayerNorm affine terms are non-trivial on purpose so that every
-    bias/affine code path of the kernels is exercised by parity tests.
-    """
+def _draw(specs, seed: int, dtype: torch.dtype) -> dict[str, torch.Tensor]:
     g = torch.Generator(device="cpu")
     g.manual_seed(int(seed))
     out: dict[str, torch.Tensor] = {}
-    for name, shape, kind, scale in clipseg_param_specs(cfg):
+    for name, shape, kind, scale in specs:
         if kind == "const":
             x = torch.tensor(scale, dtype=torch.float32)
         elif kind == "normal":
@@ -95,11 +91,157 @@ def init_clipseg_state_dict(cfg: CLIPSegConfig, seed: int = 0, dtype: torch.dtyp
             x = 1.0 + torch.randn(shape, generator=g, dtype=torch.float32) * scale
         elif kind == "film_b":
             x = 1.0 + torch.randn(shape, generator=g, dtype=torch.float32) * scale
+        elif kind == "bn_w":  # BatchNorm scale around `scale`
+            x = scale * (1.0 + 0.1 * torch.randn(shape, generator=g, dtype=torch.float32))
+        elif kind == "bn_var":  # running variance in [0.5, 1.5] * scale
+            x = scale * (0.5 + torch.rand(shape, generator=g, dtype=torch.float32))
         else:  # pragma: no cover
             raise ValueError(kind)
         out[name] = x.to(dtype)
     return out
 
 
+def init_clipseg_state_dict(cfg: CLIPSegConfig, seed: int = 0, dtype: torch.dtype = torch.float32) -> dict[str, torch.Tensor]:
+    """Seeded CPU draw of every backbone tensor (fp32), HF key names.
+
+    Biases and LayerNorm affine terms are non-trivial on purpose so that every
+    bias/affine code path of the kernels is exercised by parity tests.
+    """
+    return _draw(clipseg_param_specs(cfg), seed, dtype)
+
+
 def count_params(cfg: CLIPSegConfig) -> int:
     return sum(math.prod(s) for _, s, _, _ in clipseg_param_specs(cfg))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CRIS (reference src/models/components/cris_model/{__init__,clip,layers}.py); key names = the reference module tree
+# ---------------------------------------------------------------------------------------------------------------------
+def _bn_specs(prefix: str, c: int, w_scale: float = 1.0):
+    yield f"{prefix}.weight", (c,), "bn_w", w_scale
+    yield f"{prefix}.bias", (c,), "normal", 0.05
+    yield f"{prefix}.running_mean", (c,), "normal", 0.1
+    yield f"{prefix}.running_var", (c,), "bn_var", 1.0
+
+
+def _conv_specs(name: str, cout: int, cin: int, k: int, gain: float = 1.0):
+    yield name, (cout, cin, k, k), "normal", gain * (2.0 / (cin * k * k)) ** 0.5
+
+
+def _conv_layer_specs(prefix: str, cin: int, cout: int, k: int):
+    """``conv_layer`` = Conv(no bias) + BN + ReLU (layers.py:15-26)."""
+    yield from _conv_specs(f"{prefix}.0.weight", cout, cin, k)
+    yield from _bn_specs(f"{prefix}.1", cout)
+
+
+def _mha_specs(prefix: str, d: int, out_gain: float = 1.0):
+    yield f"{prefix}.in_proj_weight", (3 * d, d), "normal", d**-0.5
+    yield f"{prefix}.in_proj_bias", (3 * d,), "normal", 0.02
+    yield f"{prefix}.out_proj.weight", (d, d), "normal", out_gain * d**-0.5
+    yield f"{prefix}.out_proj.bias", (d,), "normal", 0.02
+
+
+def _ln_specs(prefix: str, d: int):
+    yield f"{prefix}.weight", (d,), "ln_w", 0.05
+    yield f"{prefix}.bias", (d,), "normal", 0.02
+
+
+def cris_param_specs(cfg: CRISConfig) -> Iterator[tuple[str, tuple[int, ...], str, float]]:
+    w = cfg.vision_width
+    v = "backbone.visual"
+    # ModifiedResNet stem (clip.py:205-229)
+    yield from _conv_specs(f"{v}.conv1.weight", w // 2, 3, 3)
+    yield from _bn_specs(f"{v}.bn1", w // 2)
+    yield from _conv_specs(f"{v}.conv2.weight", w // 2, w // 2, 3)
+    yield from _bn_specs(f"{v}.bn2", w // 2)
+    yield from _conv_specs(f"{v}.conv3.weight", w, w // 2, 3)
+    yield from _bn_specs(f"{v}.bn3", w)
+    inplanes = w
+    for li, (planes, blocks) in enumerate(zip((w, 2 * w, 4 * w, 8 * w), cfg.vision_layers), start=1):
+        for bi in range(blocks):
+            stride = 2 if (li > 1 and bi == 0) else 1
+            p = f"{v}.layer{li}.{bi}"
+            yield from _conv_specs(f"{p}.conv1.weight", planes, inplanes, 1)
+            yield from _bn_specs(f"{p}.bn1", planes)
+            yield from _conv_specs(f"{p}.conv2.weight", planes, planes, 3)
+            yield from _bn_specs(f"{p}.bn2", planes)
+            yield from _conv_specs(f"{p}.conv3.weight", 4 * planes, planes, 1)
+            yield from _bn_specs(f"{p}.bn3", 4 * planes, 0.5)
+            if stride > 1 or inplanes != 4 * planes:
+                yield from _conv_specs(f"{p}.downsample.0.weight", 4 * planes, inplanes, 1, 0.7)
+                yield from _bn_specs(f"{p}.downsample.1", 4 * planes)
+            inplanes = 4 * planes
+    e = cfg.vision_embed
+    sp = cfg.image_resolution // 32
+    yield f"{v}.attnpool.positional_embedding", (sp * sp + 1, e), "normal", e**-0.5 * 4
+    for n in ("k_proj", "q_proj", "v_proj"):
+        yield f"{v}.attnpool.{n}.weight", (e, e), "normal", e**-0.5
+        yield f"{v}.attnpool.{n}.bias", (e,), "normal", 0.02
+    yield f"{v}.attnpool.c_proj.weight", (cfg.embed_dim, e), "normal", e**-0.5
+    yield f"{v}.attnpool.c_proj.bias", (cfg.embed_dim,), "normal", 0.02
+    yield from _conv_specs(f"{v}.attnpool.connect.0.weight", cfg.embed_dim, e, 1, 0.7)
+    yield from _bn_specs(f"{v}.attnpool.connect.1", cfg.embed_dim)
+    # CLIP text tower (clip.py:296-325,460-470)
+    d = cfg.transformer_width
+    for i in range(cfg.transformer_layers):
+        p = f"backbone.transformer.resblocks.{i}"
+        yield from _mha_specs(f"{p}.attn", d, (2 * cfg.transformer_layers) ** -0.5 * 2.0)
+        yield from _ln_specs(f"{p}.ln_1", d)
+        yield f"{p}.mlp.c_fc.weight", (4 * d, d), "normal", (2 * d) ** -0.5 * 1.5
+        yield f"{p}.mlp.c_fc.bias", (4 * d,), "normal", 0.02
+        yield f"{p}.mlp.c_proj.weight", (d, 4 * d), "normal", (4 * d) ** -0.5 * (2 * cfg.transformer_layers) ** -0.5 * 2.0
+        yield f"{p}.mlp.c_proj.bias", (d,), "normal", 0.02
+        yield from _ln_specs(f"{p}.ln_2", d)
+    yield "backbone.token_embedding.weight", (cfg.vocab_size, d), "normal", 0.1
+    yield "backbone.positional_embedding", (cfg.context_length, d), "normal", 0.05
+    yield from _ln_specs("backbone.ln_final", d)
+    yield "backbone.text_projection", (d, cfg.embed_dim), "normal", d**-0.5
+    yield "backbone.logit_scale", (), "const", 2.6592
+    # FPN neck (layers.py:359-410)
+    fi, fo = cfg.fpn_in, cfg.fpn_out
+    yield "neck.txt_proj.0.weight", (fo[2], fi[2]), "normal", fi[2] ** -0.5 * 1.5
+    yield from _bn_specs("neck.txt_proj.1", fo[2])
+    yield from _conv_layer_specs("neck.f1_v_proj", fi[2], fo[2], 1)
+    yield from _bn_specs("neck.norm_layer.0", fo[2])
+    yield from _conv_layer_specs("neck.f2_v_proj", fi[1], fo[1], 3)
+    yield from _conv_layer_specs("neck.f2_cat", fo[2] + fo[1], fo[1], 1)
+    yield from _conv_layer_specs("neck.f3_v_proj", fi[0], fo[0], 3)
+    yield from _conv_layer_specs("neck.f3_cat", fo[0] + fo[1], fo[1], 1)
+    yield from _conv_layer_specs("neck.f4_proj5", fo[2], fo[1], 3)
+    yield from _conv_layer_specs("neck.f4_proj4", fo[1], fo[1], 3)
+    yield from _conv_layer_specs("neck.f4_proj3", fo[1], fo[1], 3)
+    yield from _conv_layer_specs("neck.aggr", 3 * fo[1], fo[1], 1)
+    yield from _conv_layer_specs("neck.coordconv.0.conv1", fo[1] + 2, fo[1], 3)
+    yield from _conv_layer_specs("neck.coordconv.1", fo[1], fo[1], 3)
+    # cross-attention decoder (layers.py:124-356)
+    dm, ff = cfg.vis_dim, cfg.dim_ffn
+    for i in range(cfg.num_layers):
+        p = f"decoder.layers.{i}"
+        yield from _ln_specs(f"{p}.self_attn_norm", dm)
+        yield from _ln_specs(f"{p}.cross_attn_norm", dm)
+        yield from _mha_specs(f"{p}.self_attn", dm)
+        yield from _mha_specs(f"{p}.multihead_attn", dm)
+        yield f"{p}.ffn.0.weight", (ff, dm), "normal", (2.0 / dm) ** 0.5
+        yield f"{p}.ffn.0.bias", (ff,), "normal", 0.02
+        yield from _ln_specs(f"{p}.ffn.3", ff)
+        yield f"{p}.ffn.4.weight", (dm, ff), "normal", ff**-0.5
+        yield f"{p}.ffn.4.bias", (dm,), "normal", 0.02
+        yield from _ln_specs(f"{p}.norm1", dm)
+        yield from _ln_specs(f"{p}.norm2", dm)
+        yield from _ln_specs(f"{p}.norm3", dm)
+    yield from _ln_specs("decoder.norm", dm)
+    # projector (layers.py:71-94)
+    c = cfg.vis_dim // 2
+    yield from _conv_layer_specs("proj.vis.1", 2 * c, 2 * c, 3)
+    yield from _conv_layer_specs("proj.vis.3", 2 * c, c, 3)
+    yield "proj.vis.4.weight", (c, c, 1, 1), "normal", c**-0.5
+    yield "proj.vis.4.bias", (c,), "normal", 0.02
+    yield "proj.txt.weight", (c * 9 + 1, cfg.word_dim), "normal", cfg.word_dim**-0.5 * (c * 9) ** -0.5 * 3
+    yield "proj.txt.bias", (c * 9 + 1,), "normal", 0.02
+
+
+def init_cris_state_dict(cfg: CRISConfig, seed: int = 0, dtype: torch.dtype = torch.float32) -> dict[str, torch.Tensor]:
+    """Seeded CPU draw of every CRIS tensor under the reference's module names (``CRIS.state_dict()`` keys minus
+    ``num_batches_tracked``).  BatchNorm running statistics are non-trivial: the towers run in eval mode
+    (reference coop_cris.py:66-68)."""
+    return _draw(cris_param_specs(cfg), seed, dtype)
