@@ -81,8 +81,9 @@ int tvl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
  * q/k/v: element (b, t, h, d) at ptr[b*bs + t*ts + h*dh + d] (packed QKV GEMM output or separate).
  * o: [B, T, H*dh] (ldo = row stride).  lse: [B, H, T] natural-log-sum-exp of the scaled scores.
  * causal != 0: key j visible to query i iff j <= i (reference coop_clipseg.py:229-233);
- * key_mask (may be NULL): int32 [B, T], 0 = padded key (coop_clipseg.py:236-246).
- * dh in {8,16,32,64}.
+ * key_mask (may be NULL): int32 [B, Tk], 0 = padded key (coop_clipseg.py:236-246).
+ * dh in {8,16,32,64}.  Tk = number of keys/values (0: same as T); Tk != T is cross-attention (CRIS decoder,
+ * reference cris_model/layers.py:341-349: 676 visual queries x <=77 word keys with a key-padding mask), no causal.
  */
 typedef struct {
     const float *q, *k, *v; int64_t q_bs, k_bs, v_bs; int32_t q_ts, k_ts, v_ts;
@@ -91,6 +92,7 @@ typedef struct {
     const int32_t* key_mask;
     int32_t B, H, T, dh, causal;
     float scale;
+    int32_t Tk;
 } tvlAttnFwdArgs;
 int tvl_attn_fwd(const tvlAttnFwdArgs* a, tvlStream_t stream);
 
@@ -103,6 +105,7 @@ typedef struct {
     const int32_t* key_mask;
     int32_t B, H, T, dh, causal;
     float scale;
+    int32_t Tk;
 } tvlAttnBwdArgs;
 int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream);
 
@@ -189,6 +192,36 @@ int tvl_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float
 int tvl_dot(const float* x, const float* y, float* out, int64_t n, int32_t accumulate, tvlStream_t stream);
 /* colsum[c] (+)= sum_r x[r,c]  (bias gradients of small trainable Linears) */
 int tvl_colsum(const float* x, float* out, int64_t rows, int32_t cols, int32_t accumulate, tvlStream_t stream);
+
+/* ---- CRIS conv path (BASELINE configs[2]; reference src/models/components/cris_model/clip.py:18-274,
+ *      layers.py:15-119,359-445, src/models/core_models/coop/coop_cris.py:203-242) ----
+ * Feature maps are NHWC pixel matrices: element (b, y, x, c) at ptr[((b*H + y)*W + x)*ld + c] (ld >= C: a channel slice of a
+ * wider concat buffer is addressed by pointer offset + ld).  A 1x1 conv (+ folded eval BatchNorm + ReLU) is tvl_gemm_* over
+ * the map; a 3x3 conv is tvl_gemm_* over the im2col matrix; their data gradients are the same two calls with the
+ * transposed / tap-flipped weight matrix. */
+/* cols[(b,oy,ox), (ky*3+kx)*C + c] = x[b*sb + (oy*stride+ky-1)*sy + (ox*stride+kx-1)*sx + c*sc] (0 outside the map);
+ * explicit element strides let the stem conv read the NCHW image; columns 9*C..ldc-1 are zero-filled. pad 1, stride 1|2. */
+int tvl_im2col3x3(const float* x, int64_t sb, int64_t sy, int64_t sx, int64_t sc, float* cols, int32_t ldc,
+                  int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride, tvlStream_t stream);
+/* nn.AvgPool2d(k) / F.avg_pool2d(x, k, k) on [B,H,W,C] (H, W divisible by k) and its gradient (H, W = input sizes) */
+int tvl_avgpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);
+int tvl_avgpool_bwd(const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);
+/* F.interpolate(scale_factor=s, mode="bilinear") / nn.Upsample (align_corners=False), integer s; bwd: H, W = input sizes */
+int tvl_bilinear_up_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t s, tvlStream_t stream);
+int tvl_bilinear_up_bwd(const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t s, tvlStream_t stream);
+/* y[b] = a * F.interpolate(x[b], (Ho,Wo), mode="bicubic", align_corners=True) + r * extra[b]  (extra may be NULL);
+ * single-channel maps [B,Hi,Wi] -> [B,Ho,Wo] (coop_cris.py:235,240-242); bwd: dx = a * bicubic^T(dy) */
+int tvl_bicubic_ac_fwd(const float* x, float* y, const float* extra, float a, float r, int32_t B, int32_t Hi, int32_t Wi,
+                       int32_t Ho, int32_t Wo, tvlStream_t stream);
+int tvl_bicubic_ac_bwd(const float* dy, float a, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, tvlStream_t stream);
+/* Projector tail (layers.py:106-118): out[b,y,x] = word[b,9C] + sum_{c,ky,kx} word[b, c*9+ky*3+kx] * x[b, y+ky-1, x+kx-1, c]
+ * (a grouped conv with one 3x3xC kernel per sample).  taps: workspace [B*H*W, 9]. */
+int tvl_dynconv_fwd(const float* x, int32_t ldx, const float* word, int32_t ldw, float* taps, float* out,
+                    int32_t B, int32_t H, int32_t W, int32_t C, tvlStream_t stream);
+/* dx (may be NULL) [B*H*W, lddx], dword [B, ldw]; work: tvl_dynconv_bwd_work_floats(B,H,W,C) floats (deterministic two-stage sum) */
+int64_t tvl_dynconv_bwd_work_floats(int32_t B, int32_t H, int32_t W, int32_t C);
+int tvl_dynconv_bwd(const float* dout, const float* x, int32_t ldx, const float* word, int32_t ldw, float* dx, int32_t lddx,
+                    float* dword, float* work, int32_t B, int32_t H, int32_t W, int32_t C, tvlStream_t stream);
 
 #ifdef __cplusplus
 }

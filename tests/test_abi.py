@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     from tunevlseg_amd import hip
 
     lib = hip.load()
-    assert lib.tvl_abi_version() == 1
+    assert lib.tvl_abi_version() == 2
     decl = declared_symbols()
     assert len(decl) >= 30
     missing = [s for s in decl if not hasattr(lib, s)]
@@ -44,8 +44,8 @@ def test_struct_layouts_match_header(tmp_path):
         pytest.skip("gcc not available")
     probe = tmp_path / "probe.c"
     fields = {"tvlGemmArgs": ["layout", "A", "ldb", "C", "bias", "residual", "act", "pre_out", "dact_aux", "dact", "alpha", "a_map", "c_map"],
-              "tvlAttnFwdArgs": ["q", "q_bs", "q_ts", "o", "ldo", "lse", "key_mask", "B", "causal", "scale"],
-              "tvlAttnBwdArgs": ["q", "v_ts", "o", "d_o", "ldo", "lse", "delta", "dq", "dq_bs", "dv_ts", "key_mask", "B", "scale"]}
+              "tvlAttnFwdArgs": ["q", "q_bs", "q_ts", "o", "ldo", "lse", "key_mask", "B", "causal", "scale", "Tk"],
+              "tvlAttnBwdArgs": ["q", "v_ts", "o", "d_o", "ldo", "lse", "delta", "dq", "dq_bs", "dv_ts", "key_mask", "B", "scale", "Tk"]}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT / "include" / "tvl_hip.h"}"', "int main(void){"]
     for st, fs in fields.items():
         lines.append(f'printf("{st} %zu\\n", sizeof({st}));')

@@ -1,0 +1,171 @@
+"""Kernel-level parity of the CRIS conv-path entry points (csrc/conv.hip, cross-attention) against float64 PyTorch.
+
+Runs on the GPU box only (-m gpu).  Layout reminder: maps are NHWC pixel matrices [B*H*W, C].
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tunevlseg_amd import hip as H
+
+    H.load()
+    return H
+
+
+def dev(t):
+    return t.to("cuda").contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, tol, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item() + 1e-30
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+def nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def nchw(m, B, H, W):
+    return m.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("B,C,H,W,stride,Cout", [(2, 8, 6, 6, 1, 5), (1, 3, 10, 12, 2, 4), (3, 6, 7, 5, 1, 9), (2, 64, 13, 13, 1, 32),
+                                                 (1, 3, 32, 32, 2, 16)])
+def test_conv3x3_as_im2col_gemm(hip, B, C, H, W, stride, Cout):
+    x, w = rnd(B, C, H, W, seed=1), rnd(Cout, C, 3, 3, seed=2)
+    ref = F.conv2d(x.double(), w.double(), stride=stride, padding=1)
+    Ho, Wo = ref.shape[2:]
+    cols = hip.im2col3x3(dev(nhwc(x)), B, H, W, stride)
+    K = cols.shape[1]
+    wm = torch.zeros(Cout, K)
+    wm[:, : 9 * C] = w.permute(0, 2, 3, 1).reshape(Cout, 9 * C)  # (ky, kx, c) column order
+    y = torch.empty(B * Ho * Wo, Cout, device="cuda")
+    hip.gemm(0, B * Ho * Wo, Cout, K, cols, K, dev(wm), K, y, Cout)
+    close(nchw(y, B, Ho, Wo), ref, 1e-5 * math.sqrt(9 * C), "conv3x3")
+    # the stem reads the NCHW image directly
+    cols2 = hip.im2col3x3_nchw(dev(x), stride)
+    assert torch.equal(cols2, cols)
+
+
+def test_im2col_reads_channel_slice(hip):
+    B, C, H, W = 2, 8, 5, 5
+    x = rnd(B, 2 * C, H, W, seed=3)
+    wide = dev(nhwc(x))
+    a = hip.im2col3x3(wide[:, C:], B, H, W, 1)
+    b = hip.im2col3x3(dev(nhwc(x[:, C:])), B, H, W, 1)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,C,H,W,k", [(2, 5, 8, 6, 2), (1, 16, 4, 4, 2), (2, 3, 9, 6, 3)])
+def test_avgpool(hip, B, C, H, W, k):
+    x = rnd(B, C, H, W, seed=4).double().requires_grad_()
+    ref = F.avg_pool2d(x, k)
+    g = rnd(*ref.shape, seed=5)
+    ref.backward(g.double())
+    y = hip.avgpool_fwd(dev(nhwc(x.detach().float())), B, H, W, k)
+    close(nchw(y, B, H // k, W // k), ref, 1e-6, "avgpool fwd")
+    dx = hip.avgpool_bwd(dev(nhwc(g)), B, H, W, k)
+    close(nchw(dx, B, H, W), x.grad, 1e-6, "avgpool bwd")
+    # write into a column slice of a wider buffer (channel concat)
+    wide = torch.zeros(B * (H // k) * (W // k), C + 3, device="cuda")
+    hip.avgpool_fwd(dev(nhwc(x.detach().float())), B, H, W, k, out=wide[:, 3:])
+    assert torch.equal(wide[:, 3:], y) and wide[:, :3].abs().max() == 0
+
+
+@pytest.mark.parametrize("B,C,H,W,s", [(2, 5, 3, 4, 2), (1, 8, 13, 13, 2), (2, 3, 1, 5, 2), (1, 4, 6, 6, 4)])
+def test_bilinear_up(hip, B, C, H, W, s):
+    x = rnd(B, C, H, W, seed=6).double().requires_grad_()
+    ref = F.interpolate(x, scale_factor=s, mode="bilinear")
+    g = rnd(*ref.shape, seed=7)
+    ref.backward(g.double())
+    y = hip.bilinear_up_fwd(dev(nhwc(x.detach().float())), B, H, W, s)
+    close(nchw(y, B, H * s, W * s), ref, 2e-6, "bilinear fwd")
+    dx = hip.bilinear_up_bwd(dev(nhwc(g)), B, H, W, s)
+    close(nchw(dx, B, H, W), x.grad, 2e-6, "bilinear bwd")
+
+
+@pytest.mark.parametrize("B,Hi,Wi,Ho,Wo", [(2, 6, 6, 24, 24), (1, 24, 24, 96, 96), (2, 5, 7, 13, 30), (1, 104, 104, 416, 416), (1, 4, 4, 4, 4)])
+def test_bicubic_align_corners(hip, B, Hi, Wi, Ho, Wo):
+    x = rnd(B, 1, Hi, Wi, seed=8).double().requires_grad_()
+    ref = F.interpolate(x, (Ho, Wo), mode="bicubic", align_corners=True)
+    g = rnd(*ref.shape, seed=9)
+    ref.backward(g.double())
+    extra = rnd(B, Ho, Wo, seed=10)
+    y = hip.bicubic_ac_fwd(dev(x.detach().float()[:, 0]), Ho, Wo)
+    close(y, ref[:, 0], 2e-5, "bicubic fwd")
+    y2 = hip.bicubic_ac_fwd(dev(x.detach().float()[:, 0]), Ho, Wo, extra=dev(extra), a=0.3, r=0.7)
+    close(y2, 0.3 * ref[:, 0] + 0.7 * extra.double(), 2e-5, "bicubic fwd mix")
+    dx = hip.bicubic_ac_bwd(dev(g[:, 0]), Hi, Wi, a=0.3)
+    close(dx, 0.3 * x.grad[:, 0], 2e-5, "bicubic bwd")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 16, 6, 6), (3, 5, 7, 9), (1, 256, 24, 24), (2, 70, 12, 11)])
+def test_dynconv(hip, B, C, H, W):
+    x = rnd(B, C, H, W, seed=11).double().requires_grad_()
+    word = (rnd(B, 9 * C + 1, seed=12) * 0.2).double().requires_grad_()
+    wgt, bias = word[:, :-1].reshape(B, C, 3, 3), word[:, -1]
+    ref = F.conv2d(x.reshape(1, B * C, H, W), wgt, bias, padding=1, groups=B).transpose(0, 1)  # [B,1,H,W]
+    g = rnd(*ref.shape, seed=13)
+    ref.backward(g.double())
+    xm, wd = dev(nhwc(x.detach().float())), dev(word.detach().float())
+    out = hip.dynconv_fwd(xm, wd, B, H, W)
+    close(out, ref[:, 0], 1e-5 * math.sqrt(9 * C), "dynconv fwd")
+    dx, dword = hip.dynconv_bwd(dev(g[:, 0]), xm, wd, B, H, W)
+    close(nchw(dx, B, H, W), x.grad, 1e-5, "dynconv dx")
+    close(dword, word.grad, 1e-5 * math.sqrt(H * W), "dynconv dword")
+
+
+@pytest.mark.parametrize("B,H,dh,T,Tk,masked", [(2, 2, 16, 36, 10, True), (1, 8, 64, 676, 17, True), (2, 4, 32, 50, 77, False),
+                                                 (3, 2, 8, 5, 130, True)])
+def test_cross_attention(hip, B, H, dh, T, Tk, masked):
+    D = H * dh
+    q, k, v = rnd(B, T, D, seed=14), rnd(B, Tk, D, seed=15), rnd(B, Tk, D, seed=16)
+    km = torch.ones(B, Tk, dtype=torch.int32)
+    if masked:
+        for b in range(B):
+            km[b, Tk - 1 - (b % 3) * 2:] = 0
+    qd, kd, vd = (t.double().requires_grad_() for t in (q, k, v))
+    qh = qd.view(B, T, H, dh).transpose(1, 2)
+    kh = kd.view(B, Tk, H, dh).transpose(1, 2)
+    vh = vd.view(B, Tk, H, dh).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) * dh**-0.5
+    s = s.masked_fill(km[:, None, None, :] == 0, float("-inf"))
+    ref = (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, T, D)
+    g = rnd(B, T, D, seed=17)
+    ref.backward(g.double())
+    q2, k2, v2 = dev(q.view(B * T, D)), dev(k.view(B * Tk, D)), dev(v.view(B * Tk, D))
+    o, lse = hip.attn_fwd(q2, k2, v2, B, T, Tk, H, dh, dh**-0.5, key_mask=dev(km) if masked else None)
+    close(o.view(B, T, D), ref, 2e-5, "xattn fwd")
+    dq, dk, dv = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(v2)
+    hip.attn_bwd(q2, k2, v2, o, dev(g.view(B * T, D)), lse, dq, dk, dv, B, T, Tk, H, dh, dh**-0.5, key_mask=dev(km) if masked else None)
+    close(dq.view(B, T, D), qd.grad, 3e-5, "xattn dq")
+    close(dk.view(B, Tk, D), kd.grad, 3e-5, "xattn dk")
+    close(dv.view(B, Tk, D), vd.grad, 3e-5, "xattn dv")
+
+
+def test_self_attention_still_matches_through_generic_entry(hip):
+    """Tk == T through the separate-pointer entry: packed-slice views of one QKV buffer."""
+    B, H, dh, T = 2, 2, 16, 40
+    D = H * dh
+    qkv = dev(rnd(B * T, 3 * D, seed=18))
+    o1, lse1 = hip.attn_fwd_packed(qkv, B, T, H, dh, dh**-0.5)
+    o2, lse2 = hip.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, T, H, dh, dh**-0.5)
+    assert torch.equal(o1, o2) and torch.equal(lse1, lse2)

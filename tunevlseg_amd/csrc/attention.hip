@@ -35,7 +35,7 @@ struct AttnParams {
     float* lse; const float* lse_in; float* delta;
     float *dq, *dk, *dv; long dq_bs, dk_bs, dv_bs; int dq_ts, dk_ts, dv_ts;
     const int* key_mask;
-    int B, H, T, causal;
+    int B, H, T, Tk, causal;  // T = queries, Tk = keys (== T for self-attention)
     float scale;
 };
 
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
-    const int T = p.T;
+    const int T = p.T, Tk = p.Tk;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const int qi = q0 + l31;
     const int qrow = qi < T ? qi : T - 1;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const float* qb = p.q + b * p.q_bs + head * DH;
     const float* kb = p.k + b * p.k_bs + head * DH;
     const float* vb = p.v + b * p.v_bs + head * DH;
-    const int* mb = p.key_mask ? p.key_mask + (long)b * T : nullptr;
+    const int* mb = p.key_mask ? p.key_mask + (long)b * Tk : nullptr;
 
     // Q fragment, pre-scaled so that exp2 can be used: s' = (q.k) * scale * log2(e)
     float qreg[NC * 4];
@@ -109,15 +109,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
     float m_run = NEG_BIG, l_run = 0.f;
 
-    const int nkt = (T + 31) / 32;
+    const int nkt = (Tk + 31) / 32;
     TileRegs<DH> sk, sv;
     float bias_reg = 0.f;
     auto gload = [&](int kt) {
-        tile_gload<DH>(sk, kb, p.k_ts, kt * 32, T);
-        tile_gload<DH>(sv, vb, p.v_ts, kt * 32, T);
+        tile_gload<DH>(sk, kb, p.k_ts, kt * 32, Tk);
+        tile_gload<DH>(sv, vb, p.v_ts, kt * 32, Tk);
         if (threadIdx.x < 32) {
             const int key = kt * 32 + threadIdx.x;
-            bias_reg = (key < T && (!mb || mb[key] != 0)) ? 0.f : NEG_BIG;
+            bias_reg = (key < Tk && (!mb || mb[key] != 0)) ? 0.f : NEG_BIG;
         }
     };
     auto sstore = [&](int buf) {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
-    const int T = p.T;
+    const int T = p.T, Tk = p.Tk;
     const int qi = blockIdx.x * 128 + wave * 32 + l31;
     const int qrow = qi < T ? qi : T - 1;
 
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const float* kb = p.k + b * p.k_bs + head * DH;
     const float* vb = p.v + b * p.v_bs + head * DH;
     const float* dob = p.d_o + ((long)b * T) * p.ldo + head * DH;
-    const int* mb = p.key_mask ? p.key_mask + (long)b * T : nullptr;
+    const int* mb = p.key_mask ? p.key_mask + (long)b * Tk : nullptr;
 
     float qreg[NC * 4], doreg[NC * 4];
     {
@@ -285,15 +285,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_dq[d][r] = 0.f;
 
-    const int nkt = (T + 31) / 32;
+    const int nkt = (Tk + 31) / 32;
     TileRegs<DH> sk, sv;
     float bias_reg = 0.f;
     auto gload = [&](int kt) {
-        tile_gload<DH>(sk, kb, p.k_ts, kt * 32, T);
-        tile_gload<DH>(sv, vb, p.v_ts, kt * 32, T);
+        tile_gload<DH>(sk, kb, p.k_ts, kt * 32, Tk);
+        tile_gload<DH>(sv, vb, p.v_ts, kt * 32, Tk);
         if (threadIdx.x < 32) {
             const int key = kt * 32 + threadIdx.x;
-            bias_reg = (key < T && (!mb || mb[key] != 0)) ? 0.f : NEG_BIG;
+            bias_reg = (key < Tk && (!mb || mb[key] != 0)) ? 0.f : NEG_BIG;
         }
     };
     auto sstore = [&](int buf) {
@@ -390,9 +390,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
-    const int T = p.T;
+    const int T = p.T, Tk = p.Tk;
     const int ki = blockIdx.x * 128 + wave * 32 + l31;
-    const int krow = ki < T ? ki : T - 1;
+    const int krow = ki < Tk ? ki : Tk - 1;
 
     const float* qb = p.q + b * p.q_bs + head * DH;
     const float* kb = p.k + b * p.k_bs + head * DH;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     const float* dob = p.d_o + ((long)b * T) * p.ldo + head * DH;
     const float* lseb = p.lse_in + ((long)b * p.H + head) * T;
     const float* delb = p.delta + ((long)b * p.H + head) * T;
-    const bool key_ok = ki < T && (!p.key_mask || p.key_mask[(long)b * T + ki] != 0);
+    const bool key_ok = ki < Tk && (!p.key_mask || p.key_mask[(long)b * Tk + ki] != 0);
 
     float kreg[NC * 4], vreg[NC * 4];
     {
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
         __syncthreads();
     }
 
-    if (ki < T) {
+    if (ki < Tk) {
         float* okb = p.dk + b * p.dk_bs + (long)ki * p.dk_ts + head * DH;
         float* ovb = p.dv + b * p.dv_bs + (long)ki * p.dv_ts + head * DH;
 #pragma unroll
@@ -544,10 +544,11 @@ extern "C" int tvl_attn_fwd(const tvlAttnFwdArgs* a, tvlStream_t stream) {
     p.q = a->q; p.k = a->k; p.v = a->v; p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs;
     p.q_ts = a->q_ts; p.k_ts = a->k_ts; p.v_ts = a->v_ts;
     p.o = a->o; p.ldo = a->ldo; p.lse = a->lse; p.key_mask = a->key_mask;
-    p.B = a->B; p.H = a->H; p.T = a->T; p.causal = a->causal; p.scale = a->scale;
+    p.B = a->B; p.H = a->H; p.T = a->T; p.Tk = a->Tk > 0 ? a->Tk : a->T; p.causal = a->causal; p.scale = a->scale;
+    TVL_REQUIRE(!a->causal || p.Tk == p.T, "tvl_attn_fwd: causal needs Tk == T");
     dim3 grid((a->T + 127) / 128, a->H, a->B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (a->dh == 64 && !a->causal && !a->key_mask && tvl_attn_mode_bf16s()) {
+    if (a->dh == 64 && !a->causal && !a->key_mask && p.Tk == p.T && tvl_attn_mode_bf16s()) {
         tvl_attn_fwd_bf16s_impl(a, s);
         TVL_LAUNCH_CHECK("tvl_attn_fwd(bf16s)");
         return 0;
@@ -582,7 +583,9 @@ extern "C" int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream) {
     p.o_in = a->o; p.d_o = a->d_o; p.ldo = a->ldo; p.lse_in = a->lse; p.delta = a->delta;
     p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.dq_bs = a->dq_bs; p.dk_bs = a->dk_bs; p.dv_bs = a->dv_bs;
     p.dq_ts = a->dq_ts; p.dk_ts = a->dk_ts; p.dv_ts = a->dv_ts;
-    p.key_mask = a->key_mask; p.B = a->B; p.H = a->H; p.T = a->T; p.causal = a->causal; p.scale = a->scale;
+    p.key_mask = a->key_mask; p.B = a->B; p.H = a->H; p.T = a->T; p.Tk = a->Tk > 0 ? a->Tk : a->T; p.causal = a->causal;
+    p.scale = a->scale;
+    TVL_REQUIRE(!a->causal || p.Tk == p.T, "tvl_attn_bwd: causal needs Tk == T");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     {
         const long pairs = (long)a->B * a->T * a->H;
@@ -592,7 +595,7 @@ extern "C" int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream) {
                                                   a->delta, a->B, a->H, a->T));
         TVL_LAUNCH_CHECK("tvl_attn_bwd(delta)");
     }
-    if (a->dh == 64 && !a->causal && !a->key_mask && tvl_attn_mode_bf16s()) {
+    if (a->dh == 64 && !a->causal && !a->key_mask && p.Tk == p.T && tvl_attn_mode_bf16s()) {
         tvl_attn_bwd_bf16s_impl(a, s);
         TVL_LAUNCH_CHECK("tvl_attn_bwd(bf16s)");
         return 0;
@@ -600,7 +603,8 @@ extern "C" int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream) {
     dim3 grid((a->T + 127) / 128, a->H, a->B);
     TVL_DH_DISPATCH(a->dh, hipLaunchKernelGGL(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p));
     TVL_LAUNCH_CHECK("tvl_attn_bwd(dq)");
-    TVL_DH_DISPATCH(a->dh, hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DH>, grid, dim3(256), 0, s, p));
+    dim3 gridk((p.Tk + 127) / 128, a->H, a->B);
+    TVL_DH_DISPATCH(a->dh, hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DH>, gridk, dim3(256), 0, s, p));
     TVL_LAUNCH_CHECK("tvl_attn_bwd(dkdv)");
     return 0;
 }

@@ -50,7 +50,7 @@ class AttnFwdArgs(C.Structure):
         ("lse", C.c_void_p),
         ("key_mask", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("T", C.c_int32), ("dh", C.c_int32), ("causal", C.c_int32),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("Tk", C.c_int32),
     ]
 
 
@@ -67,7 +67,7 @@ class AttnBwdArgs(C.Structure):
         ("dq_ts", C.c_int32), ("dk_ts", C.c_int32), ("dv_ts", C.c_int32),
         ("key_mask", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("T", C.c_int32), ("dh", C.c_int32), ("causal", C.c_int32),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("Tk", C.c_int32),
     ]
 
 
@@ -108,8 +108,17 @@ _SIGS = {
     "tvl_l2norm_bwd": [_P, _P, _P, _P, _I, _I],
     "tvl_dot": [_P, _P, _P, _L, _I],
     "tvl_colsum": [_P, _P, _L, _I, _I],
+    "tvl_im2col3x3": [_P, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I],
+    "tvl_avgpool_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
+    "tvl_avgpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
+    "tvl_bilinear_up_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
+    "tvl_bilinear_up_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
+    "tvl_bicubic_ac_fwd": [_P, _P, _P, _F, _F, _I, _I, _I, _I, _I],
+    "tvl_bicubic_ac_bwd": [_P, _F, _P, _I, _I, _I, _I, _I],
+    "tvl_dynconv_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
+    "tvl_dynconv_bwd": [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
 }
-EXPORTS = ["tvl_last_error", "tvl_abi_version", *_SIGS]
+EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", *_SIGS]
 
 _lib = None
 
@@ -127,6 +136,8 @@ def load():
     lib = C.CDLL(str(LIB_PATH))
     lib.tvl_last_error.restype = C.c_char_p
     lib.tvl_abi_version.restype = C.c_int
+    lib.tvl_dynconv_bwd_work_floats.argtypes = [_I, _I, _I, _I]
+    lib.tvl_dynconv_bwd_work_floats.restype = C.c_int64
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = [*sig, C.c_void_p]
@@ -151,6 +162,15 @@ def _p(t: torch.Tensor | None, dtype=torch.float32):
         return None
     if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
         raise RuntimeError(f"HIP op needs a contiguous {dtype} device tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def _ps(t: torch.Tensor | None):
+    """Pointer of a 2-D fp32 device matrix whose rows may be strided (a column slice of a wider matrix: channel concat)."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RuntimeError(f"HIP op needs a 2-D fp32 device matrix with unit column stride, got {t.dtype} {t.device} {tuple(t.shape)} {t.stride()}")
     return t.data_ptr()
 
 
@@ -219,7 +239,8 @@ def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True, split: int = 
 
 def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias=None, residual=None, ldr=0, act=ACT_NONE,
          pre_out=None, dact_aux=None, ld_aux=0, dact=ACT_NONE, alpha=1.0, a_map=None, c_map=None):
-    args = GemmArgs(layout, M, N, K, _p(A), lda, _p(B), ldb, _p(Cout), ldc, _p(bias), _p(residual), ldr, act, _p(pre_out),
+    args = GemmArgs(layout, M, N, K, _ps(A) if A.dim() == 2 else _p(A), lda, _p(B), ldb, _ps(Cout) if Cout.dim() == 2 else _p(Cout), ldc,
+                    _p(bias), _ps(residual) if (residual is not None and residual.dim() == 2) else _p(residual), ldr, act, _p(pre_out),
                     _p(dact_aux), ld_aux, dact, alpha, a_map or _ident(), c_map or _ident())
     split = _NSPLIT.get(GEMM_MODE, 0) if (layout == NT and M >= 256) else 0
     if _gemm_prof is not None:
@@ -511,3 +532,129 @@ def dropout(x, p: float, seed: int):
     y = torch.empty_like(x)
     _call("tvl_dropout", _p(x), _p(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF)
     return y
+
+
+# --------------------------------------------------------------------------------------
+# attention with separate q / k / v matrices (cross-attention: T queries x Tk keys)
+# --------------------------------------------------------------------------------------
+def _qkv_view(t: torch.Tensor, rows_per_batch: int):
+    """(ptr, batch stride, row stride) of a [B*rows, >=H*dh] matrix that may be a column slice of a packed buffer."""
+    return _ps(t), t.stride(0) * rows_per_batch, t.stride(0)
+
+
+def attn_fwd(q, k, v, B: int, T: int, Tk: int, H: int, dh: int, scale: float, causal=False, key_mask=None, want_lse=True):
+    D = H * dh
+    o = torch.empty((B * T, D), device=q.device, dtype=torch.float32)
+    lse = torch.empty((B, H, T), device=q.device, dtype=torch.float32) if want_lse else None
+    (qp, qb, qt), (kp, kb, kt), (vp, vb, vt) = _qkv_view(q, T), _qkv_view(k, Tk), _qkv_view(v, Tk)
+    a = AttnFwdArgs(qp, kp, vp, qb, kb, vb, qt, kt, vt, _p(o), D, _p(lse), _p(key_mask, torch.int32), B, H, T, dh,
+                    int(bool(causal)), float(scale), Tk)
+    _call("tvl_attn_fwd", C.byref(a))
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B: int, T: int, Tk: int, H: int, dh: int, scale: float, causal=False, key_mask=None):
+    """dq/dk/dv are caller-provided matrices (possibly column slices of one packed gradient buffer)."""
+    D = H * dh
+    delta = torch.empty((B, H, T), device=q.device, dtype=torch.float32)
+    (qp, qb, qt), (kp, kb, kt), (vp, vb, vt) = _qkv_view(q, T), _qkv_view(k, Tk), _qkv_view(v, Tk)
+    (dqp, dqb, dqt), (dkp, dkb, dkt), (dvp, dvb, dvt) = _qkv_view(dq, T), _qkv_view(dk, Tk), _qkv_view(dv, Tk)
+    a = AttnBwdArgs(qp, kp, vp, qb, kb, vb, qt, kt, vt, _p(o), _p(d_o), D, _p(lse), _p(delta), dqp, dkp, dvp, dqb, dkb, dvb,
+                    dqt, dkt, dvt, _p(key_mask, torch.int32), B, H, T, dh, int(bool(causal)), float(scale), Tk)
+    _call("tvl_attn_bwd", C.byref(a))
+
+
+# --------------------------------------------------------------------------------------
+# CRIS conv path: NHWC pixel matrices [B*H*W, C] (rows may be strided: channel slices of a concat buffer)
+# --------------------------------------------------------------------------------------
+def _out2d(out, rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
+    if out is None:
+        return torch.empty((rows, cols), device=like.device, dtype=torch.float32)
+    if tuple(out.shape) != (rows, cols):
+        raise RuntimeError(f"output matrix has shape {tuple(out.shape)}, expected {(rows, cols)}")
+    return out
+
+
+def im2col3x3(x2d: torch.Tensor, B: int, H: int, W: int, stride: int = 1) -> torch.Tensor:
+    """x2d [B*H*W, C] NHWC -> cols [B*Ho*Wo, 9*C (padded to a multiple of 4)], column = (ky*3+kx)*C + c."""
+    Cc = x2d.shape[1]
+    ld = x2d.stride(0)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    ldc = (9 * Cc + 3) // 4 * 4
+    cols = torch.empty((B * Ho * Wo, ldc), device=x2d.device, dtype=torch.float32)
+    _call("tvl_im2col3x3", _ps(x2d), H * W * ld, W * ld, ld, 1, _p(cols), ldc, B, H, W, Cc, stride)
+    return cols
+
+
+def im2col3x3_nchw(img: torch.Tensor, stride: int = 1) -> torch.Tensor:
+    """NCHW image [B,C,H,W] -> cols, same column order (the stem conv reads the image directly)."""
+    B, Cc, H, W = img.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    ldc = (9 * Cc + 3) // 4 * 4
+    cols = torch.empty((B * Ho * Wo, ldc), device=img.device, dtype=torch.float32)
+    _call("tvl_im2col3x3", _p(img), Cc * H * W, W, 1, H * W, _p(cols), ldc, B, H, W, Cc, stride)
+    return cols
+
+
+def avgpool_fwd(x2d, B: int, H: int, W: int, k: int, out=None):
+    Cc = x2d.shape[1]
+    y = _out2d(out, B * (H // k) * (W // k), Cc, x2d)
+    _call("tvl_avgpool_fwd", _ps(x2d), x2d.stride(0), _ps(y), y.stride(0), B, H, W, Cc, k)
+    return y
+
+
+def avgpool_bwd(dy2d, B: int, H: int, W: int, k: int, out=None):
+    """H, W are the INPUT sizes of the pooled map."""
+    Cc = dy2d.shape[1]
+    dx = _out2d(out, B * H * W, Cc, dy2d)
+    _call("tvl_avgpool_bwd", _ps(dy2d), dy2d.stride(0), _ps(dx), dx.stride(0), B, H, W, Cc, k)
+    return dx
+
+
+def bilinear_up_fwd(x2d, B: int, H: int, W: int, s: int, out=None):
+    Cc = x2d.shape[1]
+    y = _out2d(out, B * H * s * W * s, Cc, x2d)
+    _call("tvl_bilinear_up_fwd", _ps(x2d), x2d.stride(0), _ps(y), y.stride(0), B, H, W, Cc, s)
+    return y
+
+
+def bilinear_up_bwd(dy2d, B: int, H: int, W: int, s: int, out=None):
+    """H, W are the INPUT sizes (dy is [B*H*s*W*s, C])."""
+    Cc = dy2d.shape[1]
+    dx = _out2d(out, B * H * W, Cc, dy2d)
+    _call("tvl_bilinear_up_bwd", _ps(dy2d), dy2d.stride(0), _ps(dx), dx.stride(0), B, H, W, Cc, s)
+    return dx
+
+
+def bicubic_ac_fwd(x, Ho: int, Wo: int, extra=None, a: float = 1.0, r: float = 0.0):
+    """x [B,Hi,Wi] -> a * bicubic(x; align_corners=True) [+ r * extra] as [B,Ho,Wo]."""
+    B, Hi, Wi = x.shape
+    y = torch.empty((B, Ho, Wo), device=x.device, dtype=torch.float32)
+    _call("tvl_bicubic_ac_fwd", _p(x), _p(y), _p(extra), float(a), float(r), B, Hi, Wi, Ho, Wo)
+    return y
+
+
+def bicubic_ac_bwd(dy, Hi: int, Wi: int, a: float = 1.0):
+    B, Ho, Wo = dy.shape
+    dx = torch.empty((B, Hi, Wi), device=dy.device, dtype=torch.float32)
+    _call("tvl_bicubic_ac_bwd", _p(dy), float(a), _p(dx), B, Hi, Wi, Ho, Wo)
+    return dx
+
+
+def dynconv_fwd(x2d, word, B: int, H: int, W: int):
+    """Per-sample 3x3 conv C->1 with kernel/bias from ``word`` [B, 9C+1] (reference cris_model/layers.py:106-118)."""
+    Cc = x2d.shape[1]
+    taps = torch.empty((B * H * W, 9), device=x2d.device, dtype=torch.float32)
+    out = torch.empty((B, H, W), device=x2d.device, dtype=torch.float32)
+    _call("tvl_dynconv_fwd", _ps(x2d), x2d.stride(0), _p(word), word.shape[1], _p(taps), _p(out), B, H, W, Cc)
+    return out
+
+
+def dynconv_bwd(dout, x2d, word, B: int, H: int, W: int, need_dx: bool = True):
+    Cc = x2d.shape[1]
+    dx = torch.empty((B * H * W, Cc), device=x2d.device, dtype=torch.float32) if need_dx else None
+    dword = torch.empty_like(word)
+    n = load().tvl_dynconv_bwd_work_floats(B, H, W, Cc)
+    work = torch.empty(n, device=x2d.device, dtype=torch.float32)
+    _call("tvl_dynconv_bwd", _p(dout), _ps(x2d), x2d.stride(0), _p(word), word.shape[1], _p(dx), Cc, _p(dword), _p(work), B, H, W, Cc)
+    return dx, dword
