@@ -199,6 +199,8 @@ int tvl_colsum(const float* x, float* out, int64_t rows, int32_t cols, int32_t a
  * wider concat buffer is addressed by pointer offset + ld).  A 1x1 conv (+ folded eval BatchNorm + ReLU) is tvl_gemm_* over
  * the map; a 3x3 conv is tvl_gemm_* over the im2col matrix; their data gradients are the same two calls with the
  * transposed / tap-flipped weight matrix. */
+/* dst[r*ldd + c] = src[r*lds + c]: channel concat (torch.cat(dim=1) of NCHW maps, layers.py:424,429,440) and its split */
+int tvl_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int64_t rows, int32_t cols, tvlStream_t stream);
 /* cols[(b,oy,ox), (ky*3+kx)*C + c] = x[b*sb + (oy*stride+ky-1)*sy + (ox*stride+kx-1)*sx + c*sc] (0 outside the map);
  * explicit element strides let the stem conv read the NCHW image; columns 9*C..ldc-1 are zero-filled. pad 1, stride 1|2. */
 int tvl_im2col3x3(const float* x, int64_t sb, int64_t sy, int64_t sx, int64_t sc, float* cols, int32_t ldc,

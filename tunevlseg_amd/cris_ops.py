@@ -1,0 +1,314 @@
+"""autograd nodes of the CRIS path (BASELINE configs[2]); every forward/backward body is a sequence of HIP launches.
+
+Feature maps are NHWC pixel matrices ``[B*H*W, C]`` (csrc/conv.hip).  The whole CRIS model is frozen and in eval mode
+(reference coop_cris.py:66-68), so BatchNorm is folded into the preceding conv/linear once at load time and every node
+below carries a data-gradient-only backward; weight gradients exist only for the new last layer and the mix ratio.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import hip
+from .ops import Fn, _c
+
+
+@dataclass
+class FrozenLinear:
+    """``y = act(x W^T + b)``: nn.Linear, or a 1x1 conv (+ folded eval BatchNorm) over a pixel matrix."""
+    W: torch.Tensor            # [N, K]
+    b: torch.Tensor | None     # [N]
+    Wt: torch.Tensor           # [K, N]  (data gradient as an NT GEMM)
+
+
+@dataclass
+class FrozenConv3:
+    """3x3 / pad 1 conv (+ folded eval BatchNorm) as a GEMM over the im2col matrix."""
+    Wm: torch.Tensor           # [Cout, Kpad]  columns ordered (ky, kx, c), zero padded to a multiple of 4
+    b: torch.Tensor | None     # [Cout]
+    Wd: torch.Tensor | None    # [Cin, 9*Cout (padded)] tap-flipped transpose: dX = im2col(dY) Wd^T  (stride 1 only)
+    cin: int
+    cout: int
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# no-grad helpers (image tower, text-independent part of the neck)
+# ----------------------------------------------------------------------------------------------------------------------
+def flinear(x2d: torch.Tensor, fl: FrozenLinear, act: int = hip.ACT_NONE, residual=None, out=None) -> torch.Tensor:
+    M, K = x2d.shape
+    N = fl.W.shape[0]
+    y = out if out is not None else torch.empty((M, N), device=x2d.device, dtype=torch.float32)
+    hip.gemm(hip.NT, M, N, K, x2d, x2d.stride(0), fl.W, K, y, y.stride(0), bias=fl.b, act=act,
+             residual=residual, ldr=0 if residual is None else residual.stride(0))
+    return y
+
+
+def fconv3(x2d: torch.Tensor, fc: FrozenConv3, B: int, H: int, W: int, act: int = hip.ACT_NONE, stride: int = 1, out=None) -> torch.Tensor:
+    cols = hip.im2col3x3(x2d, B, H, W, stride)
+    M, K = cols.shape
+    y = out if out is not None else torch.empty((M, fc.cout), device=x2d.device, dtype=torch.float32)
+    hip.gemm(hip.NT, M, fc.cout, K, cols, K, fc.Wm, K, y, y.stride(0), bias=fc.b, act=act)
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# autograd nodes
+# ----------------------------------------------------------------------------------------------------------------------
+class FLinearFn(Fn):
+    @staticmethod
+    def forward(ctx, x, fl: FrozenLinear, act):
+        shape = x.shape
+        x2d = _c(x).view(-1, shape[-1])
+        y = flinear(x2d, fl, act)
+        ctx.fl, ctx.act, ctx.shape = fl, act, shape
+        ctx.save_for_backward(y if act == hip.ACT_RELU else None)
+        if act not in (hip.ACT_NONE, hip.ACT_RELU):
+            raise NotImplementedError("FLinearFn: only ReLU / identity epilogues are differentiated")
+        return y.view(*shape[:-1], y.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        fl = ctx.fl
+        dy2d = _c(dy).view(-1, fl.W.shape[0])
+        if ctx.act == hip.ACT_RELU:
+            dy2d = hip.dact_mul(dy2d, y, hip.ACT_RELU)  # relu'(pre) == (y > 0)
+        return hip.linear_dgrad(dy2d, fl.W, Wt=fl.Wt).view(ctx.shape), None, None
+
+
+def flinear_g(x, fl: FrozenLinear, act: int = hip.ACT_NONE):
+    return FLinearFn.apply(x, fl, act)
+
+
+class FConv3Fn(Fn):
+    @staticmethod
+    def forward(ctx, x2d, fc: FrozenConv3, B, H, W, act):
+        x2d = _c(x2d)
+        y = fconv3(x2d, fc, B, H, W, act)
+        ctx.fc, ctx.act, ctx.geom = fc, act, (B, H, W)
+        ctx.save_for_backward(y if act == hip.ACT_RELU else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        fc = ctx.fc
+        B, H, W = ctx.geom
+        dy2d = _c(dy)
+        if ctx.act == hip.ACT_RELU:
+            dy2d = hip.dact_mul(dy2d, y, hip.ACT_RELU)
+        cols = hip.im2col3x3(dy2d, B, H, W, 1)
+        M, K = cols.shape
+        dx = torch.empty((M, fc.cin), device=dy2d.device, dtype=torch.float32)
+        hip.gemm(hip.NT, M, fc.cin, K, cols, K, fc.Wd, K, dx, fc.cin)
+        return dx, None, None, None, None, None
+
+
+def fconv3_g(x2d, fc: FrozenConv3, B: int, H: int, W: int, act: int = hip.ACT_RELU):
+    return FConv3Fn.apply(x2d, fc, B, H, W, act)
+
+
+class ReluFn(Fn):
+    @staticmethod
+    def forward(ctx, x):
+        y = hip.bias_act(_c(x).view(-1, x.shape[-1]), None, hip.ACT_RELU).view(x.shape)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return hip.dact_mul(_c(dy).view(-1, y.shape[-1]), y.view(-1, y.shape[-1]), hip.ACT_RELU).view(y.shape)
+
+
+class BilinearUpFn(Fn):
+    @staticmethod
+    def forward(ctx, x2d, B, H, W, s):
+        ctx.geom = (B, H, W, s)
+        return hip.bilinear_up_fwd(_c(x2d), B, H, W, s)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, s = ctx.geom
+        return hip.bilinear_up_bwd(_c(dy), B, H, W, s), None, None, None, None
+
+
+class CatColsFn(Fn):
+    """torch.cat(dim=1) of NCHW maps == column concat of pixel matrices (reference layers.py:424,429,440)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        rows = parts[0].shape[0]
+        widths = [p.shape[1] for p in parts]
+        out = torch.empty((rows, sum(widths)), device=parts[0].device, dtype=torch.float32)
+        off = 0
+        for p, w in zip(parts, widths):
+            hip.copy2d(p, out[:, off:off + w])
+            off += w
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = _c(d)
+        grads, off = [], 0
+        for i, w in enumerate(ctx.widths):
+            if ctx.needs_input_grad[i]:
+                g = torch.empty((d.shape[0], w), device=d.device, dtype=torch.float32)
+                hip.copy2d(d[:, off:off + w], g)
+                grads.append(g)
+            else:
+                grads.append(None)
+            off += w
+        return tuple(grads)
+
+
+class BcastAddFn(Fn):
+    """x[b, t, :] + pos[t, :]: fixed sin/cos position codes added to every sample (layers.py:318-320)."""
+
+    @staticmethod
+    def forward(ctx, x, pos, B):
+        x2 = _c(x).view(B, -1)
+        return hip.bias_act(x2, pos.view(-1), hip.ACT_NONE).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, None, None
+
+
+class SelfAttnQKFn(Fn):
+    """Self-attention whose q and k come from one packed projection ``qk`` [B*T, 2D] and v from another matrix."""
+
+    @staticmethod
+    def forward(ctx, qk, v, B, T, H, dh):
+        qk, v = _c(qk), _c(v)
+        D = H * dh
+        o, lse = hip.attn_fwd(qk[:, :D], qk[:, D:], v, B, T, T, H, dh, dh**-0.5)
+        ctx.save_for_backward(qk, v, o, lse)
+        ctx.geom = (B, T, H, dh)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qk, v, o, lse = ctx.saved_tensors
+        B, T, H, dh = ctx.geom
+        D = H * dh
+        dqk, dv = torch.empty_like(qk), torch.empty_like(v)
+        hip.attn_bwd(qk[:, :D], qk[:, D:], v, o, _c(d_o), lse, dqk[:, :D], dqk[:, D:], dv, B, T, T, H, dh, dh**-0.5)
+        return dqk, dv, None, None, None, None
+
+
+class CrossAttnFn(Fn):
+    """T visual queries x Tk word keys with a key-padding mask (layers.py:341-349)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_mask, B, T, Tk, H, dh):
+        q, k, v = _c(q), _c(k), _c(v)
+        o, lse = hip.attn_fwd(q, k, v, B, T, Tk, H, dh, dh**-0.5, key_mask=key_mask)
+        ctx.save_for_backward(q, k, v, o, lse, key_mask)
+        ctx.geom = (B, T, Tk, H, dh)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, lse, key_mask = ctx.saved_tensors
+        B, T, Tk, H, dh = ctx.geom
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        hip.attn_bwd(q, k, v, o, _c(d_o), lse, dq, dk, dv, B, T, Tk, H, dh, dh**-0.5, key_mask=key_mask)
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+class DynConvFn(Fn):
+    """Projector tail: per-sample 3x3 kernel + bias from the text state (layers.py:106-118)."""
+
+    @staticmethod
+    def forward(ctx, x2d, word, B, H, W):
+        x2d, word = _c(x2d), _c(word)
+        ctx.save_for_backward(x2d, word)
+        ctx.geom = (B, H, W)
+        return hip.dynconv_fwd(x2d, word, B, H, W)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2d, word = ctx.saved_tensors
+        B, H, W = ctx.geom
+        dx, dword = hip.dynconv_bwd(_c(dout), x2d, word, B, H, W, need_dx=ctx.needs_input_grad[0])
+        return dx, dword, None, None, None
+
+
+class BicubicFn(Fn):
+    """F.interpolate(pred, img_size, mode="bicubic", align_corners=True) on [B,h,w] maps (coop_cris.py:235)."""
+
+    @staticmethod
+    def forward(ctx, pred, Ho, Wo):
+        ctx.geom = pred.shape[1:]
+        return hip.bicubic_ac_fwd(_c(pred), Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, d):
+        return hip.bicubic_ac_bwd(_c(d), *ctx.geom), None, None
+
+
+class UpconvFn(Fn):
+    """Upsample(x ps, bilinear) -> Conv2d(C->1, k, same, replicate) on a [B*G*G, C] map; the C x (G*ps)^2 tensor is never
+    materialised (csrc/upconv.hip).  ``conv_w`` / ``conv_b`` are trainable (coop_cris.py:74-86)."""
+
+    @staticmethod
+    def forward(ctx, z, conv_w, conv_b, B, G, ps):
+        z = _c(z)
+        Cc, k = z.shape[1], conv_w.shape[-1]
+        w2 = _c(conv_w).view(Cc, k * k)
+        taps = torch.empty((B * G * G, k * k), device=z.device, dtype=torch.float32)
+        hip.gemm(hip.NN, B * G * G, k * k, Cc, z, Cc, w2, k * k, taps, k * k)
+        ctx.save_for_backward(z, w2)
+        ctx.geom = (B, G, ps, k, Cc)
+        return hip.upconv_taps_fwd(taps, conv_b, B, G, ps, k)
+
+    @staticmethod
+    def backward(ctx, d):
+        z, w2 = ctx.saved_tensors
+        B, G, ps, k, Cc = ctx.geom
+        d = _c(d)
+        M = B * G * G
+        dtaps = hip.upconv_taps_bwd(d, B, G, ps, k)
+        dz = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dz = torch.empty((M, Cc), device=d.device, dtype=torch.float32)
+            hip.gemm(hip.NT, M, Cc, k * k, dtaps, k * k, w2, k * k, dz, Cc)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((Cc, k * k), device=d.device, dtype=torch.float32)
+            hip.gemm(hip.TN, Cc, k * k, M, z, Cc, dtaps, k * k, dw, k * k)
+            dw = dw.view(1, Cc, k, k)
+        if ctx.needs_input_grad[2]:
+            db = hip.dot(d)
+        return dz, dw, db, None, None, None
+
+
+class MixFn(Fn):
+    """``(1 - r) * main + r * extra`` with a trainable scalar r (coop_cris.py:240-242)."""
+
+    @staticmethod
+    def forward(ctx, main, extra, ratio):
+        r = float(ratio.item()) if isinstance(ratio, torch.Tensor) else float(ratio)
+        out = _c(extra).clone()
+        hip.axpby(_c(main), 1.0 - r, out, r)
+        ctx.r = r
+        ctx.save_for_backward(main, extra)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        main, extra = ctx.saved_tensors
+        d = _c(d)
+        r = ctx.r
+        dmain = dextra = dr = None
+        if ctx.needs_input_grad[0]:
+            dmain = torch.zeros_like(d)
+            hip.axpby(d, 1.0 - r, dmain, 0.0)
+        if ctx.needs_input_grad[1]:
+            dextra = torch.zeros_like(d)
+            hip.axpby(d, r, dextra, 0.0)
+        if ctx.needs_input_grad[2]:
+            dr = (hip.dot(d, extra) - hip.dot(d, main)).view(())
+        return dmain, dextra, dr

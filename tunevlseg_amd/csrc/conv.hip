@@ -331,7 +331,37 @@ __global__ void dynconv_reduce_kernel(const float* __restrict__ work, float* __r
     }
 }
 
+// ---- strided matrix copy (channel concat / split of pixel matrices) --------------------------------------------------------
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, long rows, int cols, int vec) {
+    if (vec) {
+        const int c4 = cols >> 2;
+        const long total = rows * c4;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const long r = i / c4;
+            const int c = (int)(i % c4) * 4;
+            *reinterpret_cast<float4*>(dst + r * ldd + c) = *reinterpret_cast<const float4*>(src + r * lds + c);
+        }
+    } else {
+        const long total = rows * cols;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const long r = i / cols;
+            const int c = (int)(i % cols);
+            dst[r * ldd + c] = src[r * lds + c];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int tvl_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int64_t rows, int32_t cols, tvlStream_t stream) {
+    TVL_REQUIRE(src && dst, "tvl_copy2d: null pointer");
+    TVL_REQUIRE(rows > 0 && cols > 0 && lds >= cols && ldd >= cols, "tvl_copy2d: bad shape rows=%ld cols=%d lds=%d ldd=%d", (long)rows, cols, lds, ldd);
+    const int vec = cols % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && tvl_aligned16(src) && tvl_aligned16(dst);
+    hipLaunchKernelGGL(copy2d_kernel, dim3(nblk(vec ? rows * (cols / 4) : rows * cols)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, lds,
+                       dst, ldd, (long)rows, cols, vec);
+    TVL_LAUNCH_CHECK("tvl_copy2d");
+    return 0;
+}
 
 extern "C" int tvl_im2col3x3(const float* x, int64_t sb, int64_t sy, int64_t sx, int64_t sc, float* cols, int32_t ldc, int32_t B,
                              int32_t H, int32_t W, int32_t C, int32_t stride, tvlStream_t stream) {

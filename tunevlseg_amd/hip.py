@@ -108,6 +108,7 @@ _SIGS = {
     "tvl_l2norm_bwd": [_P, _P, _P, _P, _I, _I],
     "tvl_dot": [_P, _P, _P, _L, _I],
     "tvl_colsum": [_P, _P, _L, _I, _I],
+    "tvl_copy2d": [_P, _I, _P, _I, _L, _I],
     "tvl_im2col3x3": [_P, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
@@ -658,3 +659,11 @@ def dynconv_bwd(dout, x2d, word, B: int, H: int, W: int, need_dx: bool = True):
     work = torch.empty(n, device=x2d.device, dtype=torch.float32)
     _call("tvl_dynconv_bwd", _p(dout), _ps(x2d), x2d.stride(0), _p(word), word.shape[1], _p(dx), Cc, _p(dword), _p(work), B, H, W, Cc)
     return dx, dword
+
+
+def copy2d(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst[:, :] = src for 2-D matrices whose rows may be strided (channel concat / split)."""
+    if src.shape != dst.shape:
+        raise RuntimeError(f"copy2d shape mismatch {tuple(src.shape)} vs {tuple(dst.shape)}")
+    _call("tvl_copy2d", _ps(src), src.stride(0), _ps(dst), dst.stride(0), src.shape[0], src.shape[1])
+    return dst
