@@ -34,11 +34,11 @@ MODE_DTYPE = {"f32": "f32", "bf16x6": "f32 (3xbf16-split operands on bf16 MFMA, 
               "bf16x3": "f32 in/out, 2xbf16-split operands (reduced precision)", "bf16": "bf16 operands, fp32 accumulate (reduced precision)"}
 
 
-def make_batch(B: int, size: int, seed: int, device):
+def make_batch(B: int, size: int, seed: int, device, pad_id: int = 1):
     g = torch.Generator().manual_seed(seed)
     img = torch.randn(B, 3, size, size, generator=g)
     L = 8
-    ids = torch.full((B, L), 1, dtype=torch.long)
+    ids = torch.full((B, L), pad_id, dtype=torch.long)
     am = torch.zeros(B, L, dtype=torch.long)
     for b in range(B):
         n_words = 2 + (b % 4)
@@ -47,6 +47,38 @@ def make_batch(B: int, size: int, seed: int, device):
         am[b, : len(row)] = 1
     mask = (torch.rand(B, 1, size, size, generator=g) > 0.7).float()
     return {"image": img.to(device), "input_ids": ids.to(device), "attention_mask": am.to(device), "mask": mask.to(device)}
+
+
+class _PromptTokenizer:
+    """Stand-in for ``AutoTokenizer("CIDAS/clipseg-rd64")`` (not reachable offline): CLIP BPE ids of "a photo of a"."""
+
+    def __call__(self, text, **kw):
+        class R:
+            pass
+
+        r = R()
+        r.input_ids = torch.tensor([[320, 1125, 539, 320]] * (1 if isinstance(text, str) else len(text)), dtype=torch.long)
+        return r
+
+
+def build_cris_module(device, seed: int = 0):
+    """BASELINE configs[2]: CRIS + CoCoOp meta-net (reference configs/model/cocoop/cris.yaml), 416x416."""
+    from tunevlseg_amd import nets
+    from tunevlseg_amd.nets.context_learner import CoCoOpContextLearner
+    from tunevlseg_amd.task import DiceCELoss, FusedAdamW, ImageTextMaskModule
+
+    torch.manual_seed(12345)
+    net = nets.COOPCRIS(
+        model_cfg={"clip_pretrain": f"random:rn50:seed={seed}", "img_size": 416, "freeze_encoder": True, "cris_pretrain": None},
+        context_learner=partial(CoCoOpContextLearner, norm_image_features=False, prompt_depth=1, use_unified_projection=False,
+                                intermediate_dim=64, use_proj_norm=True, use_lora_proj=False, num_context=4,
+                                context_initializer="a photo of a", vector_std=0.02, tokenizer=_PromptTokenizer()),
+        freeze_all=True, no_freeze_last_layer=False, use_new_last_layer=True, new_last_layer_kernel_size=5, residual_ratio=0.5)
+    module = ImageTextMaskModule(net=net, loss_fn=DiceCELoss(sigmoid=True, lambda_dice=1, lambda_ce=0.2),
+                                 optimizer=partial(FusedAdamW, lr=2e-5), scheduler=None, compile=False, task="binary",
+                                 threshold=0.5, weight_decay=0.0).to(device)
+    module.setup("fit")
+    return module, module.configure_optimizers()["optimizer"]
 
 
 def build_module(device, num_context: int = 10, prompt_depth: int = 1, seed: int = 0):
@@ -106,6 +138,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--workload", choices=("vpt", "cris"), default="vpt",
+                    help="vpt = BASELINE configs[1] (the headline line); cris = configs[2] (CRIS + CoCoOp, 416x416), reported for DESIGN.md")
     args = ap.parse_args()
 
     from tunevlseg_amd import dist as tdist
@@ -120,8 +154,10 @@ def main():
     device = torch.device("cuda", local_rank)
     hip.load()
 
-    module, opt = build_module(device)
-    batch = make_batch(args.batch, 352, 100 + rank, device)
+    cris = args.workload == "cris"
+    module, opt = build_cris_module(device) if cris else build_module(device)
+    batch = make_batch(args.batch, 416 if cris else 352, 100 + rank, device, pad_id=0 if cris else 1)
+    gflop_per_image = 212.8 if cris else GFLOP_PER_IMAGE_TRAIN  # SURVEY.md §8d (FlopCounterMode on the reference classes)
 
     def step():
         opt.zero_grad()
@@ -180,20 +216,23 @@ def main():
         ms = 1e3 * elapsed / args.steps
         value = world * args.batch * args.steps / elapsed
         out = {
-            "metric": "images/sec, train step (fwd + DiceCE + bwd + AdamW on prompts), CLIPSeg ViT-B/16 + VPT-10 shallow, 352x352",
+            "metric": ("images/sec, train step (fwd + DiceCE + bwd + AdamW on prompts), " +
+                       ("CRIS (CLIP-RN50) + CoCoOp, 416x416" if cris else "CLIPSeg ViT-B/16 + VPT-10 shallow, 352x352")),
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": MODE_DTYPE[hip.GEMM_MODE],
             "gemm_mode": hip.GEMM_MODE,
             "data": "synthetic", "per_gpu": round(value / world, 2),
-            "config": {"workload": "CLIPSeg ViT-B/16 + VPT-shallow (10 visual prompts), 352x352, bs=32/GPU (BASELINE configs[1])",
+            "config": {"workload": ("CRIS (CLIP-RN50 + cross-attn decoder) + CoCoOp meta-net, 416x416, bs=32/GPU (BASELINE configs[2])" if cris else
+                                    "CLIPSeg ViT-B/16 + VPT-shallow (10 visual prompts), 352x352, bs=32/GPU (BASELINE configs[1])"),
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
-                       "weights": "seeded random init (rd64 geometry)", "use_new_last_layer": False},
-            "step_tflops": round(value * GFLOP_PER_IMAGE_TRAIN / 1e3, 2),
-            "step_frac_of_f32_mfma_peak": round(value / world * GFLOP_PER_IMAGE_TRAIN / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+                       "weights": "seeded random init (RN50 CRIS geometry)" if cris else "seeded random init (rd64 geometry)",
+                       "use_new_last_layer": cris},
+            "step_tflops": round(value * gflop_per_image / 1e3, 2),
+            "step_frac_of_f32_mfma_peak": round(value / world * gflop_per_image / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
             "loss": round(float(loss.item()), 6), "train_dice": round(metrics["train_dice"], 6), "train_iou": round(metrics["train_iou"], 6),
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not cris:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(out), flush=True)
     if world > 1:

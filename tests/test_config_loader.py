@@ -147,3 +147,19 @@ def test_reference_config_tree_composes(model):
     assert net["model_cfg"]["pretrained_model_name_or_path"] == "CIDAS/clipseg-rd64"
     assert cfg["seed"] == 12345 and cfg["trainer"]["max_epochs"] == 20
     assert CL.resolve(cfg, cfg["model"]["optimizer"])["lr"] == pytest.approx(2.0e-4)
+
+
+@pytest.mark.skipif(not REF_CONFIGS.exists(), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("model", ["coop/cris", "cocoop/cris"])
+def test_reference_cris_config_composes(model):
+    """BASELINE configs[2]: experiment=coop/cris composes from the reference's YAMLs and maps onto COOPCRIS here."""
+    from tunevlseg_amd import nets
+
+    cfg = CL.Composer(REF_CONFIGS).compose("train", ["experiment=coop/cris", f"model={model}", "ds_name=kvasir_polyp", "prompt_index=0",
+                                                     "logger=null"])
+    net = CL.resolve(cfg, cfg["model"]["net"])
+    assert CL.locate(net["_target_"]) is nets.COOPCRIS
+    assert CL.map_target(net["context_learner"]["_target_"]).startswith("tunevlseg_amd.nets.context_learner.")
+    mc = net["model_cfg"]
+    assert mc["img_size"] == 416 and mc["fpn_in"] == [512, 1024, 1024] and mc["num_layers"] == 3 and mc["word_dim"] == 1024
+    assert net["use_new_last_layer"] is True and net["context_learner"]["context_initializer"] == "a photo of a"

@@ -79,3 +79,48 @@ def test_fit_reduces_loss_and_checkpoints_round_trip(tmp_path):
             assert torch.equal(p.detach(), before[k]), k
     test_metrics = trainer.test(module, va, ckpt_path="best")
     assert set(test_metrics) == {"test_dice", "test_iou", "test_loss"}
+
+
+def test_cris_two_adamw_steps_match_oracle():
+    """BASELINE configs[2] update path at reduced width: COOPCRIS + CoOp prompts + new last layer, two AdamW steps."""
+    from oracle import clipseg_oracle as O
+    from oracle import cris_oracle as OC
+    from tunevlseg_amd import nets
+    from tunevlseg_amd.cris_config import CRISConfig
+    from tunevlseg_amd.nets.context_learner import CoOpContextLearner
+    from tunevlseg_amd.task import DiceCELoss, FusedAdamW, ImageTextMaskModule
+    from tunevlseg_amd.weights import init_cris_state_dict
+
+    cfg = CRISConfig.tiny()
+    sd = init_cris_state_dict(cfg, 31)
+    torch.manual_seed(0)
+    net = nets.COOPCRIS(model_cfg={"clip_pretrain": {"config": cfg, "state_dict": sd}, "img_size": cfg.img_size},
+                        context_learner=partial(CoOpContextLearner, prompt_depth=2, num_context=3), use_new_last_layer=True)
+    module = ImageTextMaskModule(net, DiceCELoss(sigmoid=True, lambda_dice=1, lambda_ce=0.2), optimizer=partial(FusedAdamW, lr=2e-3),
+                                 scheduler=None, weight_decay=0.01).cuda()
+    g = torch.Generator().manual_seed(5)
+    pix = torch.randn(3, 3, cfg.img_size, cfg.img_size, generator=g)
+    ids = torch.tensor([[62, 5, 9, 63, 0, 0], [62, 7, 11, 13, 63, 0], [62, 8, 63, 0, 0, 0]])
+    mask = (torch.rand(3, 1, cfg.img_size, cfg.img_size, generator=g) > 0.7).float()
+    ctx = net.context_learner.context_vectors.detach().cpu().clone().requires_grad_(True)
+    c0, c2 = net.additive_decoder_layer[0], net.additive_decoder_layer[2]
+    w1 = c0.weight.detach().cpu().clone().requires_grad_(True)
+    cw, cb = c2.weight.detach().cpu().clone().requires_grad_(True), c2.bias.detach().cpu().clone().requires_grad_(True)
+    ratio = net.residual_ratio.detach().cpu().clone().requires_grad_(True)
+    ropt = torch.optim.AdamW([{"params": [w1, cw], "weight_decay": 0.01}, {"params": [ctx, cb, ratio], "weight_decay": 0.0}], lr=2e-3)
+    module.setup("fit")
+    opt = module.configure_optimizers()["optimizer"]
+    am = (ids != 0).long()
+    batch = {"image": pix.cuda(), "input_ids": ids.cuda(), "attention_mask": am.cuda(), "mask": mask.cuda()}
+    for _ in range(2):
+        opt.zero_grad()
+        module.training_step(batch).backward()
+        opt.step()
+        ropt.zero_grad()
+        logits = OC.cris_forward(sd, cfg, {"kind": "coop", "ctx": ctx}, pix, ids, am, {"w1": w1, "w": cw, "b": cb, "ratio": ratio})
+        O.dice_ce_loss(logits, mask).backward()
+        ropt.step()
+    for mine, ref, name in ((net.context_learner.context_vectors, ctx, "ctx"), (c0.weight, w1, "w1"), (c2.weight, cw, "conv_w"),
+                            (c2.bias, cb, "conv_b"), (net.residual_ratio, ratio, "ratio")):
+        err = (mine.detach().cpu() - ref.detach()).abs().max().item()
+        assert err <= 2e-3 * 2e-2, f"{name}: {err:.3e}"
