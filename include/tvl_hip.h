@@ -205,6 +205,11 @@ int tvl_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int64_t r
  * explicit element strides let the stem conv read the NCHW image; columns 9*C..ldc-1 are zero-filled. pad 1, stride 1|2. */
 int tvl_im2col3x3(const float* x, int64_t sb, int64_t sy, int64_t sx, int64_t sc, float* cols, int32_t ldc,
                   int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride, tvlStream_t stream);
+/* The same conv WITHOUT the im2col matrix (implicit GEMM on the split-bf16 kernel): args->A = the NHWC map (lda = its row
+ * stride), args->B = weights [N, ldb] in the column order above, args->M = B*Ho*Wo, args->K = 9*C; epilogue as tvl_gemm_*.
+ * Needs C % 4 == 0.  a_map is ignored. */
+typedef struct { int32_t B, H, W, C, stride; } tvlConvGeom;
+int tvl_conv3x3_bf16s(const tvlGemmArgs* args, const tvlConvGeom* geom, int32_t nsplit, tvlStream_t stream);
 /* nn.AvgPool2d(k) / F.avg_pool2d(x, k, k) on [B,H,W,C] (H, W divisible by k) and its gradient (H, W = input sizes) */
 int tvl_avgpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);
 int tvl_avgpool_bwd(const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);

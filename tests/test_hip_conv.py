@@ -65,6 +65,25 @@ def test_conv3x3_as_im2col_gemm(hip, B, C, H, W, stride, Cout):
     assert torch.equal(cols2, cols)
 
 
+@pytest.mark.parametrize("B,C,H,W,stride,Cout", [(2, 8, 12, 12, 1, 5), (1, 32, 26, 26, 1, 64), (3, 64, 13, 13, 1, 40), (2, 16, 20, 14, 2, 24),
+                                                 (1, 512, 26, 26, 1, 512), (4, 36, 9, 11, 1, 130)])
+@pytest.mark.parametrize("mode", ["bf16x6", "f32"])
+def test_conv3x3_implicit_gemm(hip, B, C, H, W, stride, Cout, mode):
+    """hip.conv3x3: implicit GEMM (split-bf16) / im2col + GEMM (fp32) with bias + ReLU epilogue, reading a channel slice."""
+    x, w, b = rnd(B, C + 4, H, W, seed=21), rnd(Cout, C, 3, 3, seed=22) * (9 * C) ** -0.5, rnd(Cout, seed=23)
+    ref = F.relu(F.conv2d(x[:, 4:].double(), w.double(), b.double(), stride=stride, padding=1))
+    Ho, Wo = ref.shape[2:]
+    wm = w.permute(0, 2, 3, 1).reshape(Cout, 9 * C)
+    wide = dev(nhwc(x))
+    old = hip.GEMM_MODE
+    hip.set_gemm_mode(mode)
+    try:
+        y = hip.conv3x3(wide[:, 4:], B, H, W, dev(wm), dev(b), hip.ACT_RELU, stride)
+    finally:
+        hip.set_gemm_mode(old)
+    close(nchw(y, B, Ho, Wo), ref, 2e-5, f"conv3x3 {mode}")
+
+
 def test_im2col_reads_channel_slice(hip):
     B, C, H, W = 2, 8, 5, 5
     x = rnd(B, 2 * C, H, W, seed=3)

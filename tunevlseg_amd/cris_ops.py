@@ -45,11 +45,7 @@ def flinear(x2d: torch.Tensor, fl: FrozenLinear, act: int = hip.ACT_NONE, residu
 
 
 def fconv3(x2d: torch.Tensor, fc: FrozenConv3, B: int, H: int, W: int, act: int = hip.ACT_NONE, stride: int = 1, out=None) -> torch.Tensor:
-    cols = hip.im2col3x3(x2d, B, H, W, stride)
-    M, K = cols.shape
-    y = out if out is not None else torch.empty((M, fc.cout), device=x2d.device, dtype=torch.float32)
-    hip.gemm(hip.NT, M, fc.cout, K, cols, K, fc.Wm, K, y, y.stride(0), bias=fc.b, act=act)
-    return y
+    return hip.conv3x3(x2d, B, H, W, fc.Wm, fc.b, act, stride, out)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -98,11 +94,7 @@ class FConv3Fn(Fn):
         dy2d = _c(dy)
         if ctx.act == hip.ACT_RELU:
             dy2d = hip.dact_mul(dy2d, y, hip.ACT_RELU)
-        cols = hip.im2col3x3(dy2d, B, H, W, 1)
-        M, K = cols.shape
-        dx = torch.empty((M, fc.cin), device=dy2d.device, dtype=torch.float32)
-        hip.gemm(hip.NT, M, fc.cin, K, cols, K, fc.Wd, K, dx, fc.cin)
-        return dx, None, None, None, None, None
+        return hip.conv3x3(dy2d, B, H, W, fc.Wd), None, None, None, None, None
 
 
 def fconv3_g(x2d, fc: FrozenConv3, B: int, H: int, W: int, act: int = hip.ACT_RELU):

@@ -45,6 +45,9 @@ struct GemmParams {
     float alpha;
     tvlRowMap a_map, c_map;
     int tiles_m, tiles_n;
+    // implicit 3x3 / pad 1 convolution (CONV kernels): A is an NHWC pixel matrix [B*H*W, lda], the GEMM row m is the output
+    // pixel (b, oy, ox) and the GEMM column (ky*3+kx)*C + c addresses x[b, oy*stride+ky-1, ox*stride+kx-1, c] (0 outside)
+    int cH, cW, cC, cStride, cHo, cWo;
 };
 
 __device__ __forceinline__ long map_row(int r, const tvlRowMap& m) {
@@ -84,6 +87,51 @@ __device__ __forceinline__ void gload(StageRegs<ROWS, BK>& s, const float* __res
             int r = row0 + idx / F4;
             r = r < nrows ? r : nrows - 1;
             s.v[i] = load4<VEC>(base, map_row(r, map), k0 + 4 * (idx % F4), K, ld);
+        }
+    }
+}
+
+// implicit-GEMM operand load for the 3x3 conv: the im2col matrix is never materialised.  The rows a thread stages are the
+// same for every k-slab, so their (b, oy, ox) decomposition is done once (ConvRows); per slab only the tap changes.
+template <int ROWS, int BK>
+struct ConvRows {
+    static constexpr int N = StageRegs<ROWS, BK>::N;
+    long pix0[N];   // b * H * W
+    int oy[N], ox[N];
+};
+template <int ROWS, int BK>
+__device__ __forceinline__ void conv_rows_init(ConvRows<ROWS, BK>& cr, int row0, int nrows, const GemmParams& p) {
+    constexpr int F4 = BK / 4;
+#pragma unroll
+    for (int i = 0; i < ConvRows<ROWS, BK>::N; ++i) {
+        const int idx = threadIdx.x + NTHREADS * i;
+        int r = row0 + idx / F4;
+        r = r < nrows ? r : nrows - 1;
+        const int hw = p.cHo * p.cWo;
+        const int b = r / hw, rem = r - b * hw;
+        const int oy = rem / p.cWo;
+        cr.pix0[i] = (long)b * p.cH * p.cW;
+        cr.oy[i] = oy * p.cStride - 1;
+        cr.ox[i] = (rem - oy * p.cWo) * p.cStride - 1;
+    }
+}
+template <int ROWS, int BK>
+__device__ __forceinline__ void gload_conv(StageRegs<ROWS, BK>& s, const ConvRows<ROWS, BK>& cr, const GemmParams& p, int k0) {
+    constexpr int F4 = BK / 4;
+    const int kcol = k0 + 4 * (threadIdx.x % F4);  // NTHREADS % F4 == 0: the same column for every row this thread stages
+    const int tap = kcol / p.cC;
+    const int c = kcol - tap * p.cC;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const bool kok = kcol < p.K;
+#pragma unroll
+    for (int i = 0; i < StageRegs<ROWS, BK>::N; ++i) {
+        const int idx = threadIdx.x + NTHREADS * i;
+        if (StageRegs<ROWS, BK>::TOTAL % NTHREADS == 0 || idx < StageRegs<ROWS, BK>::TOTAL) {
+            const int iy = cr.oy[i] + ky, ix = cr.ox[i] + kx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW)
+                v = *reinterpret_cast<const float4*>(p.A + (cr.pix0[i] + (long)iy * p.cW + ix) * p.lda + c);
+            s.v[i] = v;
         }
     }
 }
@@ -183,7 +231,7 @@ __device__ __forceinline__ void epilogue_t(const GemmParams& p, f32x16 (&acc)[TM
     }
 }
 
-template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES>
+template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
     constexpr int LDB = BK + 8;  // bf16 elements per LDS row: 80 B (BK 32) / 48 B (BK 16), both conflict free for ds_read_b128
     constexpr int STAGE_ELEMS = S * (BM + BN) * LDB;
@@ -229,7 +277,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
     const tvlRowMap ident = {0, 0, 0};
     const int nk = (p.K + BK - 1) / BK;
 
-    gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, 0, p.K, p.a_map);
+    ConvRows<CONV ? BM : 1, BK> crows;
+    if constexpr (CONV) {
+        conv_rows_init<BM, BK>(crows, m0, p.M, p);
+        gload_conv<BM, BK>(sa, crows, p, 0);
+    } else {
+        gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, 0, p.K, p.a_map);
+    }
     gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, 0, p.K, ident);
     sstore<BM, BK, S>(sa, smem);
     sstore<BN, BK, S>(sb, smem + S * BM * LDB);
@@ -240,7 +294,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
         const __bf16* As = smem + cur * STAGE_ELEMS;
         const __bf16* Bs = As + S * BM * LDB;
         if (kt + 1 < nk) {
-            gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, p.a_map);
+            if constexpr (CONV) gload_conv<BM, BK>(sa, crows, p, (kt + 1) * BK);
+            else gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, p.a_map);
             gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, ident);
         }
         // all fragment reads of the slab are issued before its first MFMA; the compiler then waits with counted
@@ -286,14 +341,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
     epilogue_t<TM, TN, VEC>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
 }
 
-template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES>
+template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
 int launch_v(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     constexpr size_t smem = (size_t)STAGES * S * (BM + BN) * (BK + 8) * sizeof(__bf16);
     static bool attr_set = false;
-    auto kern = gemm_bf16s_kernel<BM, BN, WGM, S, VEC, BK, STAGES>;
+    auto kern = gemm_bf16s_kernel<BM, BN, WGM, S, VEC, BK, STAGES, CONV>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
@@ -313,6 +368,13 @@ int launch_tile(int bm, const GemmParams& p, hipStream_t s) {
     if (bm == 128) return launch<128, 128, 2, S, VEC>(p, s);
     if (bm == 96) return launch<96, 128, 1, S, VEC>(p, s);
     return launch<64, 64, 2, S, VEC>(p, s);
+}
+
+template <int S>
+int launch_conv_tile(int bm, const GemmParams& p, hipStream_t s) {
+    if (bm == 128) return launch_v<128, 128, 2, S, true, 32, 1, true>(p, s);
+    if (bm == 96) return launch_v<96, 128, 1, S, true, 32, 1, true>(p, s);
+    return launch_v<64, 64, 2, S, true, 32, 1, true>(p, s);
 }
 
 int choose_bm(long M, long N) {
@@ -348,6 +410,7 @@ extern "C" int tvl_gemm_bf16s(const tvlGemmArgs* a, int32_t nsplit, tvlStream_t 
     p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.act = a->act; p.pre_out = a->pre_out;
     p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha;
     p.a_map = a->a_map; p.c_map = a->c_map; p.tiles_m = p.tiles_n = 0;
+    p.cH = p.cW = p.cC = p.cStride = p.cHo = p.cWo = 0;
 
     const bool vec = tvl_aligned16(a->A) && tvl_aligned16(a->B) && (a->lda % 4 == 0) && (a->ldb % 4 == 0);
     const int bm = choose_bm(a->M, a->N);
@@ -364,5 +427,36 @@ extern "C" int tvl_gemm_bf16s(const tvlGemmArgs* a, int32_t nsplit, tvlStream_t 
     }
     TVL_REQUIRE(rc == 0, "tvl_gemm_bf16s: launch failed");
     TVL_LAUNCH_CHECK("tvl_gemm_bf16s");
+    return 0;
+}
+
+extern "C" int tvl_conv3x3_bf16s(const tvlGemmArgs* a, const tvlConvGeom* g, int32_t nsplit, tvlStream_t stream) {
+    TVL_REQUIRE(a != nullptr && g != nullptr, "tvl_conv3x3_bf16s: null args");
+    TVL_REQUIRE(nsplit >= 1 && nsplit <= 3, "tvl_conv3x3_bf16s: nsplit must be 1, 2 or 3");
+    TVL_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0 && g->C > 0 && (g->stride == 1 || g->stride == 2), "tvl_conv3x3_bf16s: bad geometry");
+    const int Ho = (g->H - 1) / g->stride + 1, Wo = (g->W - 1) / g->stride + 1;
+    TVL_REQUIRE((long)g->B * Ho * Wo == a->M && a->K == 9 * g->C && a->N > 0, "tvl_conv3x3_bf16s: M=%d K=%d do not match the geometry", a->M, a->K);
+    TVL_REQUIRE(a->A && a->B && a->C, "tvl_conv3x3_bf16s: null operand");
+    TVL_REQUIRE(g->C % 4 == 0 && a->lda % 4 == 0 && a->lda >= g->C && tvl_aligned16(a->A), "tvl_conv3x3_bf16s: needs C %% 4 == 0 and 16-byte aligned rows");
+    TVL_REQUIRE(a->ldb >= a->K && a->ldb % 4 == 0 && tvl_aligned16(a->B) && a->ldc >= a->N, "tvl_conv3x3_bf16s: bad weight / output leading dimension");
+    TVL_REQUIRE(!a->residual || a->ldr >= a->N, "tvl_conv3x3_bf16s: ldr too small");
+    TVL_REQUIRE(!a->dact || (a->dact_aux && a->ld_aux >= a->N), "tvl_conv3x3_bf16s: dact needs dact_aux");
+    TVL_REQUIRE((long)g->B * g->H * g->W * (long)a->lda < (1L << 40), "tvl_conv3x3_bf16s: map too large");
+
+    GemmParams p;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.A = a->A; p.lda = a->lda; p.B = a->B; p.ldb = a->ldb; p.C = a->C; p.ldc = a->ldc;
+    p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.act = a->act; p.pre_out = a->pre_out;
+    p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha;
+    p.a_map = tvlRowMap{0, 0, 0}; p.c_map = a->c_map; p.tiles_m = p.tiles_n = 0;
+    p.cH = g->H; p.cW = g->W; p.cC = g->C; p.cStride = g->stride; p.cHo = Ho; p.cWo = Wo;
+    const int bm = choose_bm(a->M, a->N);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    if (nsplit == 1) rc = launch_conv_tile<1>(bm, p, s);
+    else if (nsplit == 2) rc = launch_conv_tile<2>(bm, p, s);
+    else rc = launch_conv_tile<3>(bm, p, s);
+    TVL_REQUIRE(rc == 0, "tvl_conv3x3_bf16s: launch failed");
+    TVL_LAUNCH_CHECK("tvl_conv3x3_bf16s");
     return 0;
 }

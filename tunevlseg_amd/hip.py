@@ -41,6 +41,10 @@ class GemmArgs(C.Structure):
     ]
 
 
+class ConvGeom(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("stride", C.c_int32)]
+
+
 class AttnFwdArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
@@ -109,6 +113,7 @@ _SIGS = {
     "tvl_dot": [_P, _P, _P, _L, _I],
     "tvl_colsum": [_P, _P, _L, _I, _I],
     "tvl_copy2d": [_P, _I, _P, _I, _L, _I],
+    "tvl_conv3x3_bf16s": [C.POINTER(GemmArgs), C.POINTER(ConvGeom), _I],
     "tvl_im2col3x3": [_P, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
@@ -667,3 +672,31 @@ def copy2d(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
         raise RuntimeError(f"copy2d shape mismatch {tuple(src.shape)} vs {tuple(dst.shape)}")
     _call("tvl_copy2d", _ps(src), src.stride(0), _ps(dst), dst.stride(0), src.shape[0], src.shape[1])
     return dst
+
+
+def conv3x3(x2d: torch.Tensor, B: int, H: int, W: int, Wm: torch.Tensor, bias=None, act: int = ACT_NONE, stride: int = 1, out=None):
+    """3x3 / pad 1 conv of an NHWC pixel matrix with GEMM-ordered weights ``Wm`` [Cout, >=9C] (+ bias, activation).
+
+    Split-bf16 modes run it as an implicit GEMM (no im2col matrix); the exact-fp32 mode and shapes the implicit kernel does
+    not take (C % 4 != 0, tiny maps) build the im2col matrix and call the plain GEMM."""
+    Cc = x2d.shape[1]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    M, N = B * Ho * Wo, Wm.shape[0]
+    y = _out2d(out, M, N, x2d)
+    split = _NSPLIT.get(GEMM_MODE, 0)
+    if split and Cc % 4 == 0 and M >= 256 and x2d.stride(0) % 4 == 0:
+        args = GemmArgs(NT, M, N, 9 * Cc, _ps(x2d), x2d.stride(0), _p(Wm), Wm.shape[1], _ps(y), y.stride(0), _p(bias), None, 0, act,
+                        None, None, 0, ACT_NONE, 1.0, _ident(), _ident())
+        geom = ConvGeom(B, H, W, Cc, stride)
+        if _gemm_prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _call("tvl_conv3x3_bf16s", C.byref(args), C.byref(geom), split)
+        if _gemm_prof is not None:
+            e1.record()
+            _gemm_prof.append((gemm_kernel_key(NT, M, N, True, split).replace("32, 1>", "32, 1, true>"), 2.0 * M * N * 9 * Cc, e0, e1))
+        return y
+    cols = im2col3x3(x2d, B, H, W, stride)
+    K = cols.shape[1]
+    gemm(NT, M, N, K, cols, K, Wm, Wm.shape[1], y, y.stride(0), bias=bias, act=act)
+    return y
