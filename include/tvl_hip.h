@@ -34,6 +34,9 @@ typedef struct { int32_t div, mul, off; } tvlRowMap;
 
 enum { TVL_NT = 0, TVL_NN = 1, TVL_TN = 2 };
 enum { TVL_ACT_NONE = 0, TVL_ACT_QUICK_GELU = 1, TVL_ACT_RELU = 2, TVL_ACT_SIGMOID = 3 };
+/* OR into tvlGemmArgs.act: apply the activation AFTER the residual add (ResNet bottleneck tail relu(conv + identity),
+ * reference cris_model/clip.py:75); default order is act first, then residual (transformer blocks) */
+enum { TVL_ACT_POST_RESIDUAL = 0x100 };
 
 /*
  * C = epilogue(alpha * op(A) . op(B)), exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -42,7 +45,7 @@ enum { TVL_ACT_NONE = 0, TVL_ACT_QUICK_GELU = 1, TVL_ACT_RELU = 2, TVL_ACT_SIGMO
  *   layout TN: A[K,M] (lda), B[K,N] (ldb)   -> weight gradient dW = dY^T . X
  * epilogue, in this order, per element (m, n):
  *   v = alpha*acc; v += bias[n]; v *= act'(dact_aux[m,n]) (dact); pre_out[m,n] = v;
- *   v = act(v); v += residual[m,n]; C[map(m), n] = v
+ *   v = act(v); v += residual[m,n]; C[map(m), n] = v      (with TVL_ACT_POST_RESIDUAL: v += residual; v = act(v))
  * a_map remaps the rows of A as stored (the M rows for NT/NN, the K rows for TN);
  * c_map remaps rows of C / pre_out / residual / dact_aux.
  */
@@ -210,6 +213,15 @@ int tvl_im2col3x3(const float* x, int64_t sb, int64_t sy, int64_t sx, int64_t sc
  * Needs C % 4 == 0.  a_map is ignored. */
 typedef struct { int32_t B, H, W, C, stride; } tvlConvGeom;
 int tvl_conv3x3_bf16s(const tvlGemmArgs* args, const tvlConvGeom* geom, int32_t nsplit, tvlStream_t stream);
+/*
+ * The split-bf16 GEMM over PRE-SPLIT operands: x = p0 + p1 + p2 as three bf16 planes [3][rows][ldp] (ldp % 32 == 0, columns
+ * >= cols zero), made once for frozen weights and by one pass (or the producing kernel) for activations.  The GEMM then fills
+ * LDS by DMA and spends no VALU on splitting; results equal tvl_gemm_bf16s(nsplit 3) up to fp32 summation order.
+ * tvl_gemm_planes: args->A / args->B point at plane 0 of bf16 data, lda / ldb in bf16 elements; same epilogue contract as
+ * tvl_gemm_f32.  conv != NULL: implicit 3x3 / pad 1 conv over NHWC planes (args->K = 9*C, C % 8 == 0), as tvl_conv3x3_bf16s.
+ */
+int tvl_split_planes(const float* x, int32_t ldx, int64_t rows, int32_t cols, void* planes, int64_t plane_stride, int32_t ldp, tvlStream_t stream);
+int tvl_gemm_planes(const tvlGemmArgs* args, int64_t a_plane_stride, int64_t b_plane_stride, const tvlConvGeom* conv, tvlStream_t stream);
 /* nn.AvgPool2d(k) / F.avg_pool2d(x, k, k) on [B,H,W,C] (H, W divisible by k) and its gradient (H, W = input sizes) */
 int tvl_avgpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);
 int tvl_avgpool_bwd(const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);

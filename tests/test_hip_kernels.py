@@ -357,3 +357,32 @@ def test_small_reductions(hip):
     assert (t == 3.0).all()
     hip.axpby(dev(torch.ones(100)), 2.0, t, 0.5)
     assert torch.allclose(t.cpu(), torch.full((100,), 3.5))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 100), (1000, 768, 768), (4100, 2048, 96), (15840, 768, 3072), (777, 130, 36), (256, 64, 8)])
+def test_gemm_presplit_planes(hip, M, N, K):
+    """tvl_split_planes is exact (p0 + p1 + p2 == x in fp32) and tvl_gemm_planes matches the fp64 product like bf16x6 does."""
+    A, B, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    Ad, Bd = dev(A), dev(B)
+    planes = hip.split_planes(Ad)
+    back = planes[0].float() + planes[1].float() + planes[2].float()
+    assert torch.equal(back[:, :K], Ad) and (K % 32 == 0 or back[:, K:].abs().max() == 0)
+    ref = torch.relu(A.double() @ B.double().T + bias.double()) + res.double()
+    Cd = torch.empty(M, N, device="cuda")
+    old = hip.GEMM_IMPL
+    hip.GEMM_IMPL = "planes"
+    try:
+        hip.gemm(hip.NT, M, N, K, Ad, K, Bd, K, Cd, N, bias=dev(bias), act=hip.ACT_RELU, residual=dev(res), ldr=N)
+    finally:
+        hip.GEMM_IMPL = old
+    close(Cd, ref, 3e-6 * math.sqrt(K), "gemm planes")
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 25, 21632), (64, 64, 5000), (130, 25, 15488), (32, 8, 100000)])
+def test_gemm_tn_split_k(hip, M, N, K):
+    """Weight gradients with a handful of output tiles run split-K (fp32 atomics); a row map on the K rows still applies."""
+    A, B = rnd(K, M, seed=5), rnd(K, N, seed=6)
+    ref = A.double().T @ B.double()
+    Cd = torch.full((M, N), 7.0, device="cuda")  # must be overwritten, not accumulated into
+    hip.gemm(hip.TN, M, N, K, dev(A), M, dev(B), N, Cd, N)
+    close(Cd, ref, 3e-6 * math.sqrt(K), "gemm TN split-K")

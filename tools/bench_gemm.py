@@ -19,13 +19,19 @@ if len(sys.argv) > 1 and sys.argv[1] != "f32":  # split-bf16 runs data gradients
 def main():
     hip.load()
     if len(sys.argv) > 1:
-        hip.set_gemm_mode(sys.argv[1])
+        if sys.argv[1] in ("planes", "planes-only"):
+            hip.GEMM_IMPL = "planes"
+        else:
+            hip.set_gemm_mode(sys.argv[1])
     print("mode", hip.GEMM_MODE)
     torch.manual_seed(0)
     bufs = {}
     for name, layout, m, n, k in SHAPES:
         A = torch.randn(m, k, device="cuda")
         B = torch.randn(n, k, device="cuda") if layout == hip.NT else torch.randn(k, n, device="cuda")
+        hip.mark_frozen(B)
+        if len(sys.argv) > 1 and sys.argv[1] == "planes-only":  # GEMM kernel alone: A planes made once, outside the timing
+            hip.mark_frozen(A)
         C = torch.empty(m, n, device="cuda")
         bufs[name] = (A, B, C)
     rounds = 5

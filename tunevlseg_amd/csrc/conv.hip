@@ -87,54 +87,77 @@ __device__ __forceinline__ void bil_src(int dst, float inv_s, int n, int& i0, in
     i1 = i0 + (i0 < n - 1 ? 1 : 0);
     w1 = src - (float)i0;
 }
+// V = 4: one float4 of channels per thread (C, ldx, ldy multiples of 4, 16-byte aligned); V = 1: scalar
+template <int V>
+struct VecT { typedef float type; };
+template <>
+struct VecT<4> { typedef float4 type; };
+__device__ __forceinline__ float vmul(float a, float w) { return a * w; }
+__device__ __forceinline__ float4 vmul(float4 a, float w) { return make_float4(a.x * w, a.y * w, a.z * w, a.w * w); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+template <int V>
+__device__ __forceinline__ typename VecT<V>::type vzero();
+template <>
+__device__ __forceinline__ float vzero<1>() { return 0.f; }
+template <>
+__device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int V>
 __global__ void bilinear_up_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int H, int W, int C, int s) {
+    typedef typename VecT<V>::type T;
     const int Ho = H * s, Wo = W * s;
+    const int cv = C / V;
     const float inv_s = 1.0f / (float)s;
-    const long total = (long)B * Ho * Wo * C;
+    const long total = (long)B * Ho * Wo * cv;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long r = i / C;
+        const int c = (int)(i % cv) * V;
+        const long r = i / cv;
         const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), b = (int)(r / ((long)Wo * Ho));
         int y0, y1, x0, x1;
         float ly, lx;
         bil_src(oy, inv_s, H, y0, y1, ly);
         bil_src(ox, inv_s, W, x0, x1, lx);
         const float* xb = x + (long)b * H * W * ldx + c;
-        const float v00 = xb[((long)y0 * W + x0) * ldx], v01 = xb[((long)y0 * W + x1) * ldx];
-        const float v10 = xb[((long)y1 * W + x0) * ldx], v11 = xb[((long)y1 * W + x1) * ldx];
-        y[r * ldy + c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        const T v00 = *reinterpret_cast<const T*>(xb + ((long)y0 * W + x0) * ldx), v01 = *reinterpret_cast<const T*>(xb + ((long)y0 * W + x1) * ldx);
+        const T v10 = *reinterpret_cast<const T*>(xb + ((long)y1 * W + x0) * ldx), v11 = *reinterpret_cast<const T*>(xb + ((long)y1 * W + x1) * ldx);
+        const T top = vadd(vmul(v00, 1.f - lx), vmul(v01, lx)), bot = vadd(vmul(v10, 1.f - lx), vmul(v11, lx));
+        *reinterpret_cast<T*>(y + r * ldy + c) = vadd(vmul(top, 1.f - ly), vmul(bot, ly));
     }
 }
 // gather form of the transpose: input pixel i receives from the outputs whose (i0, i1) touch it
+template <int V>
 __global__ void bilinear_up_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx, int B, int H, int W, int C, int s) {
+    typedef typename VecT<V>::type T;
     const int Ho = H * s, Wo = W * s;
+    const int cv = C / V;
     const float inv_s = 1.0f / (float)s;
-    const long total = (long)B * H * W * C;
+    const long total = (long)B * H * W * cv;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long r = i / C;
+        const int c = (int)(i % cv) * V;
+        const long r = i / cv;
         const int ix = (int)(r % W), iy = (int)((r / W) % H), b = (int)(r / ((long)W * H));
         const int oy_lo = max(0, s * iy - s), oy_hi = min(Ho - 1, s * iy + 2 * s - 1);
         const int ox_lo = max(0, s * ix - s), ox_hi = min(Wo - 1, s * ix + 2 * s - 1);
         const float* db = dy + (long)b * Ho * Wo * lddy + c;
-        float acc = 0.f;
+        T acc = vzero<V>();
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
             int y0, y1;
             float ly;
             bil_src(oy, inv_s, H, y0, y1, ly);
             const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
             if (wy == 0.f) continue;
-            float row = 0.f;
+            T row = vzero<V>();
             for (int ox = ox_lo; ox <= ox_hi; ++ox) {
                 int x0, x1;
                 float lx;
                 bil_src(ox, inv_s, W, x0, x1, lx);
                 const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
-                if (wx != 0.f) row += wx * db[((long)oy * Wo + ox) * lddy];
+                if (wx != 0.f) row = vadd(row, vmul(*reinterpret_cast<const T*>(db + ((long)oy * Wo + ox) * lddy), wx));
             }
-            acc += wy * row;
+            acc = vadd(acc, vmul(row, wy));
         }
-        dx[r * lddx + c] = acc;
+        *reinterpret_cast<T*>(dx + r * lddx + c) = acc;
     }
 }
 
@@ -407,8 +430,13 @@ extern "C" int tvl_bilinear_up_fwd(const float* x, int32_t ldx, float* y, int32_
     TVL_REQUIRE(x && y, "tvl_bilinear_up_fwd: null pointer");
     TVL_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && s >= 1 && s <= 16, "tvl_bilinear_up_fwd: bad shape");
     TVL_REQUIRE(ldx >= C && ldy >= C, "tvl_bilinear_up_fwd: leading dimension too small");
-    hipLaunchKernelGGL(bilinear_up_fwd_kernel, dim3(nblk((long)B * H * s * W * s * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, y,
-                       ldy, B, H, W, C, s);
+    const bool vec = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && tvl_aligned16(x) && tvl_aligned16(y);
+    if (vec)
+        hipLaunchKernelGGL(bilinear_up_fwd_kernel<4>, dim3(nblk((long)B * H * s * W * s * (C / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                           ldx, y, ldy, B, H, W, C, s);
+    else
+        hipLaunchKernelGGL(bilinear_up_fwd_kernel<1>, dim3(nblk((long)B * H * s * W * s * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
+                           y, ldy, B, H, W, C, s);
     TVL_LAUNCH_CHECK("tvl_bilinear_up_fwd");
     return 0;
 }
@@ -417,8 +445,13 @@ extern "C" int tvl_bilinear_up_bwd(const float* dy, int32_t lddy, float* dx, int
     TVL_REQUIRE(dy && dx, "tvl_bilinear_up_bwd: null pointer");
     TVL_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && s >= 1 && s <= 16, "tvl_bilinear_up_bwd: bad shape");
     TVL_REQUIRE(lddx >= C && lddy >= C, "tvl_bilinear_up_bwd: leading dimension too small");
-    hipLaunchKernelGGL(bilinear_up_bwd_kernel, dim3(nblk((long)B * H * W * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, lddy, dx, lddx,
-                       B, H, W, C, s);
+    const bool vec = C % 4 == 0 && lddx % 4 == 0 && lddy % 4 == 0 && tvl_aligned16(dx) && tvl_aligned16(dy);
+    if (vec)
+        hipLaunchKernelGGL(bilinear_up_bwd_kernel<4>, dim3(nblk((long)B * H * W * (C / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, lddy, dx,
+                           lddx, B, H, W, C, s);
+    else
+        hipLaunchKernelGGL(bilinear_up_bwd_kernel<1>, dim3(nblk((long)B * H * W * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, lddy, dx, lddx,
+                           B, H, W, C, s);
     TVL_LAUNCH_CHECK("tvl_bilinear_up_bwd");
     return 0;
 }

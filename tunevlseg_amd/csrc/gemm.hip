@@ -41,6 +41,7 @@ struct GemmParams {
     float alpha;
     tvlRowMap a_map, c_map;
     int tiles_m, tiles_n;
+    int kchunk;  // split-K (weight gradients with a handful of output tiles): blockIdx.y owns k in [y*kchunk, (y+1)*kchunk), atomicAdd epilogue
 };
 
 __device__ __forceinline__ long map_row(int r, const tvlRowMap& m) {
@@ -163,11 +164,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     StageRegs<BN> sb;
     const tvlRowMap ident = {0, 0, 0};
 
+    const int kbeg = p.kchunk > 0 ? blockIdx.y * p.kchunk : 0;
+    const int kend = p.kchunk > 0 ? (kbeg + p.kchunk < p.K ? kbeg + p.kchunk : p.K) : p.K;
     auto gload = [&](int k0) {
-        if (A_KMAJOR) gload_kmajor<BM, VEC>(sa, p.A, p.lda, m0, p.M, k0, p.K, p.a_map);
-        else gload_mnmajor<BM, VEC>(sa, p.A, p.lda, m0, p.M, k0, p.K, p.a_map);
-        if (B_KMAJOR) gload_kmajor<BN, VEC>(sb, p.B, p.ldb, n0, p.N, k0, p.K, ident);
-        else gload_mnmajor<BN, VEC>(sb, p.B, p.ldb, n0, p.N, k0, p.K, ident);
+        if (A_KMAJOR) gload_kmajor<BM, VEC>(sa, p.A, p.lda, m0, p.M, k0, kend, p.a_map);
+        else gload_mnmajor<BM, VEC>(sa, p.A, p.lda, m0, p.M, k0, kend, p.a_map);
+        if (B_KMAJOR) gload_kmajor<BN, VEC>(sb, p.B, p.ldb, n0, p.N, k0, kend, ident);
+        else gload_mnmajor<BN, VEC>(sb, p.B, p.ldb, n0, p.N, k0, kend, ident);
     };
     auto sstore = [&](int buf) {
         float* a_dst = smem + buf * STAGE;
@@ -176,14 +179,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
         if (B_KMAJOR) sstore_kmajor<BN>(sb, b_dst); else sstore_mnmajor<BN>(sb, b_dst);
     };
 
-    const int nk = (p.K + BK - 1) / BK;
-    gload(0);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    gload(kbeg);
     sstore(0);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);  // in flight behind this slab's MFMAs
+        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);  // in flight behind this slab's MFMAs
         const float* as = smem + cur * STAGE;
         const float* bs = as + A_TILE;
 #pragma unroll
@@ -237,10 +240,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
                 if (row >= p.M) continue;
                 const long crow = map_row(row, p.c_map);
                 float v = acc[i][n][r] * p.alpha + bv;
+                if (p.kchunk > 0) {  // split-K partial: C was zeroed by the host entry
+                    atomicAdd(&p.C[crow * p.ldc + col], v);
+                    continue;
+                }
                 if (p.dact) v *= dact_f(p.dact_aux[crow * p.ld_aux + col], p.dact);
                 if (p.pre_out) p.pre_out[crow * p.ldc + col] = v;
-                v = act_f(v, p.act);
-                if (p.residual) v += p.residual[crow * p.ldr + col];
+                if (p.act & TVL_ACT_POST_RESIDUAL) {
+                    if (p.residual) v += p.residual[crow * p.ldr + col];
+                    v = act_f(v, p.act & 0xff);
+                } else {
+                    v = act_f(v, p.act);
+                    if (p.residual) v += p.residual[crow * p.ldr + col];
+                }
                 p.C[crow * p.ldc + col] = v;
             }
         }
@@ -262,7 +274,8 @@ int launch(const GemmParams& p0, hipStream_t s) {
         attr_set = true;
     }
     const long nwg = (long)p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NTHREADS), smem, s, p);
+    const int splits = p.kchunk > 0 ? (p.K + p.kchunk - 1) / p.kchunk : 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)splits), dim3(NTHREADS), smem, s, p);
     return 0;
 }
 
@@ -318,10 +331,26 @@ extern "C" int tvl_gemm_f32(const tvlGemmArgs* a, tvlStream_t stream) {
     p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.act = a->act; p.pre_out = a->pre_out;
     p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha;
     p.a_map = a->a_map; p.c_map = a->c_map; p.tiles_m = p.tiles_n = 0;
+    p.kchunk = 0;
 
     const bool vec = tvl_aligned16(a->A) && tvl_aligned16(a->B) && (a->lda % 4 == 0) && (a->ldb % 4 == 0);
     const TileChoice tc = choose_tile(a->layout, a->M, a->N);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // weight gradients of the small trainable layers: a few output tiles but a reduction over every pixel/token of the batch.
+    // One workgroup per tile would walk K alone; split K over the grid and combine with fp32 atomics (sum order varies).
+    {
+        const long tiles = (long)((a->M + tc.bm - 1) / tc.bm) * ((a->N + tc.bn - 1) / tc.bn);
+        const bool plain = !a->bias && !a->residual && !a->pre_out && !a->dact && a->act == TVL_ACT_NONE && a->c_map.div <= 0 && a->ldc == a->N;
+        if (a->layout == TVL_TN && plain && tiles <= 16 && a->K >= 4096) {
+            int splits = (int)(512 / tiles);
+            const int max_by_k = a->K / 512;
+            splits = splits < max_by_k ? splits : max_by_k;
+            if (splits > 1) {
+                p.kchunk = ((a->K + splits - 1) / splits + BK - 1) / BK * BK;
+                TVL_REQUIRE(hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N, s) == hipSuccess, "tvl_gemm_f32: memset failed");
+            }
+        }
+    }
     int rc;
     if (tc.bm == 128) rc = vec ? launch_layout<128, 128, 2, true>(a->layout, p, s) : launch_layout<128, 128, 2, false>(a->layout, p, s);
     else if (tc.bm == 96) rc = vec ? launch_layout<96, 128, 1, true>(a->layout, p, s) : launch_layout<96, 128, 1, false>(a->layout, p, s);

@@ -206,11 +206,18 @@ __device__ __forceinline__ void epilogue_t(const GemmParams& p, f32x16 (&acc)[TM
                         v[0] *= dact_f(z4.x, p.dact); v[1] *= dact_f(z4.y, p.dact); v[2] *= dact_f(z4.z, p.dact); v[3] *= dact_f(z4.w, p.dact);
                     }
                     if (p.pre_out) *reinterpret_cast<float4*>(p.pre_out + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    const bool post = (p.act & TVL_ACT_POST_RESIDUAL) != 0;
+                    if (!post) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+                        for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+                    }
                     if (p.residual) {
                         const float4 r4 = *reinterpret_cast<const float4*>(p.residual + crow * p.ldr + col);
                         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                    }
+                    if (post) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act & 0xff);
                     }
                     *reinterpret_cast<float4*>(p.C + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
@@ -221,8 +228,13 @@ __device__ __forceinline__ void epilogue_t(const GemmParams& p, f32x16 (&acc)[TM
                         float x = v[e] + (p.bias ? p.bias[c] : 0.f);
                         if (p.dact) x *= dact_f(p.dact_aux[crow * p.ld_aux + c], p.dact);
                         if (p.pre_out) p.pre_out[crow * p.ldc + c] = x;
-                        x = act_f(x, p.act);
-                        if (p.residual) x += p.residual[crow * p.ldr + c];
+                        if (p.act & TVL_ACT_POST_RESIDUAL) {
+                            if (p.residual) x += p.residual[crow * p.ldr + c];
+                            x = act_f(x, p.act & 0xff);
+                        } else {
+                            x = act_f(x, p.act);
+                            if (p.residual) x += p.residual[crow * p.ldr + c];
+                        }
                         p.C[crow * p.ldc + c] = x;
                     }
                 }

@@ -5,9 +5,9 @@
 
 namespace {
 
-constexpr int LN_MAXV = 4;  // float4 per lane held in registers -> cols <= 1024 on the fast path
+// LN_MAXV float4 per lane held in registers: 4 -> cols <= 1024, 8 -> cols <= 2048 (the CRIS decoder's LayerNorm(2048))
 
-template <bool VEC>
+template <bool VEC, int LN_MAXV = 4>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma, xhat = (x-mean)*rstd ; [+ dres]
-template <bool VEC>
+template <bool VEC, int LN_MAXV = 4>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ dres,
@@ -161,11 +161,12 @@ extern "C" int tvl_layernorm_fwd(const float* x, const float* gamma, const float
                                  int64_t rows, int32_t cols, float eps, tvlStream_t stream) {
     TVL_REQUIRE(x && gamma && y, "tvl_layernorm_fwd: null pointer");
     TVL_REQUIRE(rows > 0 && cols > 0, "tvl_layernorm_fwd: bad shape rows=%ld cols=%d", (long)rows, cols);
-    const bool vec = (cols % 4 == 0) && cols <= 256 * LN_MAXV && tvl_aligned16(x) && tvl_aligned16(y) && tvl_aligned16(gamma) &&
+    const bool vec = (cols % 4 == 0) && cols <= 256 * 8 && tvl_aligned16(x) && tvl_aligned16(y) && tvl_aligned16(gamma) &&
                      (!beta || tvl_aligned16(beta));
     const unsigned grid = (unsigned)((rows + 3) / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (vec) hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, (long)rows, cols, eps);
+    if (vec && cols <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<true, 4>), dim3(grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, (long)rows, cols, eps);
+    else if (vec) hipLaunchKernelGGL((ln_fwd_kernel<true, 8>), dim3(grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, (long)rows, cols, eps);
     else hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, (long)rows, cols, eps);
     TVL_LAUNCH_CHECK("tvl_layernorm_fwd");
     return 0;
@@ -176,11 +177,12 @@ extern "C" int tvl_layernorm_bwd(const float* dy, const float* x, const float* g
                                  tvlStream_t stream) {
     TVL_REQUIRE(dy && x && gamma && mean && rstd && dx, "tvl_layernorm_bwd: null pointer");
     TVL_REQUIRE(rows > 0 && cols > 0, "tvl_layernorm_bwd: bad shape rows=%ld cols=%d", (long)rows, cols);
-    const bool vec = (cols % 4 == 0) && cols <= 256 * LN_MAXV && tvl_aligned16(x) && tvl_aligned16(dy) && tvl_aligned16(dx) &&
+    const bool vec = (cols % 4 == 0) && cols <= 256 * 8 && tvl_aligned16(x) && tvl_aligned16(dy) && tvl_aligned16(dx) &&
                      tvl_aligned16(gamma) && (!dres || tvl_aligned16(dres));
     const unsigned grid = (unsigned)((rows + 3) / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (vec) hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, cols);
+    if (vec && cols <= 1024) hipLaunchKernelGGL((ln_bwd_kernel<true, 4>), dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, cols);
+    else if (vec) hipLaunchKernelGGL((ln_bwd_kernel<true, 8>), dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, cols);
     else hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, cols);
     TVL_LAUNCH_CHECK("tvl_layernorm_bwd");
     return 0;

@@ -119,8 +119,7 @@ class COOPCRIS(nn.Module):
                     H, W = H // blk["stride"], W // blk["stride"]
                 if blk["down"] is not None:
                     idt = C.flinear(idt, blk["down"])
-                o = C.flinear(o, blk["c3"], NONE, residual=idt)
-                x = hip.bias_act(o, None, RELU)
+                x = C.flinear(o, blk["c3"], RELU | hip.ACT_POST_RESIDUAL, residual=idt)  # relu(bn3(conv3) + identity)
                 if blk["stage_end"]:
                     feats.append((x, H, W))
             # attention pool that keeps the map (clip.py:148-182)
@@ -132,8 +131,7 @@ class COOPCRIS(nn.Module):
             qkv = C.flinear(xp, ap["qkv"])
             heads = self.config.vision_heads
             o, _ = hip.attn_fwd_packed(qkv, B, H4 * W4, heads, E // heads, (E // heads) ** -0.5, want_lse=False)
-            o = C.flinear(o, ap["c_proj"], NONE, residual=res)
-            x5 = hip.bias_act(o, None, RELU)
+            x5 = C.flinear(o, ap["c_proj"], RELU | hip.ACT_POST_RESIDUAL, residual=res)
         return feats[1], feats[2], (x5, H4, W4)
 
     # ------------------------------------------------------------------ CLIP text tower with prompts (coop_cris.py:115-183)
