@@ -50,7 +50,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 }
 
 // epilogue of a transposed-product accumulator tile: lane -> row l31, registers 4g..4g+3 -> columns 8g+4h .. 8g+4h+3
-template <int TM, int TN>
+template <int TM, int TN, bool POST>
 __device__ __forceinline__ void epilogue_t(const PlaneParams& p, f32x16 (&acc)[TM][TN], int row_base, int col_base, int l31, int h) {
     const bool vec_c = (p.ldc % 4 == 0) && tvl_dev_aligned16(p.C) && (!p.pre_out || tvl_dev_aligned16(p.pre_out)) &&
                        (!p.residual || (p.ldr % 4 == 0 && tvl_dev_aligned16(p.residual))) &&
@@ -78,18 +78,15 @@ __device__ __forceinline__ void epilogue_t(const PlaneParams& p, f32x16 (&acc)[T
                         v[0] *= dact_f(z4.x, p.dact); v[1] *= dact_f(z4.y, p.dact); v[2] *= dact_f(z4.z, p.dact); v[3] *= dact_f(z4.w, p.dact);
                     }
                     if (p.pre_out) *reinterpret_cast<float4*>(p.pre_out + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                    const bool post = (p.act & TVL_ACT_POST_RESIDUAL) != 0;
-                    if (!post) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
-                    }
-                    if (p.residual) {
+                    if (POST && p.residual) {
                         const float4 r4 = *reinterpret_cast<const float4*>(p.residual + crow * p.ldr + col);
                         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
                     }
-                    if (post) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act & 0xff);
+                    for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act & 0xff);
+                    if (!POST && p.residual) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + crow * p.ldr + col);
+                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
                     }
                     *reinterpret_cast<float4*>(p.C + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
@@ -100,13 +97,9 @@ __device__ __forceinline__ void epilogue_t(const PlaneParams& p, f32x16 (&acc)[T
                         float x = v[e] + (p.bias ? p.bias[c] : 0.f);
                         if (p.dact) x *= dact_f(p.dact_aux[crow * p.ld_aux + c], p.dact);
                         if (p.pre_out) p.pre_out[crow * p.ldc + c] = x;
-                        if (p.act & TVL_ACT_POST_RESIDUAL) {
-                            if (p.residual) x += p.residual[crow * p.ldr + c];
-                            x = act_f(x, p.act & 0xff);
-                        } else {
-                            x = act_f(x, p.act);
-                            if (p.residual) x += p.residual[crow * p.ldr + c];
-                        }
+                        if (POST && p.residual) x += p.residual[crow * p.ldr + c];
+                        x = act_f(x, p.act & 0xff);
+                        if (!POST && p.residual) x += p.residual[crow * p.ldr + c];
                         p.C[crow * p.ldc + c] = x;
                     }
                 }
@@ -264,7 +257,8 @@ __global__ __launch_bounds__(NT_) void gemm_planes_kernel(PlaneParams p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j][sb_], af[ks][i][sa_], acc[i][j], 0, 0, 0);
                 }
     }
-    epilogue_t<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
+    if (p.act & TVL_ACT_POST_RESIDUAL) epilogue_t<TM, TN, true>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
+    else epilogue_t<TM, TN, false>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
 }
 
 template <int BM, int BN, int WGM, bool CONV>
