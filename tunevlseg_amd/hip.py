@@ -244,7 +244,7 @@ def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True, split: int = 
         if best is None or cost < best:
             best, tile = cost, (bm, bn, wgm)
     if split:
-        return f"gemm_bf16s_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {split}, {'true' if vec else 'false'}, 32, 1>"
+        return f"gemm_bf16s_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {split}, {'true' if vec else 'false'}, 32, 1, false>"
     ak, bk = {NT: ("true", "true"), NN: ("true", "false"), TN: ("false", "false")}[layout]
     return f"gemm_f32_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {ak}, {bk}, {'true' if vec else 'false'}>"
 
@@ -746,7 +746,7 @@ def conv3x3(x2d: torch.Tensor, B: int, H: int, W: int, Wm: torch.Tensor, bias=No
         _call("tvl_conv3x3_bf16s", C.byref(args), C.byref(geom), split)
         if _gemm_prof is not None:
             e1.record()
-            _gemm_prof.append((gemm_kernel_key(NT, M, N, True, split).replace("32, 1>", "32, 1, true>"), 2.0 * M * N * 9 * Cc, e0, e1))
+            _gemm_prof.append((gemm_kernel_key(NT, M, N, True, split).replace("32, 1, false>", "32, 1, true>"), 2.0 * M * N * 9 * Cc, e0, e1))
         return y
     cols = im2col3x3(x2d, B, H, W, stride)
     K = cols.shape[1]
