@@ -54,7 +54,7 @@ def main():
         if not name.startswith("sq"):
             tot_f += fl
             tot_t += t
-        print(f"{name} M={m} N={n} K={k}: {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TF/s  {hip.gemm_kernel_key(layout, m, n, True, hip._NSPLIT.get(hip.GEMM_MODE, 0))}")
+        print(f"{name} M={m} N={n} K={k}: {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TF/s  {hip.gemm_kernel_key(layout, m, n, True, hip._NSPLIT.get(hip.GEMM_MODE, 0), k)}")
     print(f"layer GEMMs total: {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TF/s")
 
 

@@ -236,8 +236,8 @@ __device__ __forceinline__ void epilogue_t(const GemmParams& p, f32x16 (&acc)[TM
     }
 }
 
-template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
+template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV>
+__device__ __forceinline__ void gemm_bf16s_body(const GemmParams& p) {
     constexpr int LDB = BK + 8;  // bf16 elements per LDS row: 80 B (BK 32) / 48 B (BK 16), both conflict free for ds_read_b128
     constexpr int STAGE_ELEMS = S * (BM + BN) * LDB;
     constexpr int WGN = 4 / WGM;
@@ -303,37 +303,69 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
             else gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, p.a_map);
             gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, ident);
         }
-        // all fragment reads of the slab are issued before its first MFMA; the compiler then waits with counted
-        // lgkmcnt(N) so the later reads land underneath the earlier MFMAs
-        bf16x8 af[BK / 16][TM][S], bf[BK / 16][TN][S];
+        if constexpr (TM * TN <= 4) {
+            // all fragment reads of the slab are issued before its first MFMA; the compiler then waits with counted
+            // lgkmcnt(N) so the later reads land underneath the earlier MFMAs
+            bf16x8 af[BK / 16][TM][S], bf[BK / 16][TN][S];
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+            for (int ks = 0; ks < BK / 16; ++ks) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int s = 0; s < S; ++s)
-                    af[ks][i][s] = *reinterpret_cast<const bf16x8*>(&As[(s * BM + wm * WM + i * 32 + l31) * LDB + ks * 16 + 8 * h]);
+                    for (int s = 0; s < S; ++s)
+                        af[ks][i][s] = *reinterpret_cast<const bf16x8*>(&As[(s * BM + wm * WM + i * 32 + l31) * LDB + ks * 16 + 8 * h]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int s = 0; s < S; ++s)
-                    bf[ks][j][s] = *reinterpret_cast<const bf16x8*>(&Bs[(s * BN + wn * WN + j * 32 + l31) * LDB + ks * 16 + 8 * h]);
-        }
+                    for (int s = 0; s < S; ++s)
+                        bf[ks][j][s] = *reinterpret_cast<const bf16x8*>(&Bs[(s * BN + wn * WN + j * 32 + l31) * LDB + ks * 16 + 8 * h]);
+            }
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            // smallest-magnitude piece pairs first, the a1*b1 term last; mfma(b, a) = transposed product, so that a lane's
-            // 4 consecutive accumulator registers are 4 consecutive COLUMNS of one row of C (16-byte epilogue accesses)
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                // smallest-magnitude piece pairs first, the a1*b1 term last; mfma(b, a) = transposed product, so that a lane's
+                // 4 consecutive accumulator registers are 4 consecutive COLUMNS of one row of C (16-byte epilogue accesses)
 #pragma unroll
-            for (int order = S - 1; order >= 0; --order)
+                for (int order = S - 1; order >= 0; --order)
 #pragma unroll
-                for (int sa_ = 0; sa_ <= order; ++sa_) {
-                    const int sb_ = order - sa_;
+                    for (int sa_ = 0; sa_ <= order; ++sa_) {
+                        const int sb_ = order - sa_;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j][sb_], af[ks][i][sa_], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+            // large wave tiles (96x64): fragments of one 16-deep k-step at a time, or the slab's fragments alone would take
+            // 120 VGPRs next to the 96 accumulator registers.  Piece pairs from a table (rectangular loops unroll reliably).
+            constexpr int NPAIR = S * (S + 1) / 2;
+            constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB3[6] = {2, 1, 0, 1, 0, 0};  // S = 3: (0,2) (1,1) (2,0) (0,1) (1,0) (0,0)
+            constexpr int PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};                    // S = 2: (0,1) (1,0) (0,0)
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 af[TM][S], bf[TN][S];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        af[i][s] = *reinterpret_cast<const bf16x8*>(&As[(s * BM + wm * WM + i * 32 + l31) * LDB + ks * 16 + 8 * h]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        bf[j][s] = *reinterpret_cast<const bf16x8*>(&Bs[(s * BN + wn * WN + j * 32 + l31) * LDB + ks * 16 + 8 * h]);
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q) {
+                    const int sa_ = S == 3 ? PA[q] : (S == 2 ? PA2[q] : 0);
+                    const int sb_ = S == 3 ? PB3[q] : (S == 2 ? PB2[q] : 0);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j][sb_], af[ks][i][sa_], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][sb_], af[i][sa_], acc[i][j], 0, 0, 0);
                 }
+            }
         }
         if (STAGES == 1) __syncthreads();  // every wave is done reading this slab before it is overwritten
         if (kt + 1 < nk) {
@@ -349,13 +381,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
 }
 
 template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
+    gemm_bf16s_body<BM, BN, WGM, S, VEC, BK, STAGES, CONV>(p);
+}
+// one wave per SIMD (up to 512 registers per lane): for wave tiles whose accumulators + fragments + staging exceed 256
+template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16s_kernel_w1(GemmParams p) {
+    gemm_bf16s_body<BM, BN, WGM, S, VEC, BK, STAGES, CONV>(p);
+}
+
+template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
 int launch_v(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     constexpr size_t smem = (size_t)STAGES * S * (BM + BN) * (BK + 8) * sizeof(__bf16);
     static bool attr_set = false;
-    auto kern = gemm_bf16s_kernel<BM, BN, WGM, S, VEC, BK, STAGES, CONV>;
+    void (*kern)(GemmParams) = gemm_bf16s_kernel<BM, BN, WGM, S, VEC, BK, STAGES, CONV>;
+    if constexpr (BM * BN > 128 * 128) {
+        static const int w1 = getenv("TVL_GEMM_W1") ? atoi(getenv("TVL_GEMM_W1")) : 0;  // experiment: one wave per SIMD
+        if (w1) kern = gemm_bf16s_kernel_w1<BM, BN, WGM, S, VEC, BK, STAGES, CONV>;
+    }
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
@@ -372,6 +418,7 @@ int launch(const GemmParams& p, hipStream_t s) {
 
 template <int S, bool VEC>
 int launch_tile(int bm, const GemmParams& p, hipStream_t s) {
+    if (bm == 192) return launch<192, 128, 2, S, VEC>(p, s);
     if (bm == 128) return launch<128, 128, 2, S, VEC>(p, s);
     if (bm == 96) return launch<96, 128, 1, S, VEC>(p, s);
     return launch<64, 64, 2, S, VEC>(p, s);
@@ -380,22 +427,33 @@ int launch_tile(int bm, const GemmParams& p, hipStream_t s) {
 template <int S>
 int launch_conv_tile(int bm, const GemmParams& p, hipStream_t s) {
     if (bm == 128) return launch_v<128, 128, 2, S, true, 32, 1, true>(p, s);
+    if (bm == 192) return launch_v<192, 128, 2, S, true, 32, 1, true>(p, s);
     if (bm == 96) return launch_v<96, 128, 1, S, true, 32, 1, true>(p, s);
     return launch_v<64, 64, 2, S, true, 32, 1, true>(p, s);
 }
 
-int choose_bm(long M, long N) {
+int choose_bm(long M, long N, long K) {
     const long cus = 256;
-    struct Cand { int bm, bn, per_cu; } cands[3] = {{128, 128, 2}, {96, 128, 2}, {64, 64, 4}};
-    double best = 1e300;
+    // 192x128 (wave tile 96x64) moves the fewest operand bytes per FLOP from L2 (the measured bound of this kernel: operand
+    // loads alone take half its run time) and reads the fewest LDS bytes per MFMA: it replaces 96x128 outright (+19 % on the
+    // K = 3072 shapes) and beats 128x128 except on short-K problems, where the bigger prologue / epilogue shows;
+    // TVL_GEMM_TILE192=0 disables it
+    static const int use192 = getenv("TVL_GEMM_TILE192") ? atoi(getenv("TVL_GEMM_TILE192")) : 1;
+    struct Cand { int bm, bn, per_cu; double w; } cands[4] = {{192, 128, 2, 0.93}, {128, 128, 2, 1.0}, {96, 128, 2, 1.0}, {64, 64, 4, 1.12}};
+    double best = 1e300, raw[4] = {0, 0, 0, 0};
     int out = 64;
-    for (const Cand& c : cands) {
+    for (int ci = 0; ci < 4; ++ci) {
+        const Cand& c = cands[ci];
+        if (c.bm == 192 && !use192) continue;
+        if (c.bm == 96 && use192) continue;
         const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
         const long slots = cus * c.per_cu;
         const long rounds = (tiles + slots - 1) / slots;
-        const double cost = (double)rounds * c.per_cu * c.bm * c.bn * (c.bm == 64 ? 1.12 : 1.0);
+        raw[ci] = (double)rounds * c.per_cu * c.bm * c.bn;
+        const double cost = raw[ci] * c.w;
         if (cost < best) { best = cost; out = c.bm; }
     }
+    if (out == 192 && K < 1536 && raw[1] <= raw[0]) out = 128;
     return out;
 }
 
@@ -420,7 +478,7 @@ extern "C" int tvl_gemm_bf16s(const tvlGemmArgs* a, int32_t nsplit, tvlStream_t 
     p.cH = p.cW = p.cC = p.cStride = p.cHo = p.cWo = 0;
 
     const bool vec = tvl_aligned16(a->A) && tvl_aligned16(a->B) && (a->lda % 4 == 0) && (a->ldb % 4 == 0);
-    const int bm = choose_bm(a->M, a->N);
+    const int bm = choose_bm(a->M, a->N, a->K);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc = 1;
     if (vec) {
@@ -457,7 +515,7 @@ extern "C" int tvl_conv3x3_bf16s(const tvlGemmArgs* a, const tvlConvGeom* g, int
     p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha;
     p.a_map = tvlRowMap{0, 0, 0}; p.c_map = a->c_map; p.tiles_m = p.tiles_n = 0;
     p.cH = g->H; p.cW = g->W; p.cC = g->C; p.cStride = g->stride; p.cHo = Ho; p.cWo = Wo;
-    const int bm = choose_bm(a->M, a->N);
+    const int bm = choose_bm(a->M, a->N, a->K);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (nsplit == 1) rc = launch_conv_tile<1>(bm, p, s);

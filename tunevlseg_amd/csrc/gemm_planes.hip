@@ -12,6 +12,7 @@
 // LDS image per operand plane: [rows][32 bf16] = 64-byte rows, unpadded (an LDS-DMA instruction writes 1 KiB = 16 rows
 // contiguously); bank conflicts are avoided by an XOR swizzle of the four 16-byte chunks of a row, applied on the SOURCE
 // address of the DMA and on the ds_read address:  chunk c of row r lives at slot c ^ ((r >> 2) & 3).
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -181,8 +182,9 @@ __device__ __forceinline__ void fill(const Filler<BM, BN, CONV>& f, const PlaneP
     }
 }
 
-template <int BM, int BN, int WGM, bool CONV>
+template <int BM, int BN, int WGM, bool CONV, int NSTAGE = 1>
 __global__ __launch_bounds__(NT_) void gemm_planes_kernel(PlaneParams p) {
+    constexpr int STAGE_BYTES = 3 * (BM + BN) * 64;
     constexpr int WGN = 4 / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -227,7 +229,9 @@ __global__ __launch_bounds__(NT_) void gemm_planes_kernel(PlaneParams p) {
     const unsigned char* b_base = smem + 3 * BM * 64 + (wn * WN + l31) * 64;
 
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();  // vmcnt(0) + barrier: slab kt has landed for every wave
+        __syncthreads();  // vmcnt(0) + barrier: slab kt has landed for every wave (and, NSTAGE 2, the other stage is free)
+        const int cur = NSTAGE == 2 ? (kt & 1) * STAGE_BYTES : 0;
+        if (NSTAGE == 2 && kt + 1 < nk) fill<BM, BN, CONV>(filler, p, smem + (STAGE_BYTES - cur), wave, (kt + 1) * BK);
         bf16x8 af[2][TM][3], bf[2][TN][3];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -235,14 +239,16 @@ __global__ __launch_bounds__(NT_) void gemm_planes_kernel(PlaneParams p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int s = 0; s < 3; ++s) af[ks][i][s] = *reinterpret_cast<const bf16x8*>(a_base + (s * BM + i * 32) * 64 + slot);
+                for (int s = 0; s < 3; ++s) af[ks][i][s] = *reinterpret_cast<const bf16x8*>(a_base + cur + (s * BM + i * 32) * 64 + slot);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int s = 0; s < 3; ++s) bf[ks][j][s] = *reinterpret_cast<const bf16x8*>(b_base + (s * BN + j * 32) * 64 + slot);
+                for (int s = 0; s < 3; ++s) bf[ks][j][s] = *reinterpret_cast<const bf16x8*>(b_base + cur + (s * BN + j * 32) * 64 + slot);
         }
-        __syncthreads();  // every wave holds its fragments: the slab may be overwritten
-        if (kt + 1 < nk) fill<BM, BN, CONV>(filler, p, smem, wave, (kt + 1) * BK);
+        if (NSTAGE == 1) {
+            __syncthreads();  // every wave holds its fragments: the slab may be overwritten
+            if (kt + 1 < nk) fill<BM, BN, CONV>(filler, p, smem, wave, (kt + 1) * BK);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -261,14 +267,14 @@ __global__ __launch_bounds__(NT_) void gemm_planes_kernel(PlaneParams p) {
     else epilogue_t<TM, TN, false>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
 }
 
-template <int BM, int BN, int WGM, bool CONV>
+template <int BM, int BN, int WGM, bool CONV, int NSTAGE = 1>
 int launch(const PlaneParams& p0, hipStream_t s) {
     PlaneParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    constexpr size_t smem = (size_t)3 * (BM + BN) * 64;
+    constexpr size_t smem = (size_t)NSTAGE * 3 * (BM + BN) * 64;
     static bool attr_set = false;
-    auto kern = gemm_planes_kernel<BM, BN, WGM, CONV>;
+    auto kern = gemm_planes_kernel<BM, BN, WGM, CONV, NSTAGE>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
@@ -294,6 +300,11 @@ int choose_bm(long M, long N) {
 
 template <bool CONV>
 int launch_tile(int bm, const PlaneParams& p, hipStream_t s) {
+    static const int two_stage = getenv("TVL_PLANES_2STAGE") ? atoi(getenv("TVL_PLANES_2STAGE")) : 0;  // experiment switch
+    if (two_stage && !CONV) {
+        if (bm == 128) return launch<128, 128, 2, false, 2>(p, s);
+        if (bm == 96) return launch<96, 128, 1, false, 2>(p, s);
+    }
     if (bm == 128) return launch<128, 128, 2, CONV>(p, s);
     if (bm == 96) return launch<96, 128, 1, CONV>(p, s);
     return launch<64, 64, 2, CONV>(p, s);

@@ -232,8 +232,28 @@ def gemm_profile_stop() -> dict:
     return out
 
 
-def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True, split: int = 0) -> str:
-    """Name of the template instantiation ``tvl_gemm_f32`` picks (same rule as csrc/gemm.hip)."""
+def _bf16s_tile(M: int, N: int, K: int) -> tuple[int, int, int]:
+    """Tile the split-bf16 GEMM picks (same rule as csrc/gemm_bf16s.hip choose_bm)."""
+    use192 = int(os.environ.get("TVL_GEMM_TILE192", "1"))
+    cands = ((192, 128, 2, 2, 0.93), (128, 128, 2, 2, 1.0), (96, 128, 2, 1, 1.0), (64, 64, 4, 2, 1.12))
+    best, tile, raw = None, (64, 64, 2), {}
+    for bm, bn, per_cu, wgm, w in cands:
+        if (bm == 192 and not use192) or (bm == 96 and use192):
+            continue
+        tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+        raw[bm] = ((tiles + 256 * per_cu - 1) // (256 * per_cu)) * per_cu * bm * bn
+        if best is None or raw[bm] * w < best:
+            best, tile = raw[bm] * w, (bm, bn, wgm)
+    if tile[0] == 192 and K < 1536 and raw[128] <= raw[192]:
+        tile = (128, 128, 2)
+    return tile
+
+
+def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True, split: int = 0, K: int = 1 << 20) -> str:
+    """Name of the template instantiation the GEMM entry points pick (same rules as csrc/gemm.hip / gemm_bf16s.hip)."""
+    if split:
+        tile = _bf16s_tile(M, N, K)
+        return f"gemm_bf16s_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {split}, {'true' if vec else 'false'}, 32, 1, false>"
     best, tile = None, (64, 64, 2)
     for bm, bn, per_cu, wgm in ((128, 128, 2, 2), (96, 128, 2, 1), (64, 64, 4, 2)):
         if bm == 96 and layout == TN:
@@ -243,8 +263,6 @@ def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True, split: int = 
         cost = ((tiles + slots - 1) // slots) * per_cu * bm * bn * (1.12 if bm == 64 else 1.0)
         if best is None or cost < best:
             best, tile = cost, (bm, bn, wgm)
-    if split:
-        return f"gemm_bf16s_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {split}, {'true' if vec else 'false'}, 32, 1, false>"
     ak, bk = {NT: ("true", "true"), NN: ("true", "false"), TN: ("false", "false")}[layout]
     return f"gemm_f32_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {ak}, {bk}, {'true' if vec else 'false'}>"
 
@@ -295,7 +313,7 @@ def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias
     if _gemm_prof is not None:
         e1.record()
         vec = lda % 4 == 0 and ldb % 4 == 0
-        _gemm_prof.append((gemm_kernel_key(layout, M, N, vec, split), 2.0 * M * N * K, e0, e1))
+        _gemm_prof.append((gemm_kernel_key(layout, M, N, vec, split, K), 2.0 * M * N * K, e0, e1))
     return Cout
 
 
@@ -746,7 +764,7 @@ def conv3x3(x2d: torch.Tensor, B: int, H: int, W: int, Wm: torch.Tensor, bias=No
         _call("tvl_conv3x3_bf16s", C.byref(args), C.byref(geom), split)
         if _gemm_prof is not None:
             e1.record()
-            _gemm_prof.append((gemm_kernel_key(NT, M, N, True, split).replace("32, 1, false>", "32, 1, true>"), 2.0 * M * N * 9 * Cc, e0, e1))
+            _gemm_prof.append((gemm_kernel_key(NT, M, N, True, split, 9 * Cc).replace("32, 1, false>", "32, 1, true>"), 2.0 * M * N * 9 * Cc, e0, e1))
         return y
     cols = im2col3x3(x2d, B, H, W, stride)
     K = cols.shape[1]
