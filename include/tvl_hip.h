@@ -233,6 +233,9 @@ int tvl_bilinear_up_bwd(const float* dy, int32_t lddy, float* dx, int32_t lddx, 
 int tvl_bicubic_ac_fwd(const float* x, float* y, const float* extra, float a, float r, int32_t B, int32_t Hi, int32_t Wi,
                        int32_t Ho, int32_t Wo, tvlStream_t stream);
 int tvl_bicubic_ac_bwd(const float* dy, float a, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, tvlStream_t stream);
+/* predict tail (reference src/utils/save_utils.py:93-101): one probability map [Hi,Wi] -> TF.resize(size=(Ho,Wo), BICUBIC,
+ * antialias=False) (= F.interpolate bicubic, align_corners=False) -> save_image's uint8(clamp(v*255 + 0.5, 0, 255)) */
+int tvl_bicubic_resize_u8(const float* x, uint8_t* out, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, tvlStream_t stream);
 /* Projector tail (layers.py:106-118): out[b,y,x] = word[b,9C] + sum_{c,ky,kx} word[b, c*9+ky*3+kx] * x[b, y+ky-1, x+kx-1, c]
  * (a grouped conv with one 3x3xC kernel per sample).  taps: workspace [B*H*W, 9]. */
 int tvl_dynconv_fwd(const float* x, int32_t ldx, const float* word, int32_t ldw, float* taps, float* out,

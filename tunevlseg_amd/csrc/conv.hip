@@ -235,6 +235,34 @@ __global__ void bicubic_ac_bwd_kernel(const float* __restrict__ dy, float a, flo
     }
 }
 
+// ---- predict tail: probability map -> bicubic resize (align_corners=False, no antialias) -> 8-bit grey level -----------------
+// TF.resize(pred, mask_shape, BICUBIC, antialias=False) then torchvision.utils.save_image's x*255 + 0.5, clamp, uint8
+// (reference src/utils/save_utils.py:93-101)
+__global__ void bicubic_resize_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int Hi, int Wi, int Ho, int Wo,
+                                         float sy, float sx) {
+    const long total = (long)Ho * Wo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo), oy = (int)(i / Wo);
+        const float fy = sy * ((float)oy + 0.5f) - 0.5f, fx = sx * ((float)ox + 0.5f) - 0.5f;
+        const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+        float wy[4], wx[4];
+        cubic_coeffs(fy - (float)iy, wy);
+        cubic_coeffs(fx - (float)ix, wx);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* row = x + (long)clampi(iy - 1 + j, 0, Hi - 1) * Wi;
+            float rv = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rv += wx[k] * row[clampi(ix - 1 + k, 0, Wi - 1)];
+            acc += wy[j] * rv;
+        }
+        float v = acc * 255.f + 0.5f;
+        v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+        out[i] = (unsigned char)v;
+    }
+}
+
 // ---- Projector tail: per-sample 3x3 conv C -> 1 whose kernel + bias come from the text state --------------------------------
 // word[b, c*9 + t] = weight of channel c, tap t = ky*3+kx; word[b, 9C] = bias  (layers.py:106-118)
 // forward: taps[b,p,t] = sum_c x[b,p,c] * w[b,c,t]   then   out[b,y,x] = bias[b] + sum_t taps[b,(y+ky-1, x+kx-1), t]
@@ -474,6 +502,15 @@ extern "C" int tvl_bicubic_ac_bwd(const float* dy, float a, float* dx, int32_t B
     hipLaunchKernelGGL(bicubic_ac_bwd_kernel, dim3(nblk((long)B * Hi * Wi)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, a, dx, B, Hi, Wi,
                        Ho, Wo, ac_scale(Hi, Ho), ac_scale(Wi, Wo));
     TVL_LAUNCH_CHECK("tvl_bicubic_ac_bwd");
+    return 0;
+}
+
+extern "C" int tvl_bicubic_resize_u8(const float* x, uint8_t* out, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, tvlStream_t stream) {
+    TVL_REQUIRE(x && out, "tvl_bicubic_resize_u8: null pointer");
+    TVL_REQUIRE(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "tvl_bicubic_resize_u8: bad shape");
+    hipLaunchKernelGGL(bicubic_resize_u8_kernel, dim3(nblk((long)Ho * Wo)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out, Hi, Wi, Ho, Wo,
+                       (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    TVL_LAUNCH_CHECK("tvl_bicubic_resize_u8");
     return 0;
 }
 

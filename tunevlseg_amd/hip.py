@@ -124,6 +124,7 @@ _SIGS = {
     "tvl_bilinear_up_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_bicubic_ac_fwd": [_P, _P, _P, _F, _F, _I, _I, _I, _I, _I],
     "tvl_bicubic_ac_bwd": [_P, _F, _P, _I, _I, _I, _I, _I],
+    "tvl_bicubic_resize_u8": [_P, _P, _I, _I, _I, _I],
     "tvl_dynconv_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
     "tvl_dynconv_bwd": [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
 }
@@ -770,3 +771,11 @@ def conv3x3(x2d: torch.Tensor, B: int, H: int, W: int, Wm: torch.Tensor, bias=No
     K = cols.shape[1]
     gemm(NT, M, N, K, cols, K, Wm, Wm.shape[1], y, y.stride(0), bias=bias, act=act)
     return y
+
+
+def bicubic_resize_u8(pred: torch.Tensor, Ho: int, Wo: int) -> torch.Tensor:
+    """One probability map [H, W] -> uint8 grey levels [Ho, Wo] (bicubic, align_corners=False, no antialias; x*255+0.5 clamped)."""
+    H, W = pred.shape
+    out = torch.empty((Ho, Wo), device=pred.device, dtype=torch.uint8)
+    _call("tvl_bicubic_resize_u8", _p(pred), out.data_ptr(), H, W, Ho, Wo)
+    return out

@@ -156,8 +156,10 @@ class ImageTextMaskModule(nn.Module):
         return loss
 
     def predict_step(self, batch, batch_idx: int = 0):
+        """reference image_text_mask_module.py:244-255: probabilities + what is needed to save them at the original size."""
         with torch.no_grad():
-            return self.activation_fn(self.get_logits(batch))
+            preds = self.activation_fn(self.get_logits(batch))
+        return {"preds": preds, "mask_name": batch.get("mask_name"), "mask_shape": batch.get("mask_shape")}
 
     def epoch_metrics(self, stage: str, reset: bool = True) -> dict[str, float]:
         out = {f"{stage}_dice": self.metrics[f"{stage}_dice"].compute(), f"{stage}_iou": self.metrics[f"{stage}_iou"].compute()}
