@@ -210,7 +210,7 @@ int tvl_im2col3x3(const float* x, int64_t sb, int64_t sy, int64_t sx, int64_t sc
                   int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride, tvlStream_t stream);
 /* The same conv WITHOUT the im2col matrix (implicit GEMM on the split-bf16 kernel): args->A = the NHWC map (lda = its row
  * stride), args->B = weights [N, ldb] in the column order above, args->M = B*Ho*Wo, args->K = 9*C; epilogue as tvl_gemm_*.
- * Needs C % 4 == 0.  a_map is ignored. */
+ * Needs C % 4 == 0; nsplit must be 3 (the fp32-equivalent split).  a_map is ignored. */
 typedef struct { int32_t B, H, W, C, stride; } tvlConvGeom;
 int tvl_conv3x3_bf16s(const tvlGemmArgs* args, const tvlConvGeom* geom, int32_t nsplit, tvlStream_t stream);
 /*

@@ -1,463 +1,10 @@
-// fp32-in / fp32-out GEMM on the bf16 matrix cores by operand splitting (gfx950, v_mfma_f32_32x32x16_bf16).
-//
-// Each fp32 operand element is split, while its tile is staged to LDS, into S bf16 pieces
-//     x = x1 + x2 + ... + xS      (pieces 1..S-1 by truncation of the running residual, the last by round-to-nearest)
-// and the product is accumulated in fp32 over the piece pairs (i, j) with i + j <= S + 1:
-//     S = 1  plain bf16 operands                 1 MFMA  per 32x32x16 step   (16x the f32-MFMA rate)
-//     S = 2  a1b1 + a1b2 + a2b1                  3 MFMAs                     rel. error ~2^-16 per product
-//     S = 3  + a1b3 + a2b2 + a3b1                6 MFMAs                     three bf16 pieces carry all 24 significand
-//                                                                            bits of an fp32 value: the dropped terms are
-//                                                                            <= 2^-24 relative, i.e. fp32-equivalent
-// bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so S = 3 reproduces an fp32 GEMM to fp32
-// round-off at 6/16 of the f32-MFMA cost (8 f32 MFMAs of 64 cycles vs 6 bf16 MFMAs of 32 cycles per 16-deep k-step).
-//
-// Tuning log (profiles/r1_gemm_experiments.md): warp-specialised producer/consumer waves, a two-tile ping-pong workgroup,
-// source-level MFMA/VALU interleaving (sched_group_barrier) and a 3-deep register prefetch ring were all measured on
-// MI355X and landed within +-4 % of this simple structure (146-151 TFLOP/s fp32-equivalent on the ViT-B/16 shapes); the
-// PMC counters show 5.2 VALU instructions per MFMA and a 42 % busy matrix pipe at a ~2.3 GHz reported clock.
-//
-// Layout: NT only (A [M,K] and B [N,K], both k-contiguous); the frozen weights are kept in both orientations by the host
-// so data gradients are NT as well.  256 threads = 4 waves, tiles 128x128 (2x2 waves) / 96x128 (1x4) / 64x64 (2x2),
-// BK = 32, ONE LDS stage (S planes per operand) + register prefetch of the next slab, two barriers per slab.
-// LDS rows are 32 bf16 + 8 pad = 80 bytes = 20 dwords, so the 16 rows of a ds_read_b128 lane group start on 16
-// distinct 16-byte slots: conflict free.  Fragment map (guide §3): lane l -> row l&31, k = 8*(l>>5) .. +7.
-#include <stdlib.h>
-#include "common.h"
+// tvl_gemm_bf16s entry point; the kernel templates live in gemm_bf16s_kernel.h.  The template instantiations are spread over
+// three translation units (this one: 3-piece split; gemm_bf16s_lowp.hip: 1- and 2-piece modes; gemm_bf16s_conv.hip: implicit
+// 3x3 conv) so that `make -j` compiles them in parallel.
+#include "gemm_bf16s_kernel.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-namespace {
-
-constexpr int NTHREADS = 256;
-
-struct GemmParams {
-    int M, N, K;
-    const float* A; int lda;
-    const float* B; int ldb;
-    float* C; int ldc;
-    const float* bias;
-    const float* residual; int ldr;
-    int act;
-    float* pre_out;
-    const float* dact_aux; int ld_aux; int dact;
-    float alpha;
-    tvlRowMap a_map, c_map;
-    int tiles_m, tiles_n;
-    // implicit 3x3 / pad 1 convolution (CONV kernels): A is an NHWC pixel matrix [B*H*W, lda], the GEMM row m is the output
-    // pixel (b, oy, ox) and the GEMM column (ky*3+kx)*C + c addresses x[b, oy*stride+ky-1, ox*stride+kx-1, c] (0 outside)
-    int cH, cW, cC, cStride, cHo, cWo;
-};
-
-__device__ __forceinline__ long map_row(int r, const tvlRowMap& m) {
-    return m.div > 0 ? (long)(r / m.div) * m.mul + (r % m.div) + m.off : (long)r;
-}
-
-template <bool VEC>
-__device__ __forceinline__ float4 load4(const float* __restrict__ base, long row, int col, int cols, int ld) {
-    const float* p = base + row * (long)ld + col;
-    if (VEC) {
-        if (col + 3 < cols) return *reinterpret_cast<const float4*>(p);
-    }
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col < cols) v.x = p[0];
-    if (col + 1 < cols) v.y = p[1];
-    if (col + 2 < cols) v.z = p[2];
-    if (col + 3 < cols) v.w = p[3];
-    return v;
-}
-
-// one operand slab = ROWS x BK fp32 = ROWS*BK/4 float4, dealt round-robin over the 256 threads
-template <int ROWS, int BK>
-struct StageRegs {
-    static constexpr int TOTAL = ROWS * BK / 4;
-    static constexpr int N = (TOTAL + NTHREADS - 1) / NTHREADS;
-    float4 v[N];
-};
-
-template <int ROWS, int BK, bool VEC>
-__device__ __forceinline__ void gload(StageRegs<ROWS, BK>& s, const float* __restrict__ base, int ld, int row0, int nrows, int k0, int K,
-                                      const tvlRowMap& map) {
-    constexpr int F4 = BK / 4;
-#pragma unroll
-    for (int i = 0; i < StageRegs<ROWS, BK>::N; ++i) {
-        const int idx = threadIdx.x + NTHREADS * i;
-        if (StageRegs<ROWS, BK>::TOTAL % NTHREADS == 0 || idx < StageRegs<ROWS, BK>::TOTAL) {
-            int r = row0 + idx / F4;
-            r = r < nrows ? r : nrows - 1;
-            s.v[i] = load4<VEC>(base, map_row(r, map), k0 + 4 * (idx % F4), K, ld);
-        }
-    }
-}
-
-// implicit-GEMM operand load for the 3x3 conv: the im2col matrix is never materialised.  The rows a thread stages are the
-// same for every k-slab, so their (b, oy, ox) decomposition is done once (ConvRows); per slab only the tap changes.
-template <int ROWS, int BK>
-struct ConvRows {
-    static constexpr int N = StageRegs<ROWS, BK>::N;
-    long pix0[N];   // b * H * W
-    int oy[N], ox[N];
-};
-template <int ROWS, int BK>
-__device__ __forceinline__ void conv_rows_init(ConvRows<ROWS, BK>& cr, int row0, int nrows, const GemmParams& p) {
-    constexpr int F4 = BK / 4;
-#pragma unroll
-    for (int i = 0; i < ConvRows<ROWS, BK>::N; ++i) {
-        const int idx = threadIdx.x + NTHREADS * i;
-        int r = row0 + idx / F4;
-        r = r < nrows ? r : nrows - 1;
-        const int hw = p.cHo * p.cWo;
-        const int b = r / hw, rem = r - b * hw;
-        const int oy = rem / p.cWo;
-        cr.pix0[i] = (long)b * p.cH * p.cW;
-        cr.oy[i] = oy * p.cStride - 1;
-        cr.ox[i] = (rem - oy * p.cWo) * p.cStride - 1;
-    }
-}
-template <int ROWS, int BK>
-__device__ __forceinline__ void gload_conv(StageRegs<ROWS, BK>& s, const ConvRows<ROWS, BK>& cr, const GemmParams& p, int k0) {
-    constexpr int F4 = BK / 4;
-    const int kcol = k0 + 4 * (threadIdx.x % F4);  // NTHREADS % F4 == 0: the same column for every row this thread stages
-    const int tap = kcol / p.cC;
-    const int c = kcol - tap * p.cC;
-    const int ky = tap / 3, kx = tap - 3 * ky;
-    const bool kok = kcol < p.K;
-#pragma unroll
-    for (int i = 0; i < StageRegs<ROWS, BK>::N; ++i) {
-        const int idx = threadIdx.x + NTHREADS * i;
-        if (StageRegs<ROWS, BK>::TOTAL % NTHREADS == 0 || idx < StageRegs<ROWS, BK>::TOTAL) {
-            const int iy = cr.oy[i] + ky, ix = cr.ox[i] + kx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW)
-                v = *reinterpret_cast<const float4*>(p.A + (cr.pix0[i] + (long)iy * p.cW + ix) * p.lda + c);
-            s.v[i] = v;
-        }
-    }
-}
-
-__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
-__device__ __forceinline__ float bfloat(unsigned u) { return __builtin_bit_cast(float, u); }
-// two fp32 bit patterns -> one dword holding their upper halves (bf16 by truncation): low half = lo, high half = hi
-__device__ __forceinline__ unsigned pack_trunc(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
-__device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
-    bf16x2 t = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(unsigned, t);
-}
-
-// split 4 consecutive k-elements into S planes; plane s gets two dwords (4 bf16)
-template <int S>
-__device__ __forceinline__ void split4(const float4 v, uint2 (&out)[S]) {
-    float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        if (s == S - 1) {
-            out[s] = make_uint2(pack_rn(x[0], x[1]), pack_rn(x[2], x[3]));
-        } else {
-            out[s] = make_uint2(pack_trunc(fbits(x[0]), fbits(x[1])), pack_trunc(fbits(x[2]), fbits(x[3])));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = x[i] - bfloat(fbits(x[i]) & 0xFFFF0000u);
-        }
-    }
-}
-
-template <int ROWS, int BK, int S>
-__device__ __forceinline__ void sstore(const StageRegs<ROWS, BK>& sr, __bf16* __restrict__ lds) {
-    constexpr int F4 = BK / 4;
-    constexpr int LDB = BK + 8;
-#pragma unroll
-    for (int i = 0; i < StageRegs<ROWS, BK>::N; ++i) {
-        const int idx = threadIdx.x + NTHREADS * i;
-        if (StageRegs<ROWS, BK>::TOTAL % NTHREADS == 0 || idx < StageRegs<ROWS, BK>::TOTAL) {
-            uint2 pl[S];
-            split4<S>(sr.v[i], pl);
-#pragma unroll
-            for (int s = 0; s < S; ++s) *reinterpret_cast<uint2*>(&lds[(s * ROWS + idx / F4) * LDB + 4 * (idx % F4)]) = pl[s];
-        }
-    }
-}
-
-// epilogue of a transposed-product accumulator tile: lane -> row l31, registers 4g..4g+3 -> columns 8g+4h .. 8g+4h+3
-template <int TM, int TN, bool VEC, bool POST>
-__device__ __forceinline__ void epilogue_t(const GemmParams& p, f32x16 (&acc)[TM][TN], int row_base, int col_base, int l31, int h) {
-    const bool vec_c = VEC && (p.ldc % 4 == 0) && tvl_dev_aligned16(p.C) && (!p.pre_out || tvl_dev_aligned16(p.pre_out)) &&
-                       (!p.residual || (p.ldr % 4 == 0 && tvl_dev_aligned16(p.residual))) &&
-                       (!p.dact || (p.ld_aux % 4 == 0 && tvl_dev_aligned16(p.dact_aux))) && (!p.bias || tvl_dev_aligned16(p.bias));
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = row_base + i * 32 + l31;
-        if (row >= p.M) continue;
-        const long crow = map_row(row, p.c_map);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = col_base + j * 32 + 8 * g + 4 * h;
-                if (col >= p.N) continue;
-                float v[4] = {acc[i][j][4 * g] * p.alpha, acc[i][j][4 * g + 1] * p.alpha, acc[i][j][4 * g + 2] * p.alpha,
-                              acc[i][j][4 * g + 3] * p.alpha};
-                if (vec_c && col + 3 < p.N) {
-                    if (p.bias) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col);
-                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                    }
-                    if (p.dact) {
-                        const float4 z4 = *reinterpret_cast<const float4*>(p.dact_aux + crow * p.ld_aux + col);
-                        v[0] *= dact_f(z4.x, p.dact); v[1] *= dact_f(z4.y, p.dact); v[2] *= dact_f(z4.z, p.dact); v[3] *= dact_f(z4.w, p.dact);
-                    }
-                    if (p.pre_out) *reinterpret_cast<float4*>(p.pre_out + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                    if (POST && p.residual) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + crow * p.ldr + col);
-                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act & 0xff);
-                    if (!POST && p.residual) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + crow * p.ldr + col);
-                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-                    }
-                    *reinterpret_cast<float4*>(p.C + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int c = col + e;
-                        if (c >= p.N) continue;
-                        float x = v[e] + (p.bias ? p.bias[c] : 0.f);
-                        if (p.dact) x *= dact_f(p.dact_aux[crow * p.ld_aux + c], p.dact);
-                        if (p.pre_out) p.pre_out[crow * p.ldc + c] = x;
-                        if (POST && p.residual) x += p.residual[crow * p.ldr + c];
-                        x = act_f(x, p.act & 0xff);
-                        if (!POST && p.residual) x += p.residual[crow * p.ldr + c];
-                        p.C[crow * p.ldc + c] = x;
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV>
-__device__ __forceinline__ void gemm_bf16s_body(const GemmParams& p) {
-    constexpr int LDB = BK + 8;  // bf16 elements per LDS row: 80 B (BK 32) / 48 B (BK 16), both conflict free for ds_read_b128
-    constexpr int STAGE_ELEMS = S * (BM + BN) * LDB;
-    constexpr int WGN = 4 / WGM;
-    constexpr int WM = BM / WGM, WN = BN / WGN;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);  // per stage: A [S][BM][LDB] then B [S][BN][LDB]
-
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // grouped order: consecutive tile ids walk GROUP_M row-tiles of one column-tile before moving to the next column, so
-    // the ~64 tiles resident on an XCD cover an ~8 x 8 block: 8 A panels + 8 W slices instead of 3 A panels + all of W
-    // (rocprofv3: FETCH_SIZE of the fc1 GEMM was 19x its algorithmic bytes with the row-major order)
-    constexpr int GROUP_M = 8;
-    const int gsize_full = GROUP_M * p.tiles_n;
-    const int group = bid / gsize_full;
-    const int gm0 = group * GROUP_M;
-    const int gm = p.tiles_m - gm0 < GROUP_M ? p.tiles_m - gm0 : GROUP_M;
-    const int in_group = bid - group * gsize_full;
-    const int tile_m = gm0 + in_group % gm, tile_n = in_group / gm;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int l31 = lane & 31, h = lane >> 5;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    StageRegs<BM, BK> sa;
-    StageRegs<BN, BK> sb;
-    const tvlRowMap ident = {0, 0, 0};
-    const int nk = (p.K + BK - 1) / BK;
-
-    ConvRows<CONV ? BM : 1, BK> crows;
-    if constexpr (CONV) {
-        conv_rows_init<BM, BK>(crows, m0, p.M, p);
-        gload_conv<BM, BK>(sa, crows, p, 0);
-    } else {
-        gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, 0, p.K, p.a_map);
-    }
-    gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, 0, p.K, ident);
-    sstore<BM, BK, S>(sa, smem);
-    sstore<BN, BK, S>(sb, smem + S * BM * LDB);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = STAGES == 2 ? (kt & 1) : 0;
-        const __bf16* As = smem + cur * STAGE_ELEMS;
-        const __bf16* Bs = As + S * BM * LDB;
-        if (kt + 1 < nk) {
-            if constexpr (CONV) gload_conv<BM, BK>(sa, crows, p, (kt + 1) * BK);
-            else gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, p.a_map);
-            gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, ident);
-        }
-        if constexpr (TM * TN <= 4) {
-            // all fragment reads of the slab are issued before its first MFMA; the compiler then waits with counted
-            // lgkmcnt(N) so the later reads land underneath the earlier MFMAs
-            bf16x8 af[BK / 16][TM][S], bf[BK / 16][TN][S];
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int s = 0; s < S; ++s)
-                        af[ks][i][s] = *reinterpret_cast<const bf16x8*>(&As[(s * BM + wm * WM + i * 32 + l31) * LDB + ks * 16 + 8 * h]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int s = 0; s < S; ++s)
-                        bf[ks][j][s] = *reinterpret_cast<const bf16x8*>(&Bs[(s * BN + wn * WN + j * 32 + l31) * LDB + ks * 16 + 8 * h]);
-            }
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                // smallest-magnitude piece pairs first, the a1*b1 term last; mfma(b, a) = transposed product, so that a lane's
-                // 4 consecutive accumulator registers are 4 consecutive COLUMNS of one row of C (16-byte epilogue accesses)
-#pragma unroll
-                for (int order = S - 1; order >= 0; --order)
-#pragma unroll
-                    for (int sa_ = 0; sa_ <= order; ++sa_) {
-                        const int sb_ = order - sa_;
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j][sb_], af[ks][i][sa_], acc[i][j], 0, 0, 0);
-                    }
-            }
-        } else {
-            // large wave tiles (96x64): fragments of one 16-deep k-step at a time, or the slab's fragments alone would take
-            // 120 VGPRs next to the 96 accumulator registers.  Piece pairs from a table (rectangular loops unroll reliably).
-            constexpr int NPAIR = S * (S + 1) / 2;
-            constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB3[6] = {2, 1, 0, 1, 0, 0};  // S = 3: (0,2) (1,1) (2,0) (0,1) (1,0) (0,0)
-            constexpr int PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};                    // S = 2: (0,1) (1,0) (0,0)
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 af[TM][S], bf[TN][S];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int s = 0; s < S; ++s)
-                        af[i][s] = *reinterpret_cast<const bf16x8*>(&As[(s * BM + wm * WM + i * 32 + l31) * LDB + ks * 16 + 8 * h]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int s = 0; s < S; ++s)
-                        bf[j][s] = *reinterpret_cast<const bf16x8*>(&Bs[(s * BN + wn * WN + j * 32 + l31) * LDB + ks * 16 + 8 * h]);
-#pragma unroll
-                for (int q = 0; q < NPAIR; ++q) {
-                    const int sa_ = S == 3 ? PA[q] : (S == 2 ? PA2[q] : 0);
-                    const int sb_ = S == 3 ? PB3[q] : (S == 2 ? PB2[q] : 0);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][sb_], af[i][sa_], acc[i][j], 0, 0, 0);
-                }
-            }
-        }
-        if (STAGES == 1) __syncthreads();  // every wave is done reading this slab before it is overwritten
-        if (kt + 1 < nk) {
-            __bf16* dst = smem + (STAGES == 2 ? (cur ^ 1) * STAGE_ELEMS : 0);
-            sstore<BM, BK, S>(sa, dst);
-            sstore<BN, BK, S>(sb, dst + S * BM * LDB);
-        }
-        __syncthreads();
-    }
-    // two copies of the epilogue so that the common order (activation, then residual) keeps its straight-line code
-    if (p.act & TVL_ACT_POST_RESIDUAL) epilogue_t<TM, TN, VEC, true>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
-    else epilogue_t<TM, TN, VEC, false>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
-}
-
-template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
-    gemm_bf16s_body<BM, BN, WGM, S, VEC, BK, STAGES, CONV>(p);
-}
-// one wave per SIMD (up to 512 registers per lane): for wave tiles whose accumulators + fragments + staging exceed 256
-template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16s_kernel_w1(GemmParams p) {
-    gemm_bf16s_body<BM, BN, WGM, S, VEC, BK, STAGES, CONV>(p);
-}
-
-template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
-int launch_v(const GemmParams& p0, hipStream_t s) {
-    GemmParams p = p0;
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    constexpr size_t smem = (size_t)STAGES * S * (BM + BN) * (BK + 8) * sizeof(__bf16);
-    static bool attr_set = false;
-    void (*kern)(GemmParams) = gemm_bf16s_kernel<BM, BN, WGM, S, VEC, BK, STAGES, CONV>;
-    if constexpr (BM * BN > 128 * 128) {
-        static const int w1 = getenv("TVL_GEMM_W1") ? atoi(getenv("TVL_GEMM_W1")) : 0;  // experiment: one wave per SIMD
-        if (w1) kern = gemm_bf16s_kernel_w1<BM, BN, WGM, S, VEC, BK, STAGES, CONV>;
-    }
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
-    const long nwg = (long)p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NTHREADS), smem, s, p);
-    return 0;
-}
-
-template <int BM, int BN, int WGM, int S, bool VEC>
-int launch(const GemmParams& p, hipStream_t s) {
-    return launch_v<BM, BN, WGM, S, VEC, 32, 1>(p, s);
-}
-
-template <int S, bool VEC>
-int launch_tile(int bm, const GemmParams& p, hipStream_t s) {
-    if (bm == 192) return launch<192, 128, 2, S, VEC>(p, s);
-    if (bm == 128) return launch<128, 128, 2, S, VEC>(p, s);
-    if (bm == 96) return launch<96, 128, 1, S, VEC>(p, s);
-    return launch<64, 64, 2, S, VEC>(p, s);
-}
-
-template <int S>
-int launch_conv_tile(int bm, const GemmParams& p, hipStream_t s) {
-    if (bm == 128) return launch_v<128, 128, 2, S, true, 32, 1, true>(p, s);
-    if (bm == 192) return launch_v<192, 128, 2, S, true, 32, 1, true>(p, s);
-    if (bm == 96) return launch_v<96, 128, 1, S, true, 32, 1, true>(p, s);
-    return launch_v<64, 64, 2, S, true, 32, 1, true>(p, s);
-}
-
-int choose_bm(long M, long N, long K) {
-    const long cus = 256;
-    // 192x128 (wave tile 96x64) moves the fewest operand bytes per FLOP from L2 (the measured bound of this kernel: operand
-    // loads alone take half its run time) and reads the fewest LDS bytes per MFMA: it replaces 96x128 outright (+19 % on the
-    // K = 3072 shapes) and beats 128x128 except on short-K problems, where the bigger prologue / epilogue shows;
-    // TVL_GEMM_TILE192=0 disables it
-    static const int use192 = getenv("TVL_GEMM_TILE192") ? atoi(getenv("TVL_GEMM_TILE192")) : 1;
-    struct Cand { int bm, bn, per_cu; double w; } cands[4] = {{192, 128, 2, 0.93}, {128, 128, 2, 1.0}, {96, 128, 2, 1.0}, {64, 64, 4, 1.12}};
-    double best = 1e300, raw[4] = {0, 0, 0, 0};
-    int out = 64;
-    for (int ci = 0; ci < 4; ++ci) {
-        const Cand& c = cands[ci];
-        if (c.bm == 192 && !use192) continue;
-        if (c.bm == 96 && use192) continue;
-        const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
-        const long slots = cus * c.per_cu;
-        const long rounds = (tiles + slots - 1) / slots;
-        raw[ci] = (double)rounds * c.per_cu * c.bm * c.bn;
-        const double cost = raw[ci] * c.w;
-        if (cost < best) { best = cost; out = c.bm; }
-    }
-    if (out == 192 && K < 1536 && raw[1] <= raw[0]) out = 128;
-    return out;
-}
-
-}  // namespace
+// GemmParams lives in an anonymous namespace (identical in every TU that includes the header): passed as an opaque pointer
+int tvl_gemm_bf16s_lowp(const void* gemm_params, int nsplit, int bm, bool vec, hipStream_t s);  // gemm_bf16s_lowp.hip
 
 extern "C" int tvl_gemm_bf16s(const tvlGemmArgs* a, int32_t nsplit, tvlStream_t stream) {
     TVL_REQUIRE(a != nullptr, "tvl_gemm_bf16s: null args");
@@ -481,47 +28,11 @@ extern "C" int tvl_gemm_bf16s(const tvlGemmArgs* a, int32_t nsplit, tvlStream_t 
     const int bm = choose_bm(a->M, a->N, a->K);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc = 1;
-    if (vec) {
-        if (nsplit == 1) rc = launch_tile<1, true>(bm, p, s);
-        else if (nsplit == 2) rc = launch_tile<2, true>(bm, p, s);
-        else rc = launch_tile<3, true>(bm, p, s);
-    } else {
-        if (nsplit == 1) rc = launch_tile<1, false>(bm, p, s);
-        else if (nsplit == 2) rc = launch_tile<2, false>(bm, p, s);
-        else rc = launch_tile<3, false>(bm, p, s);
-    }
+    if (nsplit != 3) rc = tvl_gemm_bf16s_lowp(&p, nsplit, bm, vec, s);
+    else if (vec) rc = launch_tile<3, true>(bm, p, s);
+    else rc = launch_tile<3, false>(bm, p, s);
     TVL_REQUIRE(rc == 0, "tvl_gemm_bf16s: launch failed");
     TVL_LAUNCH_CHECK("tvl_gemm_bf16s");
     return 0;
 }
 
-extern "C" int tvl_conv3x3_bf16s(const tvlGemmArgs* a, const tvlConvGeom* g, int32_t nsplit, tvlStream_t stream) {
-    TVL_REQUIRE(a != nullptr && g != nullptr, "tvl_conv3x3_bf16s: null args");
-    TVL_REQUIRE(nsplit >= 1 && nsplit <= 3, "tvl_conv3x3_bf16s: nsplit must be 1, 2 or 3");
-    TVL_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0 && g->C > 0 && (g->stride == 1 || g->stride == 2), "tvl_conv3x3_bf16s: bad geometry");
-    const int Ho = (g->H - 1) / g->stride + 1, Wo = (g->W - 1) / g->stride + 1;
-    TVL_REQUIRE((long)g->B * Ho * Wo == a->M && a->K == 9 * g->C && a->N > 0, "tvl_conv3x3_bf16s: M=%d K=%d do not match the geometry", a->M, a->K);
-    TVL_REQUIRE(a->A && a->B && a->C, "tvl_conv3x3_bf16s: null operand");
-    TVL_REQUIRE(g->C % 4 == 0 && a->lda % 4 == 0 && a->lda >= g->C && tvl_aligned16(a->A), "tvl_conv3x3_bf16s: needs C %% 4 == 0 and 16-byte aligned rows");
-    TVL_REQUIRE(a->ldb >= a->K && a->ldb % 4 == 0 && tvl_aligned16(a->B) && a->ldc >= a->N, "tvl_conv3x3_bf16s: bad weight / output leading dimension");
-    TVL_REQUIRE(!a->residual || a->ldr >= a->N, "tvl_conv3x3_bf16s: ldr too small");
-    TVL_REQUIRE(!a->dact || (a->dact_aux && a->ld_aux >= a->N), "tvl_conv3x3_bf16s: dact needs dact_aux");
-    TVL_REQUIRE((long)g->B * g->H * g->W * (long)a->lda < (1L << 40), "tvl_conv3x3_bf16s: map too large");
-
-    GemmParams p;
-    p.M = a->M; p.N = a->N; p.K = a->K;
-    p.A = a->A; p.lda = a->lda; p.B = a->B; p.ldb = a->ldb; p.C = a->C; p.ldc = a->ldc;
-    p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.act = a->act; p.pre_out = a->pre_out;
-    p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha;
-    p.a_map = tvlRowMap{0, 0, 0}; p.c_map = a->c_map; p.tiles_m = p.tiles_n = 0;
-    p.cH = g->H; p.cW = g->W; p.cC = g->C; p.cStride = g->stride; p.cHo = Ho; p.cWo = Wo;
-    const int bm = choose_bm(a->M, a->N, a->K);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int rc;
-    if (nsplit == 1) rc = launch_conv_tile<1>(bm, p, s);
-    else if (nsplit == 2) rc = launch_conv_tile<2>(bm, p, s);
-    else rc = launch_conv_tile<3>(bm, p, s);
-    TVL_REQUIRE(rc == 0, "tvl_conv3x3_bf16s: launch failed");
-    TVL_LAUNCH_CHECK("tvl_conv3x3_bf16s");
-    return 0;
-}

@@ -755,7 +755,7 @@ def conv3x3(x2d: torch.Tensor, B: int, H: int, W: int, Wm: torch.Tensor, bias=No
     M, N = B * Ho * Wo, Wm.shape[0]
     y = _out2d(out, M, N, x2d)
     split = _NSPLIT.get(GEMM_MODE, 0)
-    if split and Cc % 4 == 0 and M >= 256 and x2d.stride(0) % 4 == 0:
+    if split == 3 and Cc % 4 == 0 and M >= 256 and x2d.stride(0) % 4 == 0:
         args = GemmArgs(NT, M, N, 9 * Cc, _ps(x2d), x2d.stride(0), _p(Wm), Wm.shape[1], _ps(y), y.stride(0), _p(bias), None, 0, act,
                         None, None, 0, ACT_NONE, 1.0, _ident(), _ident())
         geom = ConvGeom(B, H, W, Cc, stride)
