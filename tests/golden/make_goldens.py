@@ -404,6 +404,8 @@ def main():
                   learner_kw=dict(prompt_depth=1, num_context=2, vector_std=0.02, use_unified_projection=True,
                                   intermediate_dim=None, use_proj_norm=False, use_lora_proj=False, norm_image_features=True),
                   net_kw=base_old, img_size=128)
+    run_cris_case("cris_tiny_coop_trunc_n12_b1", preset="tiny", wseed=31, learner_kind="coop", iseed=35, B=1, L=70,
+                  learner_kw=dict(prompt_depth=2, num_context=12, vector_std=0.02), net_kw=base_new)
     run_cris_case("cris_rn50_cocoop_n4_d1_newlast", preset="rn50", wseed=41, learner_kind="cocoop", iseed=41, B=1, L=8,
                   learner_kw=dict(prompt_depth=1, num_context=4, vector_std=0.02, use_unified_projection=False,
                                   intermediate_dim=64, use_proj_norm=True, use_lora_proj=False, norm_image_features=False,
