@@ -81,6 +81,25 @@ def build_cris_module(device, seed: int = 0):
     return module, module.configure_optimizers()["optimizer"]
 
 
+def build_maple_module(device, seed: int = 0):
+    """BASELINE configs[3]: CLIPSeg + MaPLe coupled prompts, depth 9, 4 context tokens (reference configs/model/maple_clipseg.yaml)."""
+    from tunevlseg_amd import nets
+    from tunevlseg_amd.nets.context_learner import MapleContextLearner
+    from tunevlseg_amd.task import DiceCELoss, FusedAdamW, ImageTextMaskModule
+
+    torch.manual_seed(12345)
+    net = nets.MapleCLIPSeg(
+        context_learner=partial(MapleContextLearner, prompt_depth=9, num_context=4, vector_std=0.02, use_unified_projection=False,
+                                intermediate_dim=64, use_proj_norm=True, use_lora_proj=False),
+        model_cfg={"pretrained_model_name_or_path": f"random:rd64:seed={seed}", "freeze_encoder": False, "freeze_decoder": False},
+        freeze_all=True, no_freeze_last_layer=False, use_new_last_layer=True, new_last_layer_kernel_size=5, residual_ratio=0.5)
+    module = ImageTextMaskModule(net=net, loss_fn=DiceCELoss(sigmoid=True, lambda_dice=1, lambda_ce=0.2),
+                                 optimizer=partial(FusedAdamW, lr=2e-4), scheduler=None, compile=False, task="binary",
+                                 threshold=0.5, weight_decay=0.0).to(device)
+    module.setup("fit")
+    return module, module.configure_optimizers()["optimizer"]
+
+
 def build_module(device, num_context: int = 10, prompt_depth: int = 1, seed: int = 0):
     from tunevlseg_amd import nets
     from tunevlseg_amd.nets.context_learner import VPTContextLearner
@@ -138,8 +157,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--workload", choices=("vpt", "cris"), default="vpt",
-                    help="vpt = BASELINE configs[1] (the headline line); cris = configs[2] (CRIS + CoCoOp, 416x416), reported for DESIGN.md")
+    ap.add_argument("--workload", choices=("vpt", "cris", "maple"), default="vpt",
+                    help="vpt = BASELINE configs[1] (the headline line); cris = configs[2] (CRIS + CoCoOp, 416x416) and maple = configs[3] "
+                         "(MaPLe depth 9) are reported for DESIGN.md")
     args = ap.parse_args()
 
     from tunevlseg_amd import dist as tdist
@@ -154,10 +174,10 @@ def main():
     device = torch.device("cuda", local_rank)
     hip.load()
 
-    cris = args.workload == "cris"
-    module, opt = build_cris_module(device) if cris else build_module(device)
+    cris, maple = args.workload == "cris", args.workload == "maple"
+    module, opt = build_cris_module(device) if cris else (build_maple_module(device) if maple else build_module(device))
     batch = make_batch(args.batch, 416 if cris else 352, 100 + rank, device, pad_id=0 if cris else 1)
-    gflop_per_image = 212.8 if cris else GFLOP_PER_IMAGE_TRAIN  # SURVEY.md §8d (FlopCounterMode on the reference classes)
+    gflop_per_image = 212.8 if cris else (167.8 if maple else GFLOP_PER_IMAGE_TRAIN)  # SURVEY.md §8d (FlopCounterMode on the reference)
 
     def step():
         opt.zero_grad()
@@ -201,7 +221,7 @@ def main():
         # WRITE_SIZE, each in its own run; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM)
         traffic = None
         tf = ROOT / "profiles" / ("r1_g_cris_hbm_traffic.json" if cris else "r1_g_hbm_traffic.json")
-        if tf.exists():
+        if tf.exists() and not maple:
             rec = json.loads(tf.read_text()).get(name)
             traffic = rec["hbm_bytes_per_launch"] if rec else None
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -217,22 +237,24 @@ def main():
         value = world * args.batch * args.steps / elapsed
         out = {
             "metric": ("images/sec, train step (fwd + DiceCE + bwd + AdamW on prompts), " +
-                       ("CRIS (CLIP-RN50) + CoCoOp, 416x416" if cris else "CLIPSeg ViT-B/16 + VPT-10 shallow, 352x352")),
+                       ("CRIS (CLIP-RN50) + CoCoOp, 416x416" if cris else "CLIPSeg ViT-B/16 + MaPLe depth 9, 352x352" if maple
+                        else "CLIPSeg ViT-B/16 + VPT-10 shallow, 352x352")),
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": MODE_DTYPE[hip.GEMM_MODE],
             "gemm_mode": hip.GEMM_MODE,
             "data": "synthetic", "per_gpu": round(value / world, 2),
             "config": {"workload": ("CRIS (CLIP-RN50 + cross-attn decoder) + CoCoOp meta-net, 416x416, bs=32/GPU (BASELINE configs[2])" if cris else
+                                    "CLIPSeg ViT-B/16 + MaPLe (coupled V+L prompts, depth=9), 352x352, bs=32/GPU (BASELINE configs[3])" if maple else
                                     "CLIPSeg ViT-B/16 + VPT-shallow (10 visual prompts), 352x352, bs=32/GPU (BASELINE configs[1])"),
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
                        "weights": "seeded random init (RN50 CRIS geometry)" if cris else "seeded random init (rd64 geometry)",
-                       "use_new_last_layer": cris},
+                       "use_new_last_layer": cris or maple},
             "step_tflops": round(value * gflop_per_image / 1e3, 2),
             "step_frac_of_f32_mfma_peak": round(value / world * gflop_per_image / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
             "loss": round(float(loss.item()), 6), "train_dice": round(metrics["train_dice"], 6), "train_iou": round(metrics["train_iou"], 6),
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1 and not cris:
+        if not args.no_cpu_baseline and world == 1 and not cris and not maple:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
