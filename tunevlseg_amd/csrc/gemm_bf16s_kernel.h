@@ -178,6 +178,62 @@ __device__ __forceinline__ void sstore(const StageRegs<ROWS, BK>& sr, __bf16* __
     }
 }
 
+// One float4 of the epilogue (4 consecutive columns of one row), all operands 16-byte aligned and inside the matrix.
+template <bool POST>
+__device__ __forceinline__ void emit4(const GemmParams& p, long crow, int col, float4 a) {
+    float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+    if (p.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if (p.dact) {
+        const float4 z4 = *reinterpret_cast<const float4*>(p.dact_aux + crow * p.ld_aux + col);
+        v[0] *= dact_f(z4.x, p.dact); v[1] *= dact_f(z4.y, p.dact); v[2] *= dact_f(z4.z, p.dact); v[3] *= dact_f(z4.w, p.dact);
+    }
+    if (p.pre_out) *reinterpret_cast<float4*>(p.pre_out + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+    if (POST && p.residual) {
+        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + crow * p.ldr + col);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act & 0xff);
+    if (!POST && p.residual) {
+        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + crow * p.ldr + col);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+    *reinterpret_cast<float4*>(p.C + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// Coalesced epilogue.  Straight from the accumulators a store instruction covers 32 rows x 32 bytes (lane l31 owns a row, the
+// two lane halves 8 of its columns): partial-line writes that made the C write-out cost ~0.5 us per MB, un-overlapped (time vs K
+// at fixed M, N has an intercept proportional to M*N).  Each 32x32 block therefore takes a round trip through a per-wave LDS
+// scratch (free after the k-loop's last barrier) and leaves as 8 rows x 128 contiguous bytes per instruction; the epilogue's own
+// loads (residual, activation-derivative operand) get the same mapping.
+template <int TM, int TN, bool POST>
+__device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], int row_base, int col_base, int lane, float* scratch) {
+    constexpr int LDS_ROW = 36;  // floats: 32 + 4 pad, ds_write_b128 of 8 consecutive rows hits 32 distinct banks
+    const int l31 = lane & 31, h = lane >> 5;
+    const int rr = lane >> 3, cc = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(&scratch[l31 * LDS_ROW + 8 * g + 4 * h]) =
+                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            const int col = col_base + j * 32 + cc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rl = 8 * q + rr;
+                const float4 v = *reinterpret_cast<const float4*>(&scratch[rl * LDS_ROW + cc]);
+                const int row = row_base + i * 32 + rl;
+                if (row < p.M && col + 3 < p.N) emit4<POST>(p, map_row(row, p.c_map), col, v);
+            }
+        }
+    }
+}
+
 // epilogue of a transposed-product accumulator tile: lane -> row l31, registers 4g..4g+3 -> columns 8g+4h .. 8g+4h+3
 template <int TM, int TN, bool VEC, bool POST>
 __device__ __forceinline__ void epilogue_t(const GemmParams& p, f32x16 (&acc)[TM][TN], int row_base, int col_base, int l31, int h) {
@@ -377,8 +433,20 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmParams& p) {
         __syncthreads();
     }
     // two copies of the epilogue so that the common order (activation, then residual) keeps its straight-line code
-    if (p.act & TVL_ACT_POST_RESIDUAL) epilogue_t<TM, TN, VEC, true>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
-    else epilogue_t<TM, TN, VEC, false>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
+    // fast path: every epilogue operand 16-byte aligned and the wave's columns inside N -> coalesced stores through LDS
+    const bool aligned = VEC && (p.ldc % 4 == 0) && tvl_dev_aligned16(p.C) && (!p.pre_out || tvl_dev_aligned16(p.pre_out)) &&
+                         (!p.residual || (p.ldr % 4 == 0 && tvl_dev_aligned16(p.residual))) &&
+                         (!p.dact || (p.ld_aux % 4 == 0 && tvl_dev_aligned16(p.dact_aux))) && (!p.bias || tvl_dev_aligned16(p.bias));
+    const bool post = (p.act & TVL_ACT_POST_RESIDUAL) != 0;
+    if (aligned && n0 + BN <= p.N) {  // workgroup-uniform: LDS scratch is only touched on this path
+        float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+        if (post) epilogue_lds<TM, TN, true>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, scratch);
+        else epilogue_lds<TM, TN, false>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, scratch);
+    } else if (post) {
+        epilogue_t<TM, TN, VEC, true>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
+    } else {
+        epilogue_t<TM, TN, VEC, false>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
+    }
 }
 
 template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
@@ -390,7 +458,9 @@ int launch_v(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    constexpr size_t smem = (size_t)STAGES * S * (BM + BN) * (BK + 8) * sizeof(__bf16);
+    constexpr size_t stage_bytes = (size_t)STAGES * S * (BM + BN) * (BK + 8) * sizeof(__bf16);
+    constexpr size_t epi_bytes = (size_t)4 * 32 * 36 * sizeof(float);  // per-wave scratch of the coalesced epilogue
+    constexpr size_t smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_set = false;
     auto kern = gemm_bf16s_kernel<BM, BN, WGM, S, VEC, BK, STAGES, CONV>;
     if (!attr_set) {
