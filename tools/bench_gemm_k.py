@@ -14,7 +14,7 @@ def main():
     M = 15840
     for N in (768, 2304, 3072):
         rows = []
-        for K in (256, 512, 768, 1536, 3072, 6144):
+        for K in (32, 64, 128, 256, 512, 768, 1536, 3072, 6144):
             A, B, C = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda"), torch.empty(M, N, device="cuda")
             for _ in range(3):
                 hip.gemm(hip.NT, M, N, K, A, K, B, K, C, N)
@@ -30,7 +30,7 @@ def main():
             t = sorted(ts)[2]
             rows.append((K, t))
             print(f"N={N} K={K}: {t:8.1f} us  {2.0*M*N*K/t/1e6:7.1f} TF/s  {hip.gemm_kernel_key(hip.NT, M, N, True, 3, K)[17:30]}")
-        (k0, t0), (k1, t1) = rows[2], rows[4]
+        (k0, t0), (k1, t1) = rows[5], rows[7]
         b = (t1 - t0) / (k1 - k0)
         print(f"   N={N}: slope {b*1e3:.1f} ns per k  => asymptotic {2.0*M*N/b/1e6:.1f} TF/s, intercept {t0 - b*k0:.1f} us")
 
