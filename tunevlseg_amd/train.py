@@ -37,6 +37,11 @@ def train(cfg: dict[str, Any], train_loader=None, val_loader=None, test_loader=N
         metrics.update(trainer.fit(module, train_loader, val_loader, ckpt_path=cfg.get("ckpt_path")))
     if cfg.get("test", True) and test_loader is not None:
         metrics.update(trainer.test(module, test_loader, ckpt_path="best" if trainer.best_path else None))
+    if cfg.get("predict") and test_loader is not None:  # reference src/train.py: save_predictions after test
+        from .predict import save_predictions
+
+        metrics["saved_masks"] = float(save_predictions(module, test_loader, CL.resolve(cfg, cfg.get("output_masks_dir")),
+                                                        bool(cfg.get("overwrite_outputs"))))
     return metrics
 
 

@@ -158,8 +158,12 @@ class SyntheticImageTextMaskLoader:
             yy, xx = torch.meshgrid(torch.arange(image_size), torch.arange(image_size), indexing="ij")
             cx = image_size * (0.3 + 0.4 * torch.rand(B, generator=g))
             mask = (((xx[None] - cx[:, None, None]) ** 2 + (yy[None] - image_size / 2) ** 2) < (image_size / 4) ** 2).float()[:, None]
+            k = len(self.batches)
             self.batches.append({"image": img.to(device), "input_ids": ids.to(device), "attention_mask": am.to(device),
-                                 "mask": mask.to(device).contiguous()})
+                                 "mask": mask.to(device).contiguous(),
+                                 # what the predict tail needs (reference image_text_mask_dataset.py:74-96)
+                                 "mask_name": [f"synthetic/r{rank}_b{k}_{b}.png" for b in range(B)],
+                                 "mask_shape": [torch.tensor([image_size, image_size])] * B})
 
     def __iter__(self):
         return iter(self.batches)
