@@ -29,9 +29,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// 8-wave instantiations (192x256 tile) live in gemm_bf16s_w8.hip; GemmParams is TU-local, hence the opaque pointer
+int tvl_gemm_bf16s_w8(const void* gemm_params, bool vec, bool conv, hipStream_t s);
+
 namespace {
 
-constexpr int NTHREADS = 256;
+// 256 threads = 4 waves per workgroup; gemm_bf16s_w8.hip includes this header with 512 threads (8 waves) for the 192x256 tile
+#ifndef TVL_GEMM_NTHREADS
+#define TVL_GEMM_NTHREADS 256
+#endif
+constexpr int NTHREADS = TVL_GEMM_NTHREADS;
+constexpr int NWAVES = NTHREADS / 64;
 
 struct GemmParams {
     int M, N, K;
@@ -297,7 +305,7 @@ template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CON
 __device__ __forceinline__ void gemm_bf16s_body(const GemmParams& p) {
     constexpr int LDB = BK + 8;  // bf16 elements per LDS row: 80 B (BK 32) / 48 B (BK 16), both conflict free for ds_read_b128
     constexpr int STAGE_ELEMS = S * (BM + BN) * LDB;
-    constexpr int WGN = 4 / WGM;
+    constexpr int WGN = NWAVES / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
@@ -459,7 +467,7 @@ int launch_v(const GemmParams& p0, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     constexpr size_t stage_bytes = (size_t)STAGES * S * (BM + BN) * (BK + 8) * sizeof(__bf16);
-    constexpr size_t epi_bytes = (size_t)4 * 32 * 36 * sizeof(float);  // per-wave scratch of the coalesced epilogue
+    constexpr size_t epi_bytes = (size_t)NWAVES * 32 * 36 * sizeof(float);  // per-wave scratch of the coalesced epilogue
     constexpr size_t smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_set = false;
     auto kern = gemm_bf16s_kernel<BM, BN, WGM, S, VEC, BK, STAGES, CONV>;
@@ -477,11 +485,14 @@ int launch(const GemmParams& p, hipStream_t s) {
     return launch_v<BM, BN, WGM, S, VEC, 32, 1>(p, s);
 }
 
+#if TVL_GEMM_NTHREADS == 256
 template <int S, bool VEC>
 int launch_tile(int bm, const GemmParams& p, hipStream_t s) {
     if constexpr (S == 3) {
+        if (bm == 256) return tvl_gemm_bf16s_w8(&p, VEC, false, s);
         if (bm == 192) return launch<192, 128, 2, S, VEC>(p, s);
     }
+    if (bm == 256) bm = 128;
     if (bm == 192) bm = 96;  // the reduced-precision modes keep the three original tiles
     if (bm == 128) return launch<128, 128, 2, S, VEC>(p, s);
     if (bm == 96) return launch<96, 128, 1, S, VEC>(p, s);
@@ -489,34 +500,40 @@ int launch_tile(int bm, const GemmParams& p, hipStream_t s) {
 }
 
 int launch_conv_tile(int bm, const GemmParams& p, hipStream_t s) {
+    if (bm == 256) return tvl_gemm_bf16s_w8(&p, true, true, s);
     if (bm == 192) return launch_v<192, 128, 2, 3, true, 32, 1, true>(p, s);
     if (bm == 128) return launch_v<128, 128, 2, 3, true, 32, 1, true>(p, s);
     if (bm == 96) return launch_v<96, 128, 1, 3, true, 32, 1, true>(p, s);
     return launch_v<64, 64, 2, 3, true, 32, 1, true>(p, s);
 }
+#endif  // TVL_GEMM_NTHREADS == 256
 
 int choose_bm(long M, long N, long K) {
     const long cus = 256;
     // 192x128 (wave tile 96x64) moves the fewest operand bytes per FLOP from L2 (the measured bound of this kernel: operand
     // loads alone take half its run time) and reads the fewest LDS bytes per MFMA: it replaces 96x128 outright (+19 % on the
     // K = 3072 shapes) and beats 128x128 except on short-K problems, where the bigger prologue / epilogue shows;
-    // TVL_GEMM_TILE192=0 disables it
+    // TVL_GEMM_TILE192=0 disables it.  192x256 (code 256: 8 waves, one workgroup per CU, same wave tile) halves the number of
+    // tile rounds of the wide-N shapes; TVL_GEMM_TILE256=0 disables it.
     static const int use192 = getenv("TVL_GEMM_TILE192") ? atoi(getenv("TVL_GEMM_TILE192")) : 1;
-    struct Cand { int bm, bn, per_cu; double w; } cands[4] = {{192, 128, 2, 0.93}, {128, 128, 2, 1.0}, {96, 128, 2, 1.0}, {64, 64, 4, 1.12}};
-    double best = 1e300, raw[4] = {0, 0, 0, 0};
+    static const int use256 = getenv("TVL_GEMM_TILE256") ? atoi(getenv("TVL_GEMM_TILE256")) : 1;
+    struct Cand { int bm, bn, per_cu, code; double w; } cands[5] = {{192, 256, 1, 256, 0.90}, {192, 128, 2, 192, 0.93}, {128, 128, 2, 128, 1.0},
+                                                                    {96, 128, 2, 96, 1.0}, {64, 64, 4, 64, 1.12}};
+    double best = 1e300, raw[5] = {0, 0, 0, 0, 0};
     int out = 64;
-    for (int ci = 0; ci < 4; ++ci) {
+    for (int ci = 0; ci < 5; ++ci) {
         const Cand& c = cands[ci];
-        if (c.bm == 192 && !use192) continue;
-        if (c.bm == 96 && use192) continue;
+        if (c.code == 256 && (!use256 || !use192 || N % 256 != 0 || K < 1536)) continue;  // long-K only: +4 % there, -3 % at K = 768
+        if (c.code == 192 && !use192) continue;
+        if (c.code == 96 && use192) continue;
         const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
         const long slots = cus * c.per_cu;
         const long rounds = (tiles + slots - 1) / slots;
         raw[ci] = (double)rounds * c.per_cu * c.bm * c.bn;
         const double cost = raw[ci] * c.w;
-        if (cost < best) { best = cost; out = c.bm; }
+        if (cost < best) { best = cost; out = c.code; }
     }
-    if (out == 192 && K < 1536 && raw[1] <= raw[0]) out = 128;
+    if (out == 192 && K < 1536 && raw[2] <= raw[1]) out = 128;
     return out;
 }
 

@@ -234,18 +234,21 @@ def gemm_profile_stop() -> dict:
 
 
 def _bf16s_tile(M: int, N: int, K: int) -> tuple[int, int, int]:
-    """Tile the split-bf16 GEMM picks (same rule as csrc/gemm_bf16s.hip choose_bm)."""
+    """Tile the split-bf16 GEMM picks (same rule as csrc/gemm_bf16s_kernel.h choose_bm)."""
     use192 = int(os.environ.get("TVL_GEMM_TILE192", "1"))
-    cands = ((192, 128, 2, 2, 0.93), (128, 128, 2, 2, 1.0), (96, 128, 2, 1, 1.0), (64, 64, 4, 2, 1.12))
+    use256 = int(os.environ.get("TVL_GEMM_TILE256", "1"))
+    cands = ((192, 256, 1, 2, 0.90), (192, 128, 2, 2, 0.93), (128, 128, 2, 2, 1.0), (96, 128, 2, 1, 1.0), (64, 64, 4, 2, 1.12))
     best, tile, raw = None, (64, 64, 2), {}
     for bm, bn, per_cu, wgm, w in cands:
+        if bn == 256 and (not use256 or not use192 or N % 256 != 0 or K < 1536):
+            continue
         if (bm == 192 and not use192) or (bm == 96 and use192):
             continue
         tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-        raw[bm] = ((tiles + 256 * per_cu - 1) // (256 * per_cu)) * per_cu * bm * bn
-        if best is None or raw[bm] * w < best:
-            best, tile = raw[bm] * w, (bm, bn, wgm)
-    if tile[0] == 192 and K < 1536 and raw[128] <= raw[192]:
+        raw[(bm, bn)] = ((tiles + 256 * per_cu - 1) // (256 * per_cu)) * per_cu * bm * bn
+        if best is None or raw[(bm, bn)] * w < best:
+            best, tile = raw[(bm, bn)] * w, (bm, bn, wgm)
+    if tile[:2] == (192, 128) and K < 1536 and raw[(128, 128)] <= raw[(192, 128)]:
         tile = (128, 128, 2)
     return tile
 
