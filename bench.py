@@ -220,7 +220,7 @@ def main():
         # HBM bytes per launch of that kernel from the PMC passes recorded in profiles/ (rocprofv3 --pmc FETCH_SIZE, then
         # WRITE_SIZE, each in its own run; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM)
         traffic = None
-        tf = ROOT / "profiles" / ("r1_h_cris_hbm_traffic.json" if cris else "r1_h_hbm_traffic.json")
+        tf = ROOT / "profiles" / ("r1_i_cris_hbm_traffic.json" if cris else "r1_i_hbm_traffic.json")
         if tf.exists() and not maple:
             rec = json.loads(tf.read_text()).get(name)
             traffic = rec["hbm_bytes_per_launch"] if rec else None
@@ -230,6 +230,11 @@ def main():
                     else "dense f32-input MFMA peak", "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "launches_per_step": d["launches"] // 2, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1),
                     "flops_per_launch": round(d["flops"] / d["launches"]), "all_gemm_ms_per_step": round(gemm_ms, 2),
+                    # every GEMM instantiation of the step (one instantiation serves several shapes: the average mixes them)
+                    "gemm_kernels": [{"kernel": k.replace("gemm_bf16s_kernel", "bf16s").replace("gemm_f32_kernel", "f32"),
+                                      "ms_per_step": round(v["ms"] / 2, 2), "launches_per_step": v["launches"] // 2,
+                                      "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:5]],
                     "all_gemm_tflops": round(sum(v["flops"] for v in prof.values()) / 2 / (gemm_ms * 1e-3) / 1e12, 2)}
 
     if rank == 0:

@@ -523,7 +523,8 @@ int choose_bm(long M, long N, long K) {
     int out = 64;
     for (int ci = 0; ci < 5; ++ci) {
         const Cand& c = cands[ci];
-        if (c.code == 256 && (!use256 || !use192 || N % 256 != 0 || K < 1536)) continue;  // long-K only: +4 % there, -3 % at K = 768
+        // long K (+4 %) or very wide N (N = 3072 at K = 768: 165 vs 163 TFLOP/s for 128x128); 1-3 % slower on the other K = 768 shapes
+        if (c.code == 256 && (!use256 || !use192 || N % 256 != 0 || (K < 1536 && N < 3072))) continue;
         if (c.code == 192 && !use192) continue;
         if (c.code == 96 && use192) continue;
         const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
@@ -534,6 +535,7 @@ int choose_bm(long M, long N, long K) {
         if (cost < best) { best = cost; out = c.code; }
     }
     if (out == 192 && K < 1536 && raw[2] <= raw[1]) out = 128;
+    if (out == 128 && use256 && use192 && N % 256 == 0 && N >= 3072 && raw[0] > 0 && raw[0] <= raw[2]) out = 256;
     return out;
 }
 

@@ -240,7 +240,7 @@ def _bf16s_tile(M: int, N: int, K: int) -> tuple[int, int, int]:
     cands = ((192, 256, 1, 2, 0.90), (192, 128, 2, 2, 0.93), (128, 128, 2, 2, 1.0), (96, 128, 2, 1, 1.0), (64, 64, 4, 2, 1.12))
     best, tile, raw = None, (64, 64, 2), {}
     for bm, bn, per_cu, wgm, w in cands:
-        if bn == 256 and (not use256 or not use192 or N % 256 != 0 or K < 1536):
+        if bn == 256 and (not use256 or not use192 or N % 256 != 0 or (K < 1536 and N < 3072)):
             continue
         if (bm == 192 and not use192) or (bm == 96 and use192):
             continue
@@ -250,6 +250,8 @@ def _bf16s_tile(M: int, N: int, K: int) -> tuple[int, int, int]:
             best, tile = raw[(bm, bn)] * w, (bm, bn, wgm)
     if tile[:2] == (192, 128) and K < 1536 and raw[(128, 128)] <= raw[(192, 128)]:
         tile = (128, 128, 2)
+    if tile[:2] == (128, 128) and (192, 256) in raw and N >= 3072 and raw[(192, 256)] <= raw[(128, 128)]:
+        tile = (192, 256, 2)
     return tile
 
 
