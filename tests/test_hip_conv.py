@@ -188,3 +188,15 @@ def test_self_attention_still_matches_through_generic_entry(hip):
     o1, lse1 = hip.attn_fwd_packed(qkv, B, T, H, dh, dh**-0.5)
     o2, lse2 = hip.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, T, H, dh, dh**-0.5)
     assert torch.equal(o1, o2) and torch.equal(lse1, lse2)
+
+
+@pytest.mark.parametrize("B,C,H,W,Cout", [(32, 512, 26, 26, 512), (8, 192, 104, 104, 256)])
+def test_conv3x3_implicit_gemm_wide_tile(hip, B, C, H, W, Cout):
+    """Conv shapes that take the 192x256 8-wave tile (N % 256 == 0, K = 9C >= 1536)."""
+    from tunevlseg_amd.hip import _bf16s_tile
+
+    assert _bf16s_tile(B * H * W, Cout, 9 * C)[:2] == (192, 256)
+    x, w, b = rnd(B, C, H, W, seed=31), rnd(Cout, C, 3, 3, seed=32) * (9 * C) ** -0.5, rnd(Cout, seed=33)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    y = hip.conv3x3(dev(nhwc(x)), B, H, W, dev(w.permute(0, 2, 3, 1).reshape(Cout, 9 * C)), dev(b), hip.ACT_RELU)
+    close(nchw(y, B, H, W), ref, 2e-5, "conv3x3 wide tile")

@@ -386,3 +386,20 @@ def test_gemm_tn_split_k(hip, M, N, K):
     Cd = torch.full((M, N), 7.0, device="cuda")  # must be overwritten, not accumulated into
     hip.gemm(hip.TN, M, N, K, dev(A), M, dev(B), N, Cd, N)
     close(Cd, ref, 3e-6 * math.sqrt(K), "gemm TN split-K")
+
+
+@pytest.mark.parametrize("M,N,K", [(15840, 768, 3072), (15841, 3072, 100), (15840, 2304, 776), (40001, 256, 2304), (15840, 3072, 96)])
+def test_gemm_wide_tiles_with_epilogue(hip, M, N, K):
+    """Shapes that pick the 192x256 (8-wave) and 192x128 tiles, ragged in M and K, full epilogue incl. the post-residual order."""
+    from tunevlseg_amd.hip import _bf16s_tile
+
+    assert _bf16s_tile(M, N, K)[0] == 192
+    A, B, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    pre_ref = A.double() @ B.double().T + bias.double()
+    for post in (False, True):
+        ref = torch.relu(pre_ref + res.double()) if post else torch.relu(pre_ref) + res.double()
+        Cd, pre = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        hip.gemm(hip.NT, M, N, K, dev(A), K, dev(B), K, Cd, N, bias=dev(bias), act=hip.ACT_RELU | (hip.ACT_POST_RESIDUAL if post else 0),
+                 residual=dev(res), ldr=N, pre_out=pre)
+        close(Cd, ref, 3e-6 * math.sqrt(K), f"wide tile post={post}")
+        close(pre, pre_ref, 3e-6 * math.sqrt(K), "wide tile pre_out")
