@@ -70,6 +70,10 @@ int tvl_gemm_f32(const tvlGemmArgs* args, tvlStream_t stream);
  *   nsplit 2: 3 MFMAs, ~2^-16 relative per product;   nsplit 1: plain bf16 operands.
  */
 int tvl_gemm_bf16s(const tvlGemmArgs* args, int32_t nsplit, tvlStream_t stream);
+/* Skinny problems (few output tiles, deep K: the text towers' M = B*L-row GEMMs): the k-range is split over `splits`
+ * workgroups per output tile, partials go to `workspace` (>= splits*M*N floats) and are summed in a fixed order by a second
+ * kernel that applies the epilogue -- deterministic, 3-piece split only. */
+int tvl_gemm_bf16s_splitk(const tvlGemmArgs* args, int32_t splits, float* workspace, int64_t workspace_floats, tvlStream_t stream);
 
 /* LayerNorm over the last dim (nn.LayerNorm, eps 1e-5; HF:347,355,392,396).  mean/rstd may be NULL. */
 int tvl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -403,3 +403,22 @@ def test_gemm_wide_tiles_with_epilogue(hip, M, N, K):
                  residual=dev(res), ldr=N, pre_out=pre)
         close(Cd, ref, 3e-6 * math.sqrt(K), f"wide tile post={post}")
         close(pre, pre_ref, 3e-6 * math.sqrt(K), "wide tile pre_out")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 2048), (384, 512, 1536), (300, 130, 1100), (256, 2048, 1024)])
+def test_gemm_split_k_skinny(hip, M, N, K):
+    """Skinny, deep NT GEMMs take the deterministic split-K path (workspace partials + ordered reduction + epilogue)."""
+    A, B, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref_pre = A.double() @ B.double().T + bias.double()
+    ref = qgelu(ref_pre) + res.double()
+    outs = []
+    for _ in range(2):
+        Cd, pre = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        hip.gemm_profile_start()
+        hip.gemm(hip.NT, M, N, K, dev(A), K, dev(B), K, Cd, N, bias=dev(bias), act=hip.ACT_QUICK_GELU, residual=dev(res), ldr=N, pre_out=pre)
+        prof = hip.gemm_profile_stop()
+        assert any("splitk" in k for k in prof), prof.keys()
+        close(Cd, ref, 3e-6 * math.sqrt(K), "split-K")
+        close(pre, ref_pre, 3e-6 * math.sqrt(K), "split-K pre_out")
+        outs.append(Cd.clone())
+    assert torch.equal(outs[0], outs[1])  # fixed summation order: bitwise reproducible

@@ -457,6 +457,115 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmParams& p) {
     }
 }
 
+// Split-K variant of the 64x64 tile for skinny problems (few output tiles, deep K: the text tower's M = B*L-row GEMMs with
+// K = 1536 / 2048 walk 48-64 k-slabs serially on 32 workgroups, 55-73 us).  blockIdx.y owns a k-range and writes its raw
+// partial tile to a workspace [splits][M][N]; splitk_reduce_kernel sums the partials in a fixed order (deterministic) and
+// applies the epilogue.
+template <int S, bool VEC>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16s_splitk_kernel(GemmParams p, float* __restrict__ ws, int kchunk) {
+    constexpr int BM = 64, BN = 64, BK = 32, WGN = 2, WM = 32, WN = 32;
+    constexpr int LDB = BK + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+    const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = kbeg + kchunk < p.K ? kbeg + kchunk : p.K;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    StageRegs<BM, BK> sa;
+    StageRegs<BN, BK> sb;
+    const tvlRowMap ident = {0, 0, 0};
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, kbeg, kend, p.a_map);
+    gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, kbeg, kend, ident);
+    sstore<BM, BK, S>(sa, smem);
+    sstore<BN, BK, S>(sb, smem + S * BM * LDB);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const __bf16* As = smem;
+        const __bf16* Bs = As + S * BM * LDB;
+        if (kt + 1 < nk) {
+            gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, p.a_map);
+            gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, ident);
+        }
+        bf16x8 af[2][S], bf[2][S];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                af[ks][s] = *reinterpret_cast<const bf16x8*>(&As[(s * BM + wm * WM + l31) * LDB + ks * 16 + 8 * h]);
+                bf[ks][s] = *reinterpret_cast<const bf16x8*>(&Bs[(s * BN + wn * WN + l31) * LDB + ks * 16 + 8 * h]);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int order = S - 1; order >= 0; --order)
+#pragma unroll
+                for (int sa_ = 0; sa_ <= order; ++sa_)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][order - sa_], af[ks][sa_], acc, 0, 0, 0);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            sstore<BM, BK, S>(sa, smem);
+            sstore<BN, BK, S>(sb, smem + S * BM * LDB);
+        }
+        __syncthreads();
+    }
+    // raw partial: lane -> row l31, registers 4g..4g+3 -> columns 8g+4h..+3 (transposed product)
+    float* wp = ws + (long)blockIdx.y * p.M * p.N;
+    const int row = m0 + wm * WM + l31;
+    if (row < p.M) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = n0 + wn * WN + 8 * g + 4 * h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < p.N) wp[(long)row * p.N + col + e] = acc[4 * g + e];
+        }
+    }
+}
+
+// C[map(m), n] = epilogue(alpha * sum_s ws[s][m][n]): same epilogue order as the GEMM kernels
+__global__ void splitk_reduce_kernel(GemmParams p, const float* __restrict__ ws, int splits) {
+    const long total = (long)p.M * p.N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % p.N);
+        const int row = (int)(i / p.N);
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += ws[(long)s * total + i];
+        const long crow = map_row(row, p.c_map);
+        v = v * p.alpha + (p.bias ? p.bias[col] : 0.f);
+        if (p.dact) v *= dact_f(p.dact_aux[crow * p.ld_aux + col], p.dact);
+        if (p.pre_out) p.pre_out[crow * p.ldc + col] = v;
+        const bool post = (p.act & TVL_ACT_POST_RESIDUAL) != 0;
+        if (post && p.residual) v += p.residual[crow * p.ldr + col];
+        v = act_f(v, p.act & 0xff);
+        if (!post && p.residual) v += p.residual[crow * p.ldr + col];
+        p.C[crow * p.ldc + col] = v;
+    }
+}
+
+template <int S, bool VEC>
+int launch_splitk(const GemmParams& p0, float* ws, int splits, hipStream_t s) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + 63) / 64;
+    p.tiles_n = (p.N + 63) / 64;
+    const int kchunk = ((p.K + splits - 1) / splits + 31) / 32 * 32;
+    const int real_splits = (p.K + kchunk - 1) / kchunk;
+    constexpr size_t smem = (size_t)S * 128 * 40 * sizeof(__bf16);
+    hipLaunchKernelGGL((gemm_bf16s_splitk_kernel<S, VEC>), dim3((unsigned)(p.tiles_m * p.tiles_n), (unsigned)real_splits), dim3(NTHREADS), smem, s,
+                       p, ws, kchunk);
+    const long total = (long)p.M * p.N;
+    long nb = (total + 255) / 256;
+    nb = nb > 65536 ? 65536 : nb;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, p, (const float*)ws, real_splits);
+    return 0;
+}
+
 template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
     gemm_bf16s_body<BM, BN, WGM, S, VEC, BK, STAGES, CONV>(p);

@@ -81,6 +81,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _SIGS = {
     "tvl_gemm_f32": [C.POINTER(GemmArgs)],
     "tvl_gemm_bf16s": [C.POINTER(GemmArgs), _I],
+    "tvl_gemm_bf16s_splitk": [C.POINTER(GemmArgs), _I, _P, _L],
     "tvl_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F],
     "tvl_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
     "tvl_attn_fwd": [C.POINTER(AttnFwdArgs)],
@@ -201,6 +202,7 @@ GEMM_MODE = os.environ.get("TVL_GEMM_MODE", "bf16x6")
 # How the bf16x6 GEMM gets its bf16 pieces: "inkernel" = split while staging the tile (gemm_bf16s.hip);
 # "planes" = operands pre-split into three bf16 planes (frozen weights once, activations by a one-pass kernel), LDS-DMA fill
 GEMM_IMPL = os.environ.get("TVL_GEMM_IMPL", "inkernel")
+SPLITK = os.environ.get("TVL_GEMM_SPLITK", "1") != "0"  # deterministic split-K for skinny, deep GEMMs
 _NSPLIT = {"bf16x6": 3, "bf16x3": 2, "bf16": 1}
 
 
@@ -309,6 +311,19 @@ def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias
                     _p(bias), _ps(residual) if (residual is not None and residual.dim() == 2) else _p(residual), ldr, act, _p(pre_out),
                     _p(dact_aux), ld_aux, dact, alpha, a_map or _ident(), c_map or _ident())
     split = _NSPLIT.get(GEMM_MODE, 0) if (layout == NT and M >= 256) else 0
+    # skinny and deep (text-tower GEMMs: a few dozen 64x64 tiles, 48-64 k-slabs each): split K over more workgroups
+    tiles64 = ((M + 63) // 64) * ((N + 63) // 64)
+    if split == 3 and SPLITK and tiles64 <= 256 and K >= 1024:
+        splits = min(8, K // 256)
+        ws = torch.empty(splits * M * N, device=Cout.device, dtype=torch.float32)
+        if _gemm_prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _call("tvl_gemm_bf16s_splitk", C.byref(args), splits, _p(ws), ws.numel())
+        if _gemm_prof is not None:
+            e1.record()
+            _gemm_prof.append(("gemm_bf16s_splitk_kernel<3, true>", 2.0 * M * N * K, e0, e1))
+        return Cout
     if _gemm_prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
