@@ -220,7 +220,7 @@ def main():
         # HBM bytes per launch of that kernel from the PMC passes recorded in profiles/ (rocprofv3 --pmc FETCH_SIZE, then
         # WRITE_SIZE, each in its own run; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM)
         traffic = None
-        tf = ROOT / "profiles" / ("r1_j_cris_hbm_traffic.json" if cris else "r1_j_hbm_traffic.json")
+        tf = ROOT / "profiles" / ("r1_k_cris_hbm_traffic.json" if cris else "r1_k_hbm_traffic.json")
         if tf.exists() and not maple:
             rec = json.loads(tf.read_text()).get(name)
             traffic = rec["hbm_bytes_per_launch"] if rec else None
