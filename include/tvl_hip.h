@@ -218,14 +218,39 @@ int tvl_im2col3x3(const float* x, int64_t sb, int64_t sy, int64_t sx, int64_t sc
 typedef struct { int32_t B, H, W, C, stride; } tvlConvGeom;
 int tvl_conv3x3_bf16s(const tvlGemmArgs* args, const tvlConvGeom* geom, int32_t nsplit, tvlStream_t stream);
 /*
- * The split-bf16 GEMM over PRE-SPLIT operands: x = p0 + p1 + p2 as three bf16 planes [3][rows][ldp] (ldp % 32 == 0, columns
- * >= cols zero), made once for frozen weights and by one pass (or the producing kernel) for activations.  The GEMM then fills
- * LDS by DMA and spends no VALU on splitting; results equal tvl_gemm_bf16s(nsplit 3) up to fp32 summation order.
- * tvl_gemm_planes: args->A / args->B point at plane 0 of bf16 data, lda / ldb in bf16 elements; same epilogue contract as
- * tvl_gemm_f32.  conv != NULL: implicit 3x3 / pad 1 conv over NHWC planes (args->K = 9*C, C % 8 == 0), as tvl_conv3x3_bf16s.
+ * "tp3": an fp32 matrix X[R, K] (K % 16 == 0) handed over as three bf16 pieces per element, x = p0 + p1 + p2 (p0, p1 by
+ * truncating the running residual, p2 rounded: all 24 significand bits), stored in MFMA-fragment order:
+ *   block (rb, kb) = rows 32*rb..+31, k = 16*kb..+15 at byte ((rb * K/16 + kb) * 3 + piece) * 1024,
+ *   element (r, k) inside a piece at ((k % 16) / 8 * 32 + r % 32) * 16 + (k % 8) * 2;   rows are padded to a multiple of 32.
+ * Frozen weights are packed once (tvl_tp3_pack); activations are written in this form by their producer (LayerNorm,
+ * attention, the GEMM epilogue below), so the consumer GEMM fills LDS by DMA and spends nothing on splitting.
+ * tvl_tp3_bytes: size of the image; tvl_tp3_unpack: back to fp32 (tests / debugging).
  */
-int tvl_split_planes(const float* x, int32_t ldx, int64_t rows, int32_t cols, void* planes, int64_t plane_stride, int32_t ldp, tvlStream_t stream);
-int tvl_gemm_planes(const tvlGemmArgs* args, int64_t a_plane_stride, int64_t b_plane_stride, const tvlConvGeom* conv, tvlStream_t stream);
+int64_t tvl_tp3_bytes(int64_t rows, int32_t K);
+int tvl_tp3_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, tvlStream_t stream);
+int tvl_tp3_unpack(const void* in, int64_t rows, int32_t K, float* y, int64_t ldy, tvlStream_t stream);
+/*
+ * C[M,N] = epilogue(alpha * A . B^T) with A = tp3 image of [a_rows >= M, K] and B = tp3 image of [b_rows >= N, K]
+ * (nn.Linear forward with the weight as stored, HF modeling_clipseg.py:290-292,333,352-354; its data gradient with the
+ * transposed weight packed once).  Same epilogue contract and order as tvl_gemm_f32 (no row maps; pre_out shares ldc).
+ * Outputs: C (fp32, may be NULL) and / or C_tp3, the tp3 image of the final value as the next GEMM's A operand [M, N].
+ * K % 16 == 0, N % 16 == 0.  tile_m: 0 = choose, else 128 | 192 | 256 rows per workgroup; variant: scheduling A/B switch.
+ */
+typedef struct {
+    int32_t M, N, K;
+    const void* A; int64_t a_rows;
+    const void* B; int64_t b_rows;
+    float* C; int32_t ldc;
+    void* C_tp3;
+    const float* bias;
+    const float* residual; int32_t ldr;
+    int32_t act;
+    float* pre_out;
+    const float* dact_aux; int32_t ld_aux; int32_t dact;
+    float alpha;
+    int32_t tile_m, variant;
+} tvlGemmTp3Args;
+int tvl_gemm_tp3(const tvlGemmTp3Args* args, tvlStream_t stream);
 /* nn.AvgPool2d(k) / F.avg_pool2d(x, k, k) on [B,H,W,C] (H, W divisible by k) and its gradient (H, W = input sizes) */
 int tvl_avgpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);
 int tvl_avgpool_bwd(const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);

@@ -38,6 +38,7 @@ sys.path.insert(0, str(REFERENCE))
 from tunevlseg_amd.config import CLIPSegConfig  # noqa: E402
 from tunevlseg_amd.cris_config import CRISConfig  # noqa: E402
 from tunevlseg_amd.weights import init_clipseg_state_dict, init_cris_state_dict  # noqa: E402
+from tests.golden_util import synth_cris_inputs, synth_inputs  # noqa: E402  (input recipes shared with the tests)
 
 OUT = Path(__file__).resolve().parent
 
@@ -135,30 +136,25 @@ def state_checksum(sd) -> float:
 
 
 # ----------------------------------------------------------------------------
-def synth_inputs(cfg: CLIPSegConfig, B: int, H: int, L: int, seed: int, pad: bool = True):
-    """img N(0,1); ids rows padded to L; mask = U(0,1) > 0.7."""
-    g = torch.Generator().manual_seed(seed)
-    t = cfg.text_config
-    pix = torch.randn(B, 3, H, H, generator=g)
-    ids = torch.full((B, L), t.pad_token_id, dtype=torch.long)
-    am = torch.zeros(B, L, dtype=torch.long)
-    eos = 49407 if t.vocab_size > 49407 else t.vocab_size - 1
-    if t.eos_token_id != 2:
-        eos = t.eos_token_id
-    for b in range(B):
-        n_words = (L - 2) if not pad else max(1, L - 2 - (b % 3) - (1 if B == 1 else 0))
-        words = torch.randint(2, min(t.vocab_size - 2, 40000), (n_words,), generator=g)
-        if t.eos_token_id != 2:
-            words = words.masked_fill(words == t.eos_token_id, 3)
-        row = [t.bos_token_id, *words.tolist(), eos]
-        ids[b, : len(row)] = torch.tensor(row)
-        am[b, : len(row)] = 1
-    mask = (torch.rand(B, 1, H, H, generator=g) > 0.7).float()
-    return pix, ids, am, mask
+
+
+def compact_outputs(logits, mask):
+    """What a full-batch fixture keeps instead of the 16 MB logit map: every 11th pixel, and the integer / per-sample
+    statistics of the reference's own logits (plain counting of ``sigmoid(logits) > 0.5`` against ``mask.long()``)."""
+    lab = (torch.sigmoid(logits.detach()) > 0.5).flatten(1)
+    tgt = mask.long().flatten(1).bool()
+    tp, fp = (lab & tgt).sum(1), (lab & ~tgt).sum(1)
+    fn, tn = (~lab & tgt).sum(1), (~lab & ~tgt).sum(1)
+    den = (2 * tp + fp + fn).double()
+    dice = torch.where(den > 0, 2 * tp.double() / den.clamp(min=1), torch.ones_like(den))
+    return {"out.logits_s11": logits.detach()[..., ::11, ::11].contiguous().numpy(),
+            "out.counts": torch.stack((tp, fp, fn, tn), 1).numpy(), "out.dice_per_sample": dice.numpy(),
+            "out.logits_absmax": logits.detach().abs().amax().numpy(),
+            "out.min_abs_logit": logits.detach().abs().amin().numpy()}
 
 
 def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, learner_kw: dict, net_kw: dict,
-             B: int, H: int, L: int, iseed: int, M):
+             B: int, H: int, L: int, iseed: int, M, compact: bool = False):
     from src.models.components.hf_clipseg_wrapper import HFCLIPSegWrapper
     from src.models.core_models import coop as R
     from src.models.core_models.coop import context_learner as CL
@@ -206,8 +202,11 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
     loss = dice_ce_loss(logits, mask)
     loss.backward()
 
-    arrays = {"in.pixel_values": pix.numpy(), "in.input_ids": ids.numpy(), "in.attention_mask": am.numpy(),
-              "in.mask": mask.numpy(), "out.logits": logits.detach().numpy(), "out.loss": loss.detach().numpy()}
+    if compact:  # inputs are re-drawn from the seed by the test (tests/golden_util.py synth_inputs)
+        arrays = {"out.loss": loss.detach().numpy(), **compact_outputs(logits, mask)}
+    else:
+        arrays = {"in.pixel_values": pix.numpy(), "in.input_ids": ids.numpy(), "in.attention_mask": am.numpy(),
+                  "in.mask": mask.numpy(), "out.logits": logits.detach().numpy(), "out.loss": loss.detach().numpy()}
     grads_none = []
     for k, p in params.items():
         arrays["param." + k] = p.detach().numpy()
@@ -215,7 +214,7 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
             grads_none.append(k)
         else:
             arrays["grad." + k] = p.grad.numpy()
-    meta = {"name": name, "preset": preset, "eos_token_id": eos, "weight_seed": wseed, "net": net_kind,
+    meta = {"name": name, "compact": compact, "preset": preset, "eos_token_id": eos, "weight_seed": wseed, "net": net_kind,
             "learner_kw": {k: v for k, v in learner_kw.items()}, "net_kw": net_kw, "B": B, "H": H, "L": L,
             "input_seed": iseed, "weights_checksum": state_checksum(sd), "grads_none": grads_none,
             "torch": torch.__version__}
@@ -226,27 +225,10 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
           f"grads {[(k, float(p.grad.abs().max())) for k, p in params.items() if p.grad is not None][:3]} none={grads_none}")
 
 
-def synth_cris_inputs(cfg: CRISConfig, B: int, L: int, seed: int, with_attention_mask: bool):
-    """img N(0,1) at cfg.img_size; ids = [BOS, words, EOS(highest id), 0-pads]; CRIS derives its pad mask either from
-    the attention mask or from ``ids == 0`` (cris_model/__init__.py:79-86) -- both branches are exercised."""
-    g = torch.Generator().manual_seed(seed)
-    H = cfg.img_size
-    pix = torch.randn(B, 3, H, H, generator=g)
-    ids = torch.zeros(B, L, dtype=torch.long)
-    am = torch.zeros(B, L, dtype=torch.long)
-    eos, bos = cfg.vocab_size - 1, cfg.vocab_size - 2
-    for b in range(B):
-        n_words = max(1, L - 2 - (b % 3) - (1 if B == 1 else 0))
-        words = torch.randint(1, min(cfg.vocab_size - 2, 40000), (n_words,), generator=g)
-        row = [bos, *words.tolist(), eos]
-        ids[b, : len(row)] = torch.tensor(row)
-        am[b, : len(row)] = 1
-    mask = (torch.rand(B, 1, H, H, generator=g) > 0.7).float()
-    return pix, ids, (am if with_attention_mask else None), mask
 
 
 def run_cris_case(name: str, *, preset: str, wseed: int, learner_kind: str, learner_kw: dict, net_kw: dict,
-                  B: int, L: int, iseed: int, with_attention_mask: bool = True, img_size: int | None = None):
+                  B: int, L: int, iseed: int, with_attention_mask: bool = True, img_size: int | None = None, compact: bool = False):
     """COOPCRIS (reference coop_cris.py) with seeded random weights: ``CRIS.get_backbone`` (which wants pretrain/RN50.pt)
     is replaced by a local ``CLIP(...)`` constructor of the same geometry."""
     if ONLY and not any(name.startswith(o) for o in ONLY):
@@ -309,10 +291,13 @@ def run_cris_case(name: str, *, preset: str, wseed: int, learner_kind: str, lear
     logits = net(text_input=text_input, image_input=pix)
     loss = dice_ce_loss(logits, mask)
     loss.backward()
-    arrays = {"in.pixel_values": pix.numpy(), "in.input_ids": ids.numpy(), "in.mask": mask.numpy(),
-              "out.logits": logits.detach().numpy(), "out.loss": loss.detach().numpy()}
-    if am is not None:
-        arrays["in.attention_mask"] = am.numpy()
+    if compact:
+        arrays = {"out.loss": loss.detach().numpy(), **compact_outputs(logits, mask)}
+    else:
+        arrays = {"in.pixel_values": pix.numpy(), "in.input_ids": ids.numpy(), "in.mask": mask.numpy(),
+                  "out.logits": logits.detach().numpy(), "out.loss": loss.detach().numpy()}
+        if am is not None:
+            arrays["in.attention_mask"] = am.numpy()
     grads_none = []
     for k, p in params.items():
         arrays["param." + k] = p.detach().numpy()
@@ -320,7 +305,8 @@ def run_cris_case(name: str, *, preset: str, wseed: int, learner_kind: str, lear
             grads_none.append(k)
         else:
             arrays["grad." + k] = p.grad.numpy()
-    meta = {"name": name, "family": "cris", "preset": preset, "weight_seed": wseed, "net": learner_kind,
+    meta = {"name": name, "family": "cris", "compact": compact, "with_attention_mask": with_attention_mask, "preset": preset,
+            "weight_seed": wseed, "net": learner_kind,
             "learner_kw": dict(learner_kw), "net_kw": net_kw, "B": B, "L": L, "img_size": cfg.img_size,
             "input_seed": iseed, "weights_checksum": state_checksum(sd), "grads_none": grads_none, "torch": torch.__version__}
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
@@ -389,6 +375,31 @@ def main():
              learner_kw=dict(prompt_depth=9, num_context=4, vector_std=0.02, use_unified_projection=False,
                              intermediate_dim=64, use_proj_norm=True, use_lora_proj=False), net_kw=base_new, **F_)
 
+    # --- unfrozen last transposed conv (row A2, base_clipseg.py:74-80) ---------------------------------------------
+    run_case("tiny_vpt_n4_d2_nofreeze_last", eos=2, wseed=11, net_kind="vpt", iseed=14,
+             learner_kw=dict(prompt_depth=2, num_context=4, vector_std=0.02),
+             net_kw=dict(use_new_last_layer=False, no_freeze_last_layer=True), **T)
+    run_case("tiny_maple_d2_nofreeze_last", eos=2, wseed=11, net_kind="maple", iseed=15,
+             learner_kw=dict(prompt_depth=2, num_context=2, vector_std=0.02, use_unified_projection=False,
+                             intermediate_dim=8, use_proj_norm=True, use_lora_proj=False),
+             net_kw=dict(use_new_last_layer=False, no_freeze_last_layer=True), **T)
+    # --- ends of the Optuna ranges (prompt_depth 1-10, intermediate_dim 32-128, LoRA on/off), B=1 -------
+    run_case("rd64_vpt_n10_d10", eos=2, wseed=21, net_kind="vpt", iseed=24,
+             learner_kw=dict(prompt_depth=10, num_context=10, vector_std=0.02), net_kw=base_old, **F_)
+    run_case("rd64_maple_n4_d10_i32_lora", eos=2, wseed=21, net_kind="maple", iseed=25,
+             learner_kw=dict(prompt_depth=10, num_context=4, vector_std=0.02, use_unified_projection=False,
+                             intermediate_dim=32, use_proj_norm=False, use_lora_proj=True), net_kw=base_new, **F_)
+    run_case("rd64_cocoop_n4_d10_i128", eos=2, wseed=21, net_kind="cocoop", iseed=26,
+             learner_kw=dict(prompt_depth=10, num_context=4, vector_std=0.02, use_unified_projection=False,
+                             intermediate_dim=128, use_proj_norm=True, use_lora_proj=False, norm_image_features=True),
+             net_kw=base_old, **F_)
+    # --- BASELINE configs[1] exactly: VPT-10 shallow, 352x352, B = 32 (seed 1).  Compact fixture: the inputs
+    # are re-drawn from the seed; kept are loss, the 7 680-float prompt gradient, per-sample integer counts / Dice and
+    # every 11th logit.  This is the case whose M = 15 840 rows select the large GEMM tiles of the benchmarked step.
+    FB = dict(preset="rd64", B=32, H=352, L=8, M=M, compact=True)
+    run_case("rd64_vpt_n10_d1_b32", eos=2, wseed=21, net_kind="vpt", iseed=1,
+             learner_kw=dict(prompt_depth=1, num_context=10, vector_std=0.02), net_kw=base_old, **FB)
+
     # --- CRIS (BASELINE configs[2]; reference coop_cris.py) ---------------------------------------------------------
     init = dict(context_initializer="a photo of a", _init_ids=[5, 9, 7, 5])
     run_cris_case("cris_tiny_coop_n4_d1", preset="tiny", wseed=31, learner_kind="coop", iseed=31, B=2, L=7,
@@ -410,6 +421,12 @@ def main():
                   learner_kw=dict(prompt_depth=1, num_context=4, vector_std=0.02, use_unified_projection=False,
                                   intermediate_dim=64, use_proj_norm=True, use_lora_proj=False, norm_image_features=False,
                                   context_initializer="a photo of a", _init_ids=[320, 1125, 539, 320]), net_kw=base_new)
+    # BASELINE configs[2] geometry at B = 8 (compact): large-M implicit-conv tiles
+    run_cris_case("cris_rn50_cocoop_n4_d1_newlast_b8", preset="rn50", wseed=41, learner_kind="cocoop", iseed=2, B=8, L=8,
+                  learner_kw=dict(prompt_depth=1, num_context=4, vector_std=0.02, use_unified_projection=False,
+                                  intermediate_dim=64, use_proj_norm=True, use_lora_proj=False, norm_image_features=False,
+                                  context_initializer="a photo of a", _init_ids=[320, 1125, 539, 320]), net_kw=base_new,
+                  compact=True)
 
 
 if __name__ == "__main__":

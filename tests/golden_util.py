@@ -147,3 +147,45 @@ def cris_new_last_of(params):
         return None
     return {"w1": params["additive_decoder_layer.0.weight"], "w": params["additive_decoder_layer.2.weight"],
             "b": params["additive_decoder_layer.2.bias"], "ratio": params["residual_ratio"]}
+
+
+# ---- seeded synthetic inputs; the compact full-batch fixtures store only the seed ----------------------
+def synth_inputs(cfg: CLIPSegConfig, B: int, H: int, L: int, seed: int, pad: bool = True):
+    """img N(0,1); ids rows padded to L; mask = U(0,1) > 0.7."""
+    g = torch.Generator().manual_seed(seed)
+    t = cfg.text_config
+    pix = torch.randn(B, 3, H, H, generator=g)
+    ids = torch.full((B, L), t.pad_token_id, dtype=torch.long)
+    am = torch.zeros(B, L, dtype=torch.long)
+    eos = 49407 if t.vocab_size > 49407 else t.vocab_size - 1
+    if t.eos_token_id != 2:
+        eos = t.eos_token_id
+    for b in range(B):
+        n_words = (L - 2) if not pad else max(1, L - 2 - (b % 3) - (1 if B == 1 else 0))
+        words = torch.randint(2, min(t.vocab_size - 2, 40000), (n_words,), generator=g)
+        if t.eos_token_id != 2:
+            words = words.masked_fill(words == t.eos_token_id, 3)
+        row = [t.bos_token_id, *words.tolist(), eos]
+        ids[b, : len(row)] = torch.tensor(row)
+        am[b, : len(row)] = 1
+    mask = (torch.rand(B, 1, H, H, generator=g) > 0.7).float()
+    return pix, ids, am, mask
+
+
+def synth_cris_inputs(cfg: CRISConfig, B: int, L: int, seed: int, with_attention_mask: bool):
+    """img N(0,1) at cfg.img_size; ids = [BOS, words, EOS(highest id), 0-pads]; CRIS derives its pad mask either from
+    the attention mask or from ``ids == 0`` (cris_model/__init__.py:79-86) -- both branches are exercised."""
+    g = torch.Generator().manual_seed(seed)
+    H = cfg.img_size
+    pix = torch.randn(B, 3, H, H, generator=g)
+    ids = torch.zeros(B, L, dtype=torch.long)
+    am = torch.zeros(B, L, dtype=torch.long)
+    eos, bos = cfg.vocab_size - 1, cfg.vocab_size - 2
+    for b in range(B):
+        n_words = max(1, L - 2 - (b % 3) - (1 if B == 1 else 0))
+        words = torch.randint(1, min(cfg.vocab_size - 2, 40000), (n_words,), generator=g)
+        row = [bos, *words.tolist(), eos]
+        ids[b, : len(row)] = torch.tensor(row)
+        am[b, : len(row)] = 1
+    mask = (torch.rand(B, 1, H, H, generator=g) > 0.7).float()
+    return pix, ids, (am if with_attention_mask else None), mask

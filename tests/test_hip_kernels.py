@@ -359,23 +359,48 @@ def test_small_reductions(hip):
     assert torch.allclose(t.cpu(), torch.full((100,), 3.5))
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 200, 100), (1000, 768, 768), (4100, 2048, 96), (15840, 768, 3072), (777, 130, 36), (256, 64, 8)])
-def test_gemm_presplit_planes(hip, M, N, K):
-    """tvl_split_planes is exact (p0 + p1 + p2 == x in fp32) and tvl_gemm_planes matches the fp64 product like bf16x6 does."""
+@pytest.mark.parametrize("rows,cols", [(32, 16), (100, 64), (15840, 768), (77, 512)])
+def test_tp3_pack_is_exact(hip, rows, cols):
+    """x == p0 + p1 + p2 in fp32 for every element (three bf16 pieces carry all 24 significand bits); padded rows are zero."""
+    x = dev(rnd(rows, cols, seed=7) * torch.logspace(-3, 3, cols))
+    img = hip.tp3_pack(x)
+    assert img.buf.numel() == hip.load().tvl_tp3_bytes(rows, cols)
+    assert torch.equal(img.float(), x)
+    wide = dev(rnd(rows, cols + 24, seed=8))  # a column slice of a wider matrix (row stride != cols)
+    assert torch.equal(hip.tp3_pack(wide[:, 8:8 + cols]).float(), wide[:, 8:8 + cols])
+
+
+@pytest.mark.parametrize("tile", [0, 128, 192, 256])
+@pytest.mark.parametrize("M,N,K", [(15840, 768, 3072), (1000, 768, 768), (15840, 2304, 768), (333, 80, 64), (4100, 2048, 96), (192, 256, 64)])
+def test_gemm_tp3(hip, M, N, K, tile):
+    """tvl_gemm_tp3 (LDS-DMA ring over pre-tiled bf16 pieces) against the fp64 product, full epilogue, ragged M / N, both
+    outputs (fp32 and the tp3 image the next GEMM consumes), every tile height and both schedule variants."""
     A, B, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
-    Ad, Bd = dev(A), dev(B)
-    planes = hip.split_planes(Ad)
-    back = planes[0].float() + planes[1].float() + planes[2].float()
-    assert torch.equal(back[:, :K], Ad) and (K % 32 == 0 or back[:, K:].abs().max() == 0)
-    ref = torch.relu(A.double() @ B.double().T + bias.double()) + res.double()
-    Cd = torch.empty(M, N, device="cuda")
-    old = hip.GEMM_IMPL
-    hip.GEMM_IMPL = "planes"
+    At, Bt = hip.tp3_pack(dev(A)), hip.tp3_pack(dev(B))
+    pre_ref = A.double() @ B.double().T + bias.double()
+    ref = qgelu(pre_ref) + res.double()
+    old = hip.GEMM_TP3_TILE, hip.GEMM_TP3_VARIANT
     try:
-        hip.gemm(hip.NT, M, N, K, Ad, K, Bd, K, Cd, N, bias=dev(bias), act=hip.ACT_RELU, residual=dev(res), ldr=N)
+        hip.GEMM_TP3_TILE = tile
+        for variant in ((0, 1, 2) if tile in (0, 192) else (0,)):
+            hip.GEMM_TP3_VARIANT = variant
+            pre = torch.empty(M, N, device="cuda")
+            Cf, Ct = hip.gemm_tp3(At, Bt, want_tp3=True, bias=dev(bias), residual=dev(res), act=hip.ACT_QUICK_GELU, pre_out=pre)
+            close(Cf, ref, 3e-6 * math.sqrt(K), f"gemm_tp3 tile {tile} variant {variant}")
+            close(pre, pre_ref, 3e-6 * math.sqrt(K), "gemm_tp3 pre_out")
+            assert torch.equal(Ct.float(), Cf)  # the tp3 output is the exact split of the fp32 output
+        # tp3-only output feeding a second GEMM; act' epilogue (the dz of the backward)
+        z = dev(rnd(M, N, seed=5))
+        _, dz = hip.gemm_tp3(At, Bt, want_f32=False, want_tp3=True, dact=hip.ACT_QUICK_GELU, dact_aux=z)
+        s = torch.sigmoid(1.702 * z.double().cpu())
+        dref = (A.double() @ B.double().T) * (s + 1.702 * z.double().cpu() * s * (1 - s))
+        close(dz.float(), dref, 3e-6 * math.sqrt(K), "gemm_tp3 dact -> tp3")
+        if N % 32 == 0 and N >= 64:
+            W2 = rnd(48, N, seed=6)
+            C2, _ = hip.gemm_tp3(dz, hip.tp3_pack(dev(W2)))
+            close(C2, dref @ W2.double().T, 3e-6 * math.sqrt(K) * math.sqrt(N), "gemm_tp3 chained")
     finally:
-        hip.GEMM_IMPL = old
-    close(Cd, ref, 3e-6 * math.sqrt(K), "gemm planes")
+        hip.GEMM_TP3_TILE, hip.GEMM_TP3_VARIANT = old
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 25, 21632), (64, 64, 5000), (130, 25, 15488), (32, 8, 100000)])

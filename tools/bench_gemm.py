@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """GEMM micro-benchmark on the ViT-B/16 shapes of the hot path (M = 32*495 = 15840). Interleaved rounds, HIP events."""
+import os
 import sys
 from pathlib import Path
 
@@ -16,11 +17,16 @@ if len(sys.argv) > 1 and sys.argv[1] != "f32":  # split-bf16 runs data gradients
     SHAPES = [(n.replace("NN", "NT"), hip.NT, m, nn_, k) for n, _, m, nn_, k in SHAPES]
 
 
+TP3 = len(sys.argv) > 1 and sys.argv[1].startswith("tp3")
+
+
 def main():
     hip.load()
     if len(sys.argv) > 1:
-        if sys.argv[1] in ("planes", "planes-only"):
-            hip.GEMM_IMPL = "planes"
+        if sys.argv[1].startswith("tp3"):  # tp3 | tp3:<tile>:<variant>
+            parts = sys.argv[1].split(":")
+            hip.GEMM_TP3_TILE = int(parts[1]) if len(parts) > 1 else 0
+            hip.GEMM_TP3_VARIANT = int(parts[2]) if len(parts) > 2 else hip.GEMM_TP3_VARIANT
         else:
             hip.set_gemm_mode(sys.argv[1])
     print("mode", hip.GEMM_MODE)
@@ -29,10 +35,12 @@ def main():
     for name, layout, m, n, k in SHAPES:
         A = torch.randn(m, k, device="cuda")
         B = torch.randn(n, k, device="cuda") if layout == hip.NT else torch.randn(k, n, device="cuda")
+        if os.environ.get("TVL_BENCH_ZERO"):  # DVFS probe: zero operands let the chip hold a higher clock (guide rule 25)
+            A.zero_(), B.zero_()
         hip.mark_frozen(B)
-        if len(sys.argv) > 1 and sys.argv[1] == "planes-only":  # GEMM kernel alone: A planes made once, outside the timing
-            hip.mark_frozen(A)
         C = torch.empty(m, n, device="cuda")
+        if TP3:  # operands handed over pre-tiled (activations by their producer, weights once)
+            A, B = hip.tp3_pack(A), hip.tp3_pack(B)
         bufs[name] = (A, B, C)
     rounds = 5
     times = {s[0]: [] for s in SHAPES}
@@ -42,7 +50,10 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                hip.gemm(layout, m, n, k, A, A.shape[1], B, B.shape[1], C, n)
+                if TP3:
+                    hip.gemm_tp3(A, B, out=C)
+                else:
+                    hip.gemm(layout, m, n, k, A, A.shape[1], B, B.shape[1], C, n)
             e1.record()
             torch.cuda.synchronize()
             if r:
@@ -54,7 +65,8 @@ def main():
         if not name.startswith("sq"):
             tot_f += fl
             tot_t += t
-        print(f"{name} M={m} N={n} K={k}: {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TF/s  {hip.gemm_kernel_key(layout, m, n, True, hip._NSPLIT.get(hip.GEMM_MODE, 0), k)}")
+        key = f"gemm_tp3<{hip.tp3_tile(m, n)},256,{hip.GEMM_TP3_VARIANT}>" if TP3 else hip.gemm_kernel_key(layout, m, n, True, hip._NSPLIT.get(hip.GEMM_MODE, 0), k)
+        print(f"{name} M={m} N={n} K={k}: {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TF/s  {key}")
     print(f"layer GEMMs total: {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TF/s")
 
 

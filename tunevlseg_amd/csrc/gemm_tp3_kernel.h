@@ -1,0 +1,427 @@
+// fp32-equivalent GEMM over operands that already live in HBM as three bf16 pieces, in fragment order ("tp3" format).
+// gfx950: LDS-DMA ring (global_load_lds_dwordx4, counted vmcnt, raw s_barrier) + v_mfma_f32_32x32x16_bf16.
+//
+// Why a second GEMM.  gemm_bf16s_kernel.h splits fp32 operands into bf16 pieces while it stages a tile: ~5 VALU per MFMA,
+// ds_write fills and two barriers per k-step, with nothing overlapping the fill (profiles/r1_gemm_experiments.md: matrix
+// pipe 42 % busy).  The vision tower's eight GEMMs per layer always have a frozen weight on one side and an activation that
+// one of our own kernels has just produced on the other, so both sides can be handed over pre-split and PRE-TILED:
+//
+//   tp3 image of a logical fp32 matrix X[R, K] (K % 16 == 0), R rounded up to 32-row blocks:
+//     block (rb, kb) = rows 32 rb .. 32 rb + 31, k = 16 kb .. 16 kb + 15, at byte ((rb * K/16 + kb) * 3 + piece) * 1024
+//     inside a piece: element (r, k) at ((k % 16) / 8 * 32 + r % 32) * 16 + (k % 8) * 2        (bf16)
+//   x = piece0 + piece1 + piece2 (pieces 0, 1 by truncating the running residual, piece 2 rounded): 24 significand bits.
+//
+// One 1-KiB piece is exactly the A (or B) operand of one v_mfma_f32_32x32x16_bf16 in lane order (lane l = row l & 31,
+// k = 8 (l >> 5) .. + 7, guide §3): the LDS image equals the HBM image, an LDS-DMA instruction copies one piece (fully
+// coalesced, no swizzle needed), and a fragment read is ds_read_b128 at lane * 16 -- conflict free by construction.
+//
+// Kernel: 512 threads = 8 waves (2 x 4), tile BM x 256, wave tile (BM/2) x 64, one workgroup per CU.  k-slab = 16 deep =
+// 3 * (BM + 256) / 32 pieces; three LDS stages.  Per slab ONE barrier:
+//     wait (counted vmcnt) until slab t+1 has landed -> s_barrier -> DMA slab t+3 into the stage slab t just left ->
+//     ds_read slab t+1's fragments into the second register set, interleaved with the 6*TM*TN MFMAs of slab t.
+// Fragments are double-buffered in registers, so the MFMAs of a slab never wait for LDS, and the DMA has two full slabs
+// (>= 2 x 1150 MFMA cycles) to land.  The ds_reads are inline asm: hipcc would otherwise put a vmcnt(0) in front of every
+// LDS read that follows an LDS-DMA (it cannot tell the stages apart) and drain the ring (guide §5, "Pipelining across
+// barriers"); their completion is our own `s_waitcnt lgkmcnt(0)` at the top of the next slab.
+//
+// Epilogue: same contract as tvl_gemm_f32 (bias, act', pre_out, act, residual) + optional tp3 output of the final value, so
+// the consumer GEMM needs no split pass (fc1 -> QuickGELU -> fc2, and the dz of the backward).
+#pragma once
+#include <stdlib.h>
+#include <utility>
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int NTH = 512;
+constexpr int NWAVE = 8;
+constexpr int PIECE = 1024;       // bytes: one MFMA operand (32 rows x 16 k bf16)
+constexpr int BLK = 3 * PIECE;    // one (32 x 16) block, three pieces
+
+struct Tp3Params {
+    int M, N, K;
+    const unsigned char* A; int a_rb;   // tp3 image of [M, K]; a_rb = 32-row blocks present
+    const unsigned char* B; int b_rb;   // tp3 image of [N, K]
+    float* C; int ldc;                  // fp32 output (may be null when Cp is given)
+    unsigned char* Cp;                  // tp3 image of the output [M, N] (as the next GEMM's A), or null
+    const float* bias;
+    const float* residual; int ldr;
+    int act;
+    float* pre_out;
+    const float* dact_aux; int ld_aux; int dact;
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_byte) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(size_t)lds_byte, 16, 0, 0);
+}
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_frag(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wait until at most `groups` of this wave's DMA groups (one group = its pieces of one slab) are still in flight
+template <int PT>
+__device__ __forceinline__ void wait_groups(int groups, bool extra) {
+    constexpr int n0 = PT / NWAVE;
+    if (groups <= 0) wait_vm<0>();
+    else if (groups == 1) { if (extra) wait_vm<n0 + 1>(); else wait_vm<n0>(); }
+    else { if (extra) wait_vm<2 * (n0 + 1)>(); else wait_vm<2 * n0>(); }
+}
+
+__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float bfloat(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ unsigned pack_trunc(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+__device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
+    bf16x2 t = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, t);
+}
+
+// 4 consecutive k-elements -> 3 pieces of 4 bf16 (8 bytes) each
+__device__ __forceinline__ void split4(const float (&v)[4], uint2 (&out)[3]) {
+    float x[4] = {v[0], v[1], v[2], v[3]};
+    out[0] = make_uint2(pack_trunc(fbits(x[0]), fbits(x[1])), pack_trunc(fbits(x[2]), fbits(x[3])));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] -= bfloat(fbits(x[i]) & 0xFFFF0000u);
+    out[1] = make_uint2(pack_trunc(fbits(x[0]), fbits(x[1])), pack_trunc(fbits(x[2]), fbits(x[3])));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] -= bfloat(fbits(x[i]) & 0xFFFF0000u);
+    out[2] = make_uint2(pack_rn(x[0], x[1]), pack_rn(x[2], x[3]));
+}
+
+// byte offset of 4 consecutive elements (row, col .. col+3), col % 4 == 0, inside a tp3 image with kblocks = cols / 16
+__device__ __forceinline__ long tp3_off(long row, int col, int kblocks) {
+    return ((row >> 5) * kblocks + (col >> 4)) * (long)BLK + ((((col >> 3) & 1) * 32 + (int)(row & 31)) * 16 + (col & 4) * 2);
+}
+
+// Epilogue modes.  EPI < 0: every option read from the arguments at run time (any combination the C ABI allows).  EPI >= 0: a
+// bit set of the options below, resolved at compile time -- the epilogue is cold, straight-line code executed once per tile, and
+// with all options live it was ~5 KB per 4-column group, 24 groups per wave: the write-out of a tile then ran at the
+// instruction-fetch rate (20 us per 192x256 tile; stamps in profiles/r2_gemm_experiments.md), not at the store rate.
+enum { E_BIAS = 1, E_RES = 2, E_QGELU = 4, E_DQGELU = 8, E_PRE = 16, E_F32 = 32, E_TP3 = 64 };
+
+template <int EPI, bool NOSTORE = false>
+__device__ __forceinline__ void emit4(const Tp3Params& p, long row, int col, float4 a) {
+    constexpr bool G = EPI < 0;
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (G) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+    }
+    if (G ? p.bias != nullptr : (EPI & E_BIAS) != 0) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if (G ? p.dact != 0 : (EPI & E_DQGELU) != 0) {
+        const float4 z4 = *reinterpret_cast<const float4*>(p.dact_aux + row * p.ld_aux + col);
+        const int d = G ? p.dact : (int)TVL_ACT_QUICK_GELU;
+        v[0] *= dact_f(z4.x, d); v[1] *= dact_f(z4.y, d); v[2] *= dact_f(z4.z, d); v[3] *= dact_f(z4.w, d);
+    }
+    if (G ? p.pre_out != nullptr : (EPI & E_PRE) != 0) *reinterpret_cast<float4*>(p.pre_out + row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+    const bool post = G && (p.act & TVL_ACT_POST_RESIDUAL) != 0;
+    const bool has_res = G ? p.residual != nullptr : (EPI & E_RES) != 0;
+    if (post && has_res) {
+        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + row * p.ldr + col);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+    if (G || (EPI & E_QGELU)) {
+        const int act = G ? (p.act & 0xff) : (int)TVL_ACT_QUICK_GELU;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], act);
+    }
+    if (!post && has_res) {
+        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + row * p.ldr + col);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+    if (NOSTORE) {  // timing-only ablation: keep the values alive, store nothing (the condition never holds)
+        if (v[0] + v[1] + v[2] + v[3] == 1.2345e-33f) p.C[0] = v[0];
+        return;
+    }
+    if (G ? p.C != nullptr : (EPI & E_F32) != 0) *reinterpret_cast<float4*>(p.C + row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+    if (G ? p.Cp != nullptr : (EPI & E_TP3) != 0) {
+        uint2 pl[3];
+        split4(v, pl);
+        unsigned char* o = p.Cp + tp3_off(row, col, p.N >> 4);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(o + s * PIECE) = pl[s];
+    }
+}
+
+// accumulators -> per-wave LDS scratch (one 32-column strip of the wave tile at a time, all its rows) -> a ROLLED loop over
+// groups of 8 rows: rows leave as 128 contiguous bytes (8 rows per store instruction) and the option handling exists once per
+// strip instead of once per 32x32 block.  The tp3 output of the same pass leaves as four 128-byte segments per instruction.
+template <int TM, int TN, int EPI, bool NOSTORE = false>
+__device__ __forceinline__ void epilogue(const Tp3Params& p, f32x16 (&acc)[TM][TN], int row_base, int col_base, int lane, float* scratch) {
+    constexpr int LDS_ROW = 36;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int rr = lane >> 3, cc = (lane & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(&scratch[(i * 32 + l31) * LDS_ROW + 8 * g + 4 * h]) =
+                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        const int col = col_base + j * 32 + cc;
+        if (col + 3 < p.N) {
+#pragma unroll 1
+            for (int rl = rr; rl < TM * 32; rl += 8) {
+                const float4 v = *reinterpret_cast<const float4*>(&scratch[rl * LDS_ROW + cc]);
+                const int row = row_base + rl;
+                if (row < p.M) emit4<EPI, NOSTORE>(p, row, col, v);
+            }
+        }
+    }
+}
+
+template <int INFLIGHT, bool ISSUE, bool LAST>
+struct StepMode {};
+
+template <int TM, int TN>
+struct Frags {
+    bf16x8 a[TM][3], b[TN][3];
+};
+
+// piece q of the slab's (memory-op, MFMA) interleave: DMA pieces first, then the fragment reads of the NEXT slab
+template <int TM, int TN, int IDX>
+__device__ __forceinline__ void read_one(Frags<TM, TN>& f, unsigned a_addr, unsigned b_addr) {
+    if constexpr (IDX < 3 * TM) f.a[IDX / 3][IDX % 3] = lds_frag<IDX * PIECE>(a_addr);
+    else if constexpr (IDX < 3 * (TM + TN)) f.b[(IDX - 3 * TM) / 3][(IDX - 3 * TM) % 3] = lds_frag<(IDX - 3 * TM) * PIECE>(b_addr);
+}
+
+template <int TM, int TN, int... I>
+__device__ __forceinline__ void read_all(Frags<TM, TN>& f, unsigned a_addr, unsigned b_addr, std::integer_sequence<int, I...>) {
+    (read_one<TM, TN, I>(f, a_addr, b_addr), ...);
+}
+
+template <int BM, int BN, int VARIANT, int EPI>
+__global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
+    Tp3Params p = p_in;
+    float* const stamp_buf = p_in.pre_out;
+    if constexpr ((VARIANT & 32) != 0) p.pre_out = nullptr;
+    constexpr int WGM = 2, WGN = 4;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int PA = 3 * BM / 32, PB = 3 * BN / 32, PT = PA + PB;   // 1-KiB pieces per slab
+    constexpr int PW = (PT + NWAVE - 1) / NWAVE;                       // pieces per wave (the first PT % 8 waves carry one more)
+    constexpr int STAGE = PT * PIECE;
+    constexpr int NREAD = 3 * (TM + TN);
+    constexpr int NMFMA = 6 * TM * TN;
+    constexpr bool PIN = (VARIANT & 1) != 0, DMA_SPREAD = (VARIANT & 2) != 0;
+    // timing-only ablations (wrong results): bit 2 = no DMA inside the loop, bit 3 = every DMA re-reads slab 0 (L2-resident)
+    constexpr bool ABL_NODMA = (VARIANT & 4) != 0, ABL_SLAB0 = (VARIANT & 8) != 0, ABL_NOSTORE = (VARIANT & 16) != 0;
+    // diagnostic build (bit 5): wave 0 stamps s_memrealtime (100 MHz) / s_memtime (shader clock) at 4 points into p.pre_out
+    constexpr bool STAMP = (VARIANT & 32) != 0;
+    unsigned long long stamp_rt[6] = {0, 0, 0, 0, 0, 0}, stamp_clk[6] = {0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int i) {
+        if constexpr (STAMP) {
+            stamp_rt[i] = __builtin_amdgcn_s_memrealtime();
+            stamp_clk[i] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    stamp(0);
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int gsize_full = GROUP_M * p.tiles_n;
+    const int group = bid / gsize_full;
+    const int gm0 = group * GROUP_M;
+    const int gm = p.tiles_m - gm0 < GROUP_M ? p.tiles_m - gm0 : GROUP_M;
+    const int in_group = bid - group * gsize_full;
+    const int tile_m = gm0 + in_group % gm, tile_n = in_group / gm;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const bool extra = wave < PT % NWAVE;
+    const int KB = p.K >> 4;
+    const int nk = KB;
+
+    // this wave's DMA sources (slab 0): wave-uniform 64-bit bases (SGPRs) + one 32-bit lane offset
+    const unsigned char* src[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int pc = wave + NWAVE * i;
+        if (pc < PA) {
+            int rb = tile_m * (BM / 32) + pc / 3;
+            rb = rb < p.a_rb ? rb : p.a_rb - 1;
+            src[i] = p.A + ((long)rb * KB) * BLK + (pc % 3) * PIECE;
+        } else {
+            const int q = pc < PT ? pc - PA : 0;
+            int rb = tile_n * (BN / 32) + q / 3;
+            rb = rb < p.b_rb ? rb : p.b_rb - 1;
+            src[i] = p.B + ((long)rb * KB) * BLK + (q % 3) * PIECE;
+        }
+    }
+    const unsigned lane16 = lane * 16;
+    // request piece i of this wave for k-slab `slab` into LDS stage `stage`
+    auto issue_piece = [&](auto idx, int slab, int stage) {
+        constexpr int i = decltype(idx)::value;
+        const int pc = wave + NWAVE * i;
+        if ((i + 1) * NWAVE <= PT || pc < PT) glds16((src[i] + (long)(ABL_SLAB0 ? (slab & 1) : slab) * BLK) + lane16, lds0 + stage * STAGE + pc * PIECE);
+    };
+    auto issue = [&](int slab, int stage) {
+        [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(std::integral_constant<int, I>{}, slab, stage), ...); }(std::make_integer_sequence<int, PW>{});
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const unsigned a_frag = lds0 + lane * 16 + wm * (TM * BLK);
+    const unsigned b_frag = lds0 + lane * 16 + PA * PIECE + wn * (TN * BLK);
+
+    // prologue: three slabs in flight, wait for the first
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    wait_groups<PT>((nk < 3 ? nk : 3) - 1, extra);
+    __builtin_amdgcn_s_barrier();
+    stamp(1);
+    Frags<TM, TN> f0, f1;
+    read_all<TM, TN>(f0, a_frag, b_frag, std::make_integer_sequence<int, NREAD>{});
+
+    constexpr int PA_[6] = {0, 1, 2, 0, 1, 0}, PB_[6] = {2, 1, 0, 1, 0, 0};  // smallest piece products first, a1*b1 last
+
+    // One slab.  `cur` holds slab kt's fragments (requested one slab ago); unless LAST, `nxt` receives slab kt+1's.
+    //   INFLIGHT: DMA groups that may stay in flight while slab kt+1 is awaited (1 in steady state, 0 near the end);
+    //   ISSUE:    slab kt+3 exists and is requested into the stage slab kt has just left.
+    auto step = [&]<int INFLIGHT, bool ISSUE, bool LAST>(StepMode<INFLIGHT, ISSUE, LAST>, int kt, int st_cur, Frags<TM, TN>& cur,
+                                                         Frags<TM, TN>& nxt) {
+        if constexpr (!LAST && !ABL_NODMA) wait_groups<PT>(INFLIGHT, extra);   // this wave's pieces of slab kt+1 have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // `cur` is complete and this wave no longer reads stage st_cur
+        if constexpr (!LAST) __builtin_amdgcn_s_barrier();        // ... nor does any other wave, and their pieces landed too
+        __builtin_amdgcn_sched_barrier(0);
+        const int st_nxt = st_cur == 2 ? 0 : st_cur + 1;
+        const unsigned a_addr = a_frag + st_nxt * STAGE, b_addr = b_frag + st_nxt * STAGE;
+        // NMFMA MFMAs of slab kt.  The memory instructions ride between them so that the matrix pipe restarts right after the
+        // barrier: the first NREAD MFMAs are each preceded by one fragment read of slab kt+1, and the PW DMA requests of slab
+        // kt+3 are spread over the slab (a request costs ~60-180 issue cycles: all of them up front left the pipe idle for
+        // ~700 of the slab's 2300 cycles on both waves of a SIMD at once)
+        constexpr int DMA_EVERY = NMFMA / PW;
+        auto body = [&](auto idx) {
+            constexpr int q = decltype(idx)::value;
+            if constexpr (!LAST && q < NREAD) read_one<TM, TN, q>(nxt, a_addr, b_addr);
+            if constexpr (ISSUE && !ABL_NODMA && DMA_SPREAD && q % DMA_EVERY == 1 && q / DMA_EVERY < PW)
+                issue_piece(std::integral_constant<int, q / DMA_EVERY>{}, kt + 3, st_cur);
+            constexpr int pair = q % 6, ij = q / 6, i = ij / TN, j = ij % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.b[j][PB_[pair]], cur.a[i][PA_[pair]], acc[i][j], 0, 0, 0);
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (ISSUE && !ABL_NODMA && !DMA_SPREAD) issue(kt + 3, st_cur);
+        [&]<int... Q>(std::integer_sequence<int, Q...>) { (body(std::integral_constant<int, Q>{}), ...); }(std::make_integer_sequence<int, NMFMA>{});
+    };
+    using Steady = StepMode<1, true, false>;
+    using Drain1 = StepMode<1, false, false>;
+    using Drain0 = StepMode<0, false, false>;
+    using Last = StepMode<0, false, true>;
+
+    // nk is even and >= 4 (K % 32 == 0, K >= 64): two slabs per trip, the last four peeled so that every wait count and
+    // every DMA request in the loop is unconditional
+    int kt = 0, st = 0;
+    for (; kt < nk - 4; kt += 2) {
+        step(Steady{}, kt, st, f0, f1);
+        st = st == 2 ? 0 : st + 1;
+        step(Steady{}, kt + 1, st, f1, f0);
+        st = st == 2 ? 0 : st + 1;
+    }
+    step(Steady{}, kt, st, f0, f1);          // kt = nk-4: requests the last slab
+    st = st == 2 ? 0 : st + 1;
+    step(Drain1{}, kt + 1, st, f1, f0);      // nk-3: awaits slab nk-2, slab nk-1 still in flight
+    st = st == 2 ? 0 : st + 1;
+    step(Drain0{}, kt + 2, st, f0, f1);      // nk-2: awaits slab nk-1
+    st = st == 2 ? 0 : st + 1;
+    step(Last{}, kt + 3, st, f1, f0);        // nk-1
+
+    stamp(2);
+    __syncthreads();  // every wave is past its last LDS read: the stages become epilogue scratch
+    stamp(4);
+    float* scratch = reinterpret_cast<float*>(smem) + wave * (TM * 32 * 36);
+    epilogue<TM, TN, EPI, ABL_NOSTORE>(p, acc, tile_m * BM + wm * WM, tile_n * BN + wn * WN, lane, scratch);
+    if constexpr (STAMP) {
+        stamp(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3);
+        if (threadIdx.x == 0 && stamp_buf) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(stamp_buf) + (long)blockIdx.x * 12;
+            for (int i = 0; i < 6; ++i) { d[i] = stamp_rt[i]; d[6 + i] = stamp_clk[i]; }
+        }
+    }
+}
+
+template <int BM, int BN, int VARIANT, int EPI>
+int launch(const Tp3Params& p0, hipStream_t s) {
+    Tp3Params p = p0;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    constexpr size_t stage_bytes = (size_t)3 * (3 * (BM + BN) / 32) * PIECE;
+    constexpr size_t epi_bytes = (size_t)NWAVE * (BM / 2) * 36 * sizeof(float);
+    constexpr size_t smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    auto kern = gemm_tp3_kernel<BM, BN, VARIANT, EPI>;
+    static int attr_dev_mask = 0;  // per device: the opt-in for > 64 KiB of dynamic LDS is a per-device function attribute
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    if (!(attr_dev_mask & (1 << dev))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 1;
+        attr_dev_mask |= 1 << dev;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)p.tiles_m * p.tiles_n)), dim3(NTH), smem, s, p);
+    return 0;
+}
+
+// the specialised epilogues of the vision tower's eight GEMMs (ops.py EncoderLayerFn); anything else runs the generic one
+template <int BM, int VARIANT>
+int launch_epi(const Tp3Params& p, int epi, hipStream_t s) {
+    switch (epi) {
+        case E_F32: return launch<BM, 256, VARIANT, E_F32>(p, s);                                           // data gradients
+        case E_BIAS | E_F32: return launch<BM, 256, VARIANT, E_BIAS | E_F32>(p, s);                         // qkv
+        case E_BIAS | E_RES | E_F32: return launch<BM, 256, VARIANT, E_BIAS | E_RES | E_F32>(p, s);         // out_proj, fc2
+        case E_BIAS | E_QGELU | E_PRE | E_TP3: return launch<BM, 256, VARIANT, E_BIAS | E_QGELU | E_PRE | E_TP3>(p, s);   // fc1 (training)
+        case E_BIAS | E_QGELU | E_TP3: return launch<BM, 256, VARIANT, E_BIAS | E_QGELU | E_TP3>(p, s);     // fc1 (no tape)
+        case E_DQGELU | E_TP3: return launch<BM, 256, VARIANT, E_DQGELU | E_TP3>(p, s);                     // dz of the backward
+        default: return launch<BM, 256, VARIANT, -1>(p, s);
+    }
+}
+
+// compile-time epilogue code of a call, or -1 (generic) when it uses anything the specialised set does not cover
+inline int epi_code(const Tp3Params& p) {
+    if (p.alpha != 1.0f || (p.act & TVL_ACT_POST_RESIDUAL)) return -1;
+    const int act = p.act & 0xff;
+    if ((act != TVL_ACT_NONE && act != TVL_ACT_QUICK_GELU) || (p.dact != TVL_ACT_NONE && p.dact != TVL_ACT_QUICK_GELU)) return -1;
+    return (p.bias ? E_BIAS : 0) | (p.residual ? E_RES : 0) | (act ? E_QGELU : 0) | (p.dact ? E_DQGELU : 0) | (p.pre_out ? E_PRE : 0) |
+           (p.C ? E_F32 : 0) | (p.Cp ? E_TP3 : 0);
+}
+
+}  // namespace
+
+// per-tile translation units (parallel make): Tp3Params is TU-local, hence the opaque pointer
+int tvl_gemm_tp3_t128(const void* params, int epi, hipStream_t s);
+int tvl_gemm_tp3_t256(const void* params, int epi, hipStream_t s);

@@ -42,6 +42,23 @@ class GemmArgs(C.Structure):
     ]
 
 
+class GemmTp3Args(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("A", C.c_void_p), ("a_rows", C.c_int64),
+        ("B", C.c_void_p), ("b_rows", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int32),
+        ("C_tp3", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_int32),
+        ("act", C.c_int32),
+        ("pre_out", C.c_void_p),
+        ("dact_aux", C.c_void_p), ("ld_aux", C.c_int32), ("dact", C.c_int32),
+        ("alpha", C.c_float),
+        ("tile_m", C.c_int32), ("variant", C.c_int32),
+    ]
+
+
 class ConvGeom(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("stride", C.c_int32)]
 
@@ -116,8 +133,9 @@ _SIGS = {
     "tvl_colsum": [_P, _P, _L, _I, _I],
     "tvl_copy2d": [_P, _I, _P, _I, _L, _I],
     "tvl_conv3x3_bf16s": [C.POINTER(GemmArgs), C.POINTER(ConvGeom), _I],
-    "tvl_split_planes": [_P, _I, _L, _I, _P, _L, _I],
-    "tvl_gemm_planes": [C.POINTER(GemmArgs), _L, _L, C.POINTER(ConvGeom)],
+    "tvl_tp3_pack": [_P, _L, _L, _I, _P],
+    "tvl_tp3_unpack": [_P, _L, _I, _P, _L],
+    "tvl_gemm_tp3": [C.POINTER(GemmTp3Args)],
     "tvl_im2col3x3": [_P, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
@@ -129,7 +147,7 @@ _SIGS = {
     "tvl_dynconv_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
     "tvl_dynconv_bwd": [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
 }
-EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", *_SIGS]
+EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", *_SIGS]
 
 _lib = None
 
@@ -149,6 +167,8 @@ def load():
     lib.tvl_abi_version.restype = C.c_int
     lib.tvl_dynconv_bwd_work_floats.argtypes = [_I, _I, _I, _I]
     lib.tvl_dynconv_bwd_work_floats.restype = C.c_int64
+    lib.tvl_tp3_bytes.argtypes = [_L, _I]
+    lib.tvl_tp3_bytes.restype = C.c_int64
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = [*sig, C.c_void_p]
@@ -199,9 +219,6 @@ def _ident():
 #   "bf16x3" 2 pieces / 3 MFMAs (~2^-16 per product; fails the 1e-3 gradient gate on the full-size fixtures)
 #   "bf16"   plain bf16 operands (fails the 1e-3 logit gate) -- both kept only as measured, documented reduced-precision modes
 GEMM_MODE = os.environ.get("TVL_GEMM_MODE", "bf16x6")
-# How the bf16x6 GEMM gets its bf16 pieces: "inkernel" = split while staging the tile (gemm_bf16s.hip);
-# "planes" = operands pre-split into three bf16 planes (frozen weights once, activations by a one-pass kernel), LDS-DMA fill
-GEMM_IMPL = os.environ.get("TVL_GEMM_IMPL", "inkernel")
 SPLITK = os.environ.get("TVL_GEMM_SPLITK", "1") != "0"  # deterministic split-K for skinny, deep GEMMs
 _NSPLIT = {"bf16x6": 3, "bf16x3": 2, "bf16": 1}
 
@@ -275,38 +292,98 @@ def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True, split: int = 
     return f"gemm_f32_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {ak}, {bk}, {'true' if vec else 'false'}>"
 
 
-def split_planes(x2d: torch.Tensor, cols: int | None = None) -> torch.Tensor:
-    """fp32 [rows, >=cols] -> bf16 planes [3, rows, ldp] with x = p0 + p1 + p2 exactly (ldp = cols rounded up to 32, zero filled)."""
-    rows = x2d.shape[0]
-    cols = x2d.shape[1] if cols is None else cols
-    ldp = (cols + 31) // 32 * 32
-    planes = torch.empty((3, rows, ldp), device=x2d.device, dtype=torch.bfloat16)
-    _call("tvl_split_planes", _ps(x2d), x2d.stride(0), rows, cols, planes.data_ptr(), rows * ldp, ldp)
-    return planes
+class Tp3:
+    """An fp32 matrix [rows, cols] held as three bf16 pieces per element in MFMA-fragment order (include/tvl_hip.h, "tp3"):
+    the operand format of ``tvl_gemm_tp3``.  ``buf`` is the raw byte image (rows padded to a multiple of 32)."""
+
+    __slots__ = ("buf", "rows", "cols")
+
+    def __init__(self, rows: int, cols: int, device, buf: torch.Tensor | None = None):
+        if cols % 16:
+            raise RuntimeError(f"tp3 needs cols % 16 == 0, got {cols}")
+        self.rows, self.cols = rows, cols
+        n = (rows + 31) // 32 * (cols // 16) * 3072
+        self.buf = buf if buf is not None else torch.empty(n, device=device, dtype=torch.uint8)
+
+    @property
+    def shape(self):
+        return (self.rows, self.cols)
+
+    def float(self) -> torch.Tensor:
+        """Back to fp32 (p0 + p1 + p2): tests and debugging."""
+        y = torch.empty((self.rows, self.cols), device=self.buf.device, dtype=torch.float32)
+        _call("tvl_tp3_unpack", self.buf.data_ptr(), self.rows, self.cols, _p(y), self.cols)
+        return y
 
 
-def weight_planes(W: torch.Tensor, cols: int | None = None) -> torch.Tensor:
-    """Planes of a weight matrix, cached on the tensor object when it is frozen (prepared weights are persistent objects);
-    anything that may change in place (trainable parameters, their detached views) is split again on every call."""
-    cached = getattr(W, "_tvl_planes", None)
-    if cached is not None and cached[0] == (W.data_ptr(), W._version, cols):
+def tp3_pack(x2d: torch.Tensor) -> Tp3:
+    """fp32 [rows, cols] (unit column stride) -> Tp3.  Frozen weights: once at load; activations come from their producers."""
+    rows, cols = x2d.shape
+    out = Tp3(rows, cols, x2d.device)
+    _call("tvl_tp3_pack", _ps(x2d), x2d.stride(0), rows, cols, out.buf.data_ptr())
+    return out
+
+
+def weight_tp3(W: torch.Tensor) -> Tp3:
+    """Tp3 image of a frozen weight, cached on the tensor object (prepared weights are persistent, see mark_frozen)."""
+    cached = getattr(W, "_tvl_tp3", None)
+    if cached is not None and cached[0] == (W.data_ptr(), W._version):
         return cached[1]
-    planes = split_planes(W, cols)
+    img = tp3_pack(W)
     if not W.requires_grad and W._base is None and W.grad_fn is None and getattr(W, "_tvl_frozen", False):
-        W._tvl_planes = ((W.data_ptr(), W._version, cols), planes)
-    return planes
+        W._tvl_tp3 = ((W.data_ptr(), W._version), img)
+    return img
 
 
 def mark_frozen(t: torch.Tensor) -> torch.Tensor:
-    """Declare a prepared weight tensor immutable for its lifetime (enables the plane cache)."""
+    """Declare a prepared weight tensor immutable for its lifetime (enables the tp3 cache)."""
     t._tvl_frozen = True
     return t
 
 
+GEMM_TP3_TILE = int(os.environ.get("TVL_TP3_TILE", "0"))      # 0 = automatic; 128 / 192 / 256 rows per workgroup
+GEMM_TP3_VARIANT = int(os.environ.get("TVL_TP3_VARIANT", "0"))  # 0 = production; others: diagnostic builds (csrc/gemm_tp3.hip)
+
+
+def gemm_tp3(A: Tp3, B: Tp3, *, M: int | None = None, out: torch.Tensor | None = None, out_tp3: Tp3 | None = None, want_f32=True,
+             want_tp3=False, bias=None, residual=None, act=ACT_NONE, pre_out=None, dact_aux=None, dact=ACT_NONE, alpha=1.0):
+    """epilogue(alpha * A . B^T) over tp3 operands; returns (C fp32 or None, C as Tp3 or None)."""
+    M = A.rows if M is None else M
+    N, K = B.rows, A.cols
+    if B.cols != K:
+        raise RuntimeError(f"gemm_tp3: K mismatch {A.shape} x {B.shape}")
+    dev = A.buf.device
+    Cf = out if out is not None else (torch.empty((M, N), device=dev, dtype=torch.float32) if want_f32 else None)
+    Ct = out_tp3 if out_tp3 is not None else (Tp3(M, N, dev) if want_tp3 else None)
+    ldc = Cf.stride(0) if Cf is not None else (pre_out.stride(0) if pre_out is not None else N)
+    args = GemmTp3Args(M, N, K, A.buf.data_ptr(), A.rows, B.buf.data_ptr(), B.rows, _ps(Cf), ldc, None if Ct is None else Ct.buf.data_ptr(),
+                       _p(bias), _ps(residual), 0 if residual is None else residual.stride(0), act, _ps(pre_out), _ps(dact_aux),
+                       0 if dact_aux is None else dact_aux.stride(0), dact, alpha, GEMM_TP3_TILE, GEMM_TP3_VARIANT)
+    if _gemm_prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _call("tvl_gemm_tp3", C.byref(args))
+    if _gemm_prof is not None:
+        e1.record()
+        _gemm_prof.append((f"gemm_tp3_kernel<{tp3_tile(M, N)}, 256, {GEMM_TP3_VARIANT}>", 2.0 * M * N * K, e0, e1))
+    return Cf, Ct
+
+
+def tp3_tile(M: int, N: int) -> int:
+    """Rows per workgroup tvl_gemm_tp3 picks (same rule as csrc/gemm_tp3.hip)."""
+    if GEMM_TP3_TILE:
+        return GEMM_TP3_TILE
+    best, bm = None, 0
+    for c in (256, 192, 128):
+        tiles = ((M + c - 1) // c) * ((N + 255) // 256)
+        cost = ((tiles + 255) // 256) * c * (1.08 if c == 128 else 1.0)
+        if best is None or cost < best:
+            best, bm = cost, c
+    return bm
+
+
 def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias=None, residual=None, ldr=0, act=ACT_NONE,
          pre_out=None, dact_aux=None, ld_aux=0, dact=ACT_NONE, alpha=1.0, a_map=None, c_map=None):
-    if GEMM_IMPL == "planes" and GEMM_MODE == "bf16x6" and layout == NT and M >= 256 and A.dim() == 2 and B.dim() == 2:
-        return _gemm_planes(M, N, K, A, B, Cout, ldc, bias, residual, ldr, act, pre_out, dact_aux, ld_aux, dact, alpha, a_map, c_map)
     args = GemmArgs(layout, M, N, K, _ps(A) if A.dim() == 2 else _p(A), lda, _p(B), ldb, _ps(Cout) if Cout.dim() == 2 else _p(Cout), ldc,
                     _p(bias), _ps(residual) if (residual is not None and residual.dim() == 2) else _p(residual), ldr, act, _p(pre_out),
                     _p(dact_aux), ld_aux, dact, alpha, a_map or _ident(), c_map or _ident())
@@ -335,22 +412,6 @@ def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias
         e1.record()
         vec = lda % 4 == 0 and ldb % 4 == 0
         _gemm_prof.append((gemm_kernel_key(layout, M, N, vec, split, K), 2.0 * M * N * K, e0, e1))
-    return Cout
-
-
-def _gemm_planes(M, N, K, A, B, Cout, ldc, bias, residual, ldr, act, pre_out, dact_aux, ld_aux, dact, alpha, a_map, c_map, conv=None):
-    Ap = (weight_planes if getattr(A, "_tvl_frozen", False) else split_planes)(A, conv.C if conv is not None else K)
-    Bp = weight_planes(B, K)
-    args = GemmArgs(NT, M, N, K, Ap.data_ptr(), Ap.shape[2], Bp.data_ptr(), Bp.shape[2], _ps(Cout) if Cout.dim() == 2 else _p(Cout), ldc,
-                    _p(bias), _ps(residual) if (residual is not None and residual.dim() == 2) else _p(residual), ldr, act, _p(pre_out),
-                    _p(dact_aux), ld_aux, dact, alpha, a_map or _ident(), c_map or _ident())
-    if _gemm_prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _call("tvl_gemm_planes", C.byref(args), Ap.shape[1] * Ap.shape[2], Bp.shape[1] * Bp.shape[2], C.byref(conv) if conv is not None else None)
-    if _gemm_prof is not None:
-        e1.record()
-        _gemm_prof.append((gemm_kernel_key(NT, M, N, True, 3).replace("gemm_bf16s_kernel", "gemm_planes_kernel"), 2.0 * M * N * K, e0, e1))
     return Cout
 
 
