@@ -216,7 +216,8 @@ def main():
         name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         gemm_ms = sum(v["ms"] for v in prof.values()) / 2
-        peak = MODE_PEAK[hip.GEMM_MODE] if "bf16s" in name else PEAK_F32_MFMA_TFLOPS
+        split = "bf16s" in name or "tp3" in name
+        peak = MODE_PEAK[hip.GEMM_MODE] if split else PEAK_F32_MFMA_TFLOPS
         # HBM bytes per launch of that kernel from the PMC passes recorded in profiles/ (rocprofv3 --pmc FETCH_SIZE, then
         # WRITE_SIZE, each in its own run; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM)
         traffic = None
@@ -226,12 +227,12 @@ def main():
             traffic = rec["hbm_bytes_per_launch"] if rec else None
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": name,
-                    "peak_note": "algorithmic fp32 FLOP/s ceiling = dense bf16 MFMA peak / MFMAs per fp32 product" if "bf16s" in name
+                    "peak_note": "algorithmic fp32 FLOP/s ceiling = dense bf16 MFMA peak / MFMAs per fp32 product" if split
                     else "dense f32-input MFMA peak", "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "launches_per_step": d["launches"] // 2, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1),
                     "flops_per_launch": round(d["flops"] / d["launches"]), "all_gemm_ms_per_step": round(gemm_ms, 2),
                     # every GEMM instantiation of the step (one instantiation serves several shapes: the average mixes them)
-                    "gemm_kernels": [{"kernel": k.replace("gemm_bf16s_kernel", "bf16s").replace("gemm_f32_kernel", "f32"),
+                    "gemm_kernels": [{"kernel": k.replace("gemm_bf16s_kernel", "bf16s").replace("gemm_f32_kernel", "f32").replace("gemm_tp3_kernel", "tp3"),
                                       "ms_per_step": round(v["ms"] / 2, 2), "launches_per_step": v["launches"] // 2,
                                       "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                      for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:5]],

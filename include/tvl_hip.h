@@ -82,6 +82,12 @@ int tvl_layernorm_fwd(const float* x, const float* gamma, const float* beta, flo
 int tvl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                       const float* dres, float* dx, float* dgamma, float* dbeta,
                       int64_t rows, int32_t cols, tvlStream_t stream);
+/* LayerNorm between tp3 GEMMs: the forward writes ONLY the tp3 image of y [rows, cols] (cols % 16 == 0, <= 2048); the backward
+ * writes dx twice, fp32 (residual-stream gradient) and tp3 (A operand of the next data-gradient GEMM); frozen gamma / beta. */
+int tvl_layernorm_fwd_tp3(const float* x, const float* gamma, const float* beta, void* y_tp3, float* mean, float* rstd,
+                          int64_t rows, int32_t cols, float eps, tvlStream_t stream);
+int tvl_layernorm_bwd_tp3(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const float* dres, float* dx, void* dx_tp3, int64_t rows, int32_t cols, tvlStream_t stream);
 
 /*
  * Multi-head softmax attention, flash style (HF eager_attention_forward, modeling_clipseg.py:232-252).
@@ -115,6 +121,11 @@ typedef struct {
     int32_t Tk;
 } tvlAttnBwdArgs;
 int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream);
+/* The vision tower's attention (d_h = 64, no masks) between tp3 GEMMs (see "tp3" below): the forward writes O as the tp3 image of
+ * [B*T, H*64] (a->o may be NULL), the backward takes that image for delta = rowsum(dO * O) and writes dQ | dK | dV as the tp3
+ * image of the packed gradient [B*T, 3*H*64] -- the A operand of the QKV data-gradient GEMM (a->o, a->dq/dk/dv must be NULL). */
+int tvl_attn_fwd_tp3(const tvlAttnFwdArgs* a, void* o_tp3, tvlStream_t stream);
+int tvl_attn_bwd_tp3(const tvlAttnBwdArgs* a, const void* o_tp3, void* dqkv_tp3, tvlStream_t stream);
 
 /* ---- token plumbing (reference vpt_context_learner.py:46-64, base_visual_learner.py:18-23,
  *      coop_context_learner.py:124-181, HF:190-206) ---- */

@@ -147,14 +147,20 @@ def compact_outputs(logits, mask):
     fn, tn = (~lab & tgt).sum(1), (~lab & ~tgt).sum(1)
     den = (2 * tp + fp + fn).double()
     dice = torch.where(den > 0, 2 * tp.double() / den.clamp(min=1), torch.ones_like(den))
-    return {"out.logits_s11": logits.detach()[..., ::11, ::11].contiguous().numpy(),
+    # full label map as packed bits + the pixels whose logit is within 1e-4 of the threshold (any fp32 evaluation, the reference's
+    # own included, may put those on either side): bit-exactness is asserted everywhere else
+    flat = logits.detach().flatten()
+    amb = torch.nonzero(flat.abs() < 1e-4).flatten()
+    return {"out.label_bits": np.packbits(lab.numpy().astype(np.uint8)), "out.ambiguous_idx": amb.numpy(),
+            "out.ambiguous_logits": flat[amb].numpy(),
+            "out.logits_s11": logits.detach()[..., ::11, ::11].contiguous().numpy(),
             "out.counts": torch.stack((tp, fp, fn, tn), 1).numpy(), "out.dice_per_sample": dice.numpy(),
             "out.logits_absmax": logits.detach().abs().amax().numpy(),
             "out.min_abs_logit": logits.detach().abs().amin().numpy()}
 
 
 def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, learner_kw: dict, net_kw: dict,
-             B: int, H: int, L: int, iseed: int, M, compact: bool = False):
+             B: int, H: int, L: int, iseed: int, M, compact: bool = False, with_f64: bool = False):
     from src.models.components.hf_clipseg_wrapper import HFCLIPSegWrapper
     from src.models.core_models import coop as R
     from src.models.core_models.coop import context_learner as CL
@@ -214,6 +220,29 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
             grads_none.append(k)
         else:
             arrays["grad." + k] = p.grad.numpy()
+    if with_f64:
+        # The same reference classes run in float64 ("grad64.*", stored rounded to fp32): deep prompts give gradients that are
+        # small differences of larger terms, and on such fixtures the reference's own fp32 gradient is ~1e-3 away from the exact
+        # one.  The tests then hold the HIP path to the exact gradient, no looser than the reference's own fp32 deviation.
+        import copy
+
+        import torch.nn.functional as TF
+
+        net64 = copy.deepcopy(net).double()
+        for p_ in net64.parameters():
+            p_.grad = None
+        orig_softmax = TF.softmax
+        TF.softmax = lambda x, dim=-1, dtype=None, **kw: orig_softmax(x, dim=dim)  # HF's eager attention pins the softmax to fp32
+        try:
+            logits64 = net64(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix.double())
+            dice_ce_loss(logits64, mask.double()).backward()
+        finally:
+            TF.softmax = orig_softmax
+        for k, p_ in net64.named_parameters():
+            if p_.requires_grad and p_.grad is not None:
+                arrays["grad64." + k] = p_.grad.float().numpy()
+        print(f"   f64: logits fp32-vs-fp64 {float((logits.detach().double() - logits64.detach()).abs().max()):.2e}; worst fp32 gradient "
+              f"deviation {max(float((params[k].grad.double() - p_.grad).abs().max() / p_.grad.abs().max()) for k, p_ in net64.named_parameters() if p_.requires_grad and p_.grad is not None):.2e}")
     meta = {"name": name, "compact": compact, "preset": preset, "eos_token_id": eos, "weight_seed": wseed, "net": net_kind,
             "learner_kw": {k: v for k, v in learner_kw.items()}, "net_kw": net_kw, "B": B, "H": H, "L": L,
             "input_seed": iseed, "weights_checksum": state_checksum(sd), "grads_none": grads_none,
@@ -385,14 +414,14 @@ def main():
              net_kw=dict(use_new_last_layer=False, no_freeze_last_layer=True), **T)
     # --- ends of the Optuna ranges (prompt_depth 1-10, intermediate_dim 32-128, LoRA on/off), B=1 -------
     run_case("rd64_vpt_n10_d10", eos=2, wseed=21, net_kind="vpt", iseed=24,
-             learner_kw=dict(prompt_depth=10, num_context=10, vector_std=0.02), net_kw=base_old, **F_)
+             learner_kw=dict(prompt_depth=10, num_context=10, vector_std=0.02), net_kw=base_old, with_f64=True, **F_)
     run_case("rd64_maple_n4_d10_i32_lora", eos=2, wseed=21, net_kind="maple", iseed=25,
              learner_kw=dict(prompt_depth=10, num_context=4, vector_std=0.02, use_unified_projection=False,
-                             intermediate_dim=32, use_proj_norm=False, use_lora_proj=True), net_kw=base_new, **F_)
+                             intermediate_dim=32, use_proj_norm=False, use_lora_proj=True), net_kw=base_new, with_f64=True, **F_)
     run_case("rd64_cocoop_n4_d10_i128", eos=2, wseed=21, net_kind="cocoop", iseed=26,
              learner_kw=dict(prompt_depth=10, num_context=4, vector_std=0.02, use_unified_projection=False,
                              intermediate_dim=128, use_proj_norm=True, use_lora_proj=False, norm_image_features=True),
-             net_kw=base_old, **F_)
+             net_kw=base_old, with_f64=True, **F_)
     # --- BASELINE configs[1] exactly: VPT-10 shallow, 352x352, B = 32 (seed 1).  Compact fixture: the inputs
     # are re-drawn from the seed; kept are loss, the 7 680-float prompt gradient, per-sample integer counts / Dice and
     # every 11th logit.  This is the case whose M = 15 840 rows select the large GEMM tiles of the benchmarked step.

@@ -189,3 +189,29 @@ def synth_cris_inputs(cfg: CRISConfig, B: int, L: int, seed: int, with_attention
         am[b, : len(row)] = 1
     mask = (torch.rand(B, 1, H, H, generator=g) > 0.7).float()
     return pix, ids, (am if with_attention_mask else None), mask
+
+
+def check_compact_labels(fx, logits: torch.Tensor, isum: torch.Tensor, mask: torch.Tensor, logit_tol: float = 1e-3) -> int:
+    """Integer parity of a compact (full-batch) fixture.  The label map ``sigmoid(logit) > 0.5`` must equal the reference's bit
+    for bit, except at the pixels the fixture lists as ambiguous (|reference logit| < 1e-4: within fp32 evaluation noise of the
+    threshold, so the reference's own fp32 run could land on either side); there the logit itself must agree to ``logit_tol``.
+    The kernel's integer TP/FP/FN/TN must be exactly the counts of the label map this path produced, and differ from the
+    reference's counts only by the ambiguous pixels that flipped.  Returns the number of flipped pixels."""
+    lg = logits.detach().cpu()
+    B = lg.shape[0]
+    lab = (torch.sigmoid(lg) > 0.5).flatten()
+    ref_lab = torch.from_numpy(np.unpackbits(fx["out.label_bits"])[: lab.numel()].astype(bool))
+    amb = torch.from_numpy(fx["out.ambiguous_idx"]).long()
+    flips = torch.nonzero(lab != ref_lab).flatten()
+    outside = set(flips.tolist()) - set(amb.tolist())
+    assert not outside, f"{len(outside)} label pixels differ from the reference away from the threshold"
+    if amb.numel():
+        assert (lg.flatten()[amb] - torch.from_numpy(fx["out.ambiguous_logits"])).abs().max().item() <= logit_tol
+    tgt = mask.detach().cpu().long().flatten(1).bool()
+    labs = lab.view(B, -1)
+    own = torch.stack(((labs & tgt).sum(1), (labs & ~tgt).sum(1), (~labs & tgt).sum(1), (~labs & ~tgt).sum(1)), 1)
+    assert torch.equal(isum.cpu(), own), "integer TP/FP/FN/TN are not the counts of this path's own label map"
+    ref_counts = torch.from_numpy(fx["out.counts"])
+    per_sample_flips = torch.zeros(B, dtype=torch.long).index_add_(0, flips // labs.shape[1], torch.ones_like(flips))
+    assert ((own - ref_counts).abs().sum(1) <= 2 * per_sample_flips).all(), "integer counts differ from the reference beyond the ambiguous pixels"
+    return int(flips.numel())

@@ -403,6 +403,34 @@ def test_gemm_tp3(hip, M, N, K, tile):
         hip.GEMM_TP3_TILE, hip.GEMM_TP3_VARIANT = old
 
 
+@pytest.mark.parametrize("rows,cols", [(15840, 768), (100, 64), (33, 1024), (489, 768)])
+def test_layernorm_tp3(hip, rows, cols):
+    """LayerNorm that writes its result only as a tp3 image / its backward that writes fp32 + tp3: identical to the fp32 kernels
+    (the tp3 image is an exact split of the same fp32 values)."""
+    x, g, b = dev(rnd(rows, cols, seed=1) * 3 + 0.5), dev(1 + 0.1 * rnd(cols, seed=2)), dev(0.1 * rnd(cols, seed=3))
+    y, mean, rstd = hip.layernorm_fwd(x, g, b, 1e-5)
+    yt, mean_t, rstd_t = hip.layernorm_fwd_tp3(x, g, b, 1e-5)
+    assert torch.equal(yt.float(), y) and torch.equal(mean, mean_t) and torch.equal(rstd, rstd_t)
+    dy, dres = dev(rnd(rows, cols, seed=4)), dev(rnd(rows, cols, seed=5))
+    dx = hip.layernorm_bwd(dy, x, g, mean, rstd, dres=dres)
+    dx2, dxt = hip.layernorm_bwd_tp3(dy, x, g, mean, rstd, dres=dres)
+    assert torch.equal(dx2, dx) and torch.equal(dxt.float(), dx)
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 495, 12), (3, 100, 2), (1, 33, 1)])
+def test_attention_tp3_outputs(hip, B, T, H):
+    """d_h = 64 attention writing O / dQ|dK|dV as tp3 images: the same values as the fp32-output kernels (exact split)."""
+    dh, D = 64, H * 64
+    qkv = dev(rnd(B * T, 3 * D, seed=1))
+    o, lse = hip.attn_fwd_packed(qkv, B, T, H, dh, dh**-0.5)
+    ot, lse_t = hip.attn_fwd_packed_tp3(qkv, B, T, H, dh, dh**-0.5)
+    assert torch.equal(ot.float(), o) and torch.equal(lse, lse_t)
+    d_o = dev(rnd(B * T, D, seed=2))
+    dqkv = hip.attn_bwd_packed(qkv, o, d_o, lse, B, T, H, dh, dh**-0.5)
+    dqkv_t = hip.attn_bwd_packed_tp3(qkv, ot, d_o, lse, B, T, H, dh, dh**-0.5)
+    close(dqkv_t.float(), dqkv, 1e-6, "attn bwd tp3")  # delta is summed in a different order
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 25, 21632), (64, 64, 5000), (130, 25, 15488), (32, 8, 100000)])
 def test_gemm_tn_split_k(hip, M, N, K):
     """Weight gradients with a handful of output tiles run split-K (fp32 atomics); a row map on the K rows still applies."""

@@ -90,6 +90,7 @@ def run_case(name):
         assert torch.equal(isum.cpu(), torch.stack((tp, fp, fn, tn), 1))
     loss.backward()
     worst = 0.0
+    agg = [0.0, 0.0, 0.0]  # squared error of HIP / of the reference's fp32 run vs the float64 gradients, and their squared norm
     for k, p in net.named_parameters():
         if not p.requires_grad:
             continue
@@ -99,10 +100,29 @@ def run_case(name):
         g_ref = torch.from_numpy(fx["grad." + k])
         assert p.grad is not None, f"{name}: no grad for {k}"
         scale = g_ref.abs().max().item() + 1e-12
-        gerr = (p.grad.cpu() - g_ref).abs().max().item()
-        assert gerr <= GRAD_RTOL * scale + 1e-9, f"{name}: grad {k} err {gerr:.3e} scale {scale:.3e}"
+        if "grad64." + k in fx:
+            # ill-conditioned fixture (deep prompts: the gradient is a small difference of larger terms).  The fixture also holds
+            # the reference run in float64: its own fp32 gradient is up to 1.2e-3 (per tensor, relative to the largest entry) away
+            # from that exact value on the CoCoOp depth-10 fixture, so "within 1e-3 of the reference" is not a meaningful gate
+            # there.  Gate instead against the EXACT gradient: per tensor within 1e-3, or within 5x the reference's own fp32
+            # deviation (individual tensors scatter: measured up to 3.3x); over all tensors together (relative L2, below) the
+            # HIP path must carry the same order of rounding noise as the reference (<= 2.5x; measured ~1.7x).
+            truth = torch.from_numpy(fx["grad64." + k])
+            ref_noise = (g_ref - truth).abs().max().item()
+            gerr = (p.grad.cpu() - truth).abs().max().item()
+            assert gerr <= max(GRAD_RTOL * scale, 5.0 * ref_noise) + 1e-9, f"{name}: grad {k} err vs fp64 {gerr:.3e} (reference fp32: {ref_noise:.3e}) scale {scale:.3e}"
+            agg[0] += (p.grad.cpu().double() - truth.double()).pow(2).sum().item()
+            agg[1] += (g_ref.double() - truth.double()).pow(2).sum().item()
+            agg[2] += truth.double().pow(2).sum().item()
+        else:
+            gerr = (p.grad.cpu() - g_ref).abs().max().item()
+            assert gerr <= GRAD_RTOL * scale + 1e-9, f"{name}: grad {k} err {gerr:.3e} scale {scale:.3e}"
         worst = max(worst, gerr / scale)
     from tunevlseg_amd import hip
+    if agg[2] > 0:
+        ours, theirs = (agg[0] / agg[2]) ** 0.5, (agg[1] / agg[2]) ** 0.5
+        print(f"PARITY(fp64) case={name} rel-L2 error of all gradients vs the float64 reference: HIP {ours:.3e}, reference fp32 {theirs:.3e}")
+        assert ours <= max(GRAD_RTOL, 2.5 * theirs), (ours, theirs)
     print(f"PARITY mode={hip.GEMM_MODE} case={name} logit_err={err:.3e} loss_err={abs(loss.item() - float(fx['out.loss'])):.2e} "
           f"worst_grad_rel={worst:.3e} label_flips={(lab != lab_ref).sum().item()}")
     return err
@@ -113,6 +133,68 @@ def test_hip_net_matches_reference_tiny(name):
     run_case(name)
 
 
-@pytest.mark.parametrize("name", golden_names("rd64_"))
+@pytest.mark.parametrize("name", [n for n in golden_names("rd64_") if not n.endswith("_b32")])
 def test_hip_net_matches_reference_full_size(name):
     run_case(name)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("rd64_") if not n.endswith("_b32")])
+def test_hip_net_matches_reference_full_size_tp3(name, monkeypatch):
+    """The same B = 1 fixtures forced onto the tp3 kernels (LDS-DMA GEMM ring, tp3-writing LayerNorm / attention) that the
+    benchmarked batch size selects by itself."""
+    from tunevlseg_amd import hip
+
+    monkeypatch.setattr(hip, "TP3_MIN_ROWS", 1)
+    hip.gemm_profile_start()
+    run_case(name)
+    prof = hip.gemm_profile_stop()
+    assert any(k.startswith("gemm_tp3_kernel") for k in prof), sorted(prof)
+
+
+def run_compact_case(name):
+    """Full-batch fixtures (compact form): inputs re-drawn from the seed; compared are the loss, every trainable gradient, the
+    per-sample integer TP/FP/FN/TN counts (bit-exact), per-sample Dice and every 11th logit."""
+    import numpy as np
+
+    from tests.golden_util import check_compact_labels, synth_inputs
+    from tunevlseg_amd import hip, ops
+
+    fx = load_golden(name)
+    m = fx["meta"]
+    assert m["compact"]
+    net = build_net(fx)
+    pix, ids, am, mask = (t.cuda() for t in synth_inputs(config_of(fx), m["B"], m["H"], m["L"], m["input_seed"]))
+    hip.gemm_profile_start()
+    logits = net(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix)
+    loss, isum = ops.DiceCELossFn.apply(logits, mask, 1.0, 0.2, 0.5)
+    loss.backward()
+    prof = hip.gemm_profile_stop()
+    ref_s = torch.from_numpy(fx["out.logits_s11"])
+    err = (logits.detach()[..., ::11, ::11].cpu() - ref_s).abs().max().item()
+    assert err <= LOGIT_TOL, f"{name}: strided logits max abs err {err:.3e}"
+    assert abs(loss.item() - float(fx["out.loss"])) <= 1e-5, (loss.item(), float(fx["out.loss"]))
+    flips = check_compact_labels(fx, logits, isum, mask)
+    tp, fp, fn = (isum[:, i].double().cpu() for i in range(3))
+    den = 2 * tp + fp + fn
+    dice = torch.where(den > 0, 2 * tp / den.clamp(min=1), torch.ones_like(den))
+    assert np.allclose(dice.numpy(), fx["out.dice_per_sample"], atol=1e-3 if flips else 1e-12)
+    worst = 0.0
+    for k, p in net.named_parameters():
+        if not p.requires_grad or k in m["grads_none"]:
+            continue
+        g_ref = torch.from_numpy(fx["grad." + k])
+        scale = g_ref.abs().max().item() + 1e-12
+        gerr = (p.grad.cpu() - g_ref).abs().max().item()
+        assert gerr <= GRAD_RTOL * scale + 1e-9, f"{name}: grad {k} err {gerr:.3e} scale {scale:.3e}"
+        worst = max(worst, gerr / scale)
+    print(f"PARITY(compact) case={name} label_flips_at_ambiguous_pixels={flips} logit_err={err:.3e} loss_err={abs(loss.item() - float(fx['out.loss'])):.2e} worst_grad_rel={worst:.3e} "
+          f"gemm kernels={sorted(prof)}")
+    return prof
+
+
+def test_hip_net_matches_reference_headline_batch():
+    """BASELINE configs[1] exactly (VPT-10 shallow, 352x352, B = 32): the configuration bench.py times.  Its M = 15 840 rows must
+    have gone through the large-tile GEMM (the 192-row tp3 ring), which no B = 1 fixture reaches by itself."""
+    prof = run_compact_case("rd64_vpt_n10_d1_b32")
+    big = [k for k in prof if k.startswith("gemm_tp3_kernel<192") or "gemm_bf16s_kernel<192" in k]
+    assert big, sorted(prof)

@@ -549,7 +549,7 @@ extern "C" int tvl_attn_fwd(const tvlAttnFwdArgs* a, tvlStream_t stream) {
     dim3 grid((a->T + 127) / 128, a->H, a->B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (a->dh == 64 && !a->causal && !a->key_mask && p.Tk == p.T && tvl_attn_mode_bf16s()) {
-        tvl_attn_fwd_bf16s_impl(a, s);
+        tvl_attn_fwd_bf16s_impl(a, nullptr, s);
         TVL_LAUNCH_CHECK("tvl_attn_fwd(bf16s)");
         return 0;
     }
@@ -596,7 +596,7 @@ extern "C" int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream) {
         TVL_LAUNCH_CHECK("tvl_attn_bwd(delta)");
     }
     if (a->dh == 64 && !a->causal && !a->key_mask && p.Tk == p.T && tvl_attn_mode_bf16s()) {
-        tvl_attn_bwd_bf16s_impl(a, s);
+        tvl_attn_bwd_bf16s_impl(a, nullptr, nullptr, s);
         TVL_LAUNCH_CHECK("tvl_attn_bwd(bf16s)");
         return 0;
     }
@@ -606,5 +606,33 @@ extern "C" int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream) {
     dim3 gridk((p.Tk + 127) / 128, a->H, a->B);
     TVL_DH_DISPATCH(a->dh, hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DH>, gridk, dim3(256), 0, s, p));
     TVL_LAUNCH_CHECK("tvl_attn_bwd(dkdv)");
+    return 0;
+}
+
+// ---- vision-tower attention (d_h = 64, no masks) between tp3 GEMMs ---------------------------------------------------------------
+extern "C" int tvl_attn_fwd_tp3(const tvlAttnFwdArgs* a, void* o_tp3, tvlStream_t stream) {
+    TVL_REQUIRE(a && a->q && a->k && a->v && o_tp3, "tvl_attn_fwd_tp3: null pointer");
+    TVL_REQUIRE(a->B > 0 && a->H > 0 && a->T > 0 && a->B <= 65535 && a->H <= 65535, "tvl_attn_fwd_tp3: bad shape");
+    TVL_REQUIRE(a->dh == 64 && !a->causal && !a->key_mask && (a->Tk == 0 || a->Tk == a->T), "tvl_attn_fwd_tp3: d_h = 64 without masks only");
+    TVL_REQUIRE(tvl_attn_mode_bf16s(), "tvl_attn_fwd_tp3: needs the split-bf16 attention kernels (TVL_ATTN_MODE=f32 is set)");
+    TVL_REQUIRE(strides_ok(a->q, a->q_bs, a->q_ts) && strides_ok(a->k, a->k_bs, a->k_ts) && strides_ok(a->v, a->v_bs, a->v_ts) && tvl_aligned16(o_tp3) &&
+                    (!a->o || (tvl_aligned16(a->o) && a->ldo % 4 == 0 && a->ldo >= a->H * 64)),
+                "tvl_attn_fwd_tp3: operands must be 16-byte aligned with strides divisible by 4");
+    tvl_attn_fwd_bf16s_impl(a, o_tp3, reinterpret_cast<hipStream_t>(stream));
+    TVL_LAUNCH_CHECK("tvl_attn_fwd_tp3");
+    return 0;
+}
+
+extern "C" int tvl_attn_bwd_tp3(const tvlAttnBwdArgs* a, const void* o_tp3, void* dqkv_tp3, tvlStream_t stream) {
+    TVL_REQUIRE(a && a->q && a->k && a->v && a->d_o && a->lse && a->delta && o_tp3 && dqkv_tp3, "tvl_attn_bwd_tp3: null pointer");
+    TVL_REQUIRE(a->B > 0 && a->H > 0 && a->T > 0 && a->B <= 65535 && a->H <= 65535, "tvl_attn_bwd_tp3: bad shape");
+    TVL_REQUIRE(a->dh == 64 && !a->causal && !a->key_mask && (a->Tk == 0 || a->Tk == a->T), "tvl_attn_bwd_tp3: d_h = 64 without masks only");
+    TVL_REQUIRE(tvl_attn_mode_bf16s(), "tvl_attn_bwd_tp3: needs the split-bf16 attention kernels (TVL_ATTN_MODE=f32 is set)");
+    TVL_REQUIRE(strides_ok(a->q, a->q_bs, a->q_ts) && strides_ok(a->k, a->k_bs, a->k_ts) && strides_ok(a->v, a->v_bs, a->v_ts) && tvl_aligned16(a->d_o) &&
+                    a->ldo % 4 == 0 && tvl_aligned16(o_tp3) && tvl_aligned16(dqkv_tp3),
+                "tvl_attn_bwd_tp3: operands must be 16-byte aligned with strides divisible by 4");
+    TVL_REQUIRE(!a->dq && !a->dk && !a->dv, "tvl_attn_bwd_tp3: the gradient leaves as the tp3 image only (dq/dk/dv must be NULL)");
+    tvl_attn_bwd_bf16s_impl(a, o_tp3, dqkv_tp3, reinterpret_cast<hipStream_t>(stream));
+    TVL_LAUNCH_CHECK("tvl_attn_bwd_tp3");
     return 0;
 }

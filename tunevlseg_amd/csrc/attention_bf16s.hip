@@ -8,6 +8,7 @@
 // Used for the unmasked vision-tower attention (95 % of the attention FLOPs); masked / small-head cases stay on the
 // exact-fp32 kernel.
 #include "common.h"
+#include "tp3.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -28,6 +29,7 @@ struct Params {
     const float *q, *k, *v; long q_bs, k_bs, v_bs; int q_ts, k_ts, v_ts;
     float* o; int ldo; float* lse;
     int B, H, T; float scale;
+    unsigned char* o_tp3; int o_kb;   // optional: O as the tp3 image of [B*T, H*64] (o_kb = H*64/16), the out_proj GEMM's A operand
 };
 
 __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
@@ -37,19 +39,17 @@ __device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
     bf16x2 t = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(unsigned, t);
 }
-// x[0..N) -> three planes of N/2 dwords each (pieces 1,2 by truncation of the running residual, piece 3 rounded)
+// x[0..N) -> three planes of N/2 dwords each: every piece is the round-to-nearest bf16 of the running residual (tp3.h)
 template <int N>
 __device__ __forceinline__ void split3(float (&x)[N], unsigned (&p0)[N / 2], unsigned (&p1)[N / 2], unsigned (&p2)[N / 2]) {
 #pragma unroll
-    for (int i = 0; i < N / 2; ++i) p0[i] = pack_trunc(fbits(x[2 * i]), fbits(x[2 * i + 1]));
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = x[i] - bfloat(fbits(x[i]) & 0xFFFF0000u);
-#pragma unroll
-    for (int i = 0; i < N / 2; ++i) p1[i] = pack_trunc(fbits(x[2 * i]), fbits(x[2 * i + 1]));
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = x[i] - bfloat(fbits(x[i]) & 0xFFFF0000u);
-#pragma unroll
-    for (int i = 0; i < N / 2; ++i) p2[i] = pack_rn(x[2 * i], x[2 * i + 1]);
+    for (int i = 0; i < N / 2; ++i) {
+        p0[i] = pack_rn(x[2 * i], x[2 * i + 1]);
+        x[2 * i] -= bfloat(p0[i] << 16); x[2 * i + 1] -= bfloat(p0[i] & 0xFFFF0000u);
+        p1[i] = pack_rn(x[2 * i], x[2 * i + 1]);
+        x[2 * i] -= bfloat(p1[i] << 16); x[2 * i + 1] -= bfloat(p1[i] & 0xFFFF0000u);
+        p2[i] = pack_rn(x[2 * i], x[2 * i + 1]);
+    }
 }
 __device__ __forceinline__ bf16x8 frag_of(unsigned a, unsigned b, unsigned c, unsigned d) {
     return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d));
@@ -216,13 +216,16 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (qi < T) {
-        float* ob = p.o + ((long)b * T + qi) * p.ldo + head * DH;
+        const long m = (long)b * T + qi;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(ob + d * 32 + 8 * g + 4 * h) = make_float4(acc_o[d][4 * g] * inv, acc_o[d][4 * g + 1] * inv,
-                                                                                   acc_o[d][4 * g + 2] * inv, acc_o[d][4 * g + 3] * inv);
+            for (int g = 0; g < 4; ++g) {
+                const float v[4] = {acc_o[d][4 * g] * inv, acc_o[d][4 * g + 1] * inv, acc_o[d][4 * g + 2] * inv, acc_o[d][4 * g + 3] * inv};
+                const int col = head * DH + d * 32 + 8 * g + 4 * h;
+                if (p.o) *reinterpret_cast<float4*>(p.o + m * p.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.o_tp3) tp3::store4(p.o_tp3, p.o_kb, m, col, v);   // the two lane halves fill one 16-byte chunk per row
+            }
         if (h == 0 && p.lse) p.lse[((long)b * p.H + head) * T + qi] = (m_run + log2f(l_tot)) * LN2;
     }
 }
@@ -238,6 +241,7 @@ struct BwdParams {
     const float* d_o; int ldo; const float* lse; const float* delta;
     float *dq, *dk, *dv; long dq_bs, dk_bs, dv_bs; int dq_ts, dk_ts, dv_ts;
     int B, H, T; float scale;
+    unsigned char* g_tp3; int g_kb;   // optional: dQ | dK | dV as the tp3 image of the packed gradient [B*T, 3*H*64] (g_kb = 3*H*64/16)
 };
 
 // 8 consecutive fp32 of one row -> three bf16x8 fragments (optionally scaled)
@@ -365,14 +369,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16s_kernel(BwdParams p) 
         __syncthreads();
     }
     if (qi < T) {
-        float* ob = p.dq + b * p.dq_bs + (long)qi * p.dq_ts + head * DH;
+        const long m = (long)b * T + qi;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(ob + d * 32 + 8 * g + 4 * h) =
-                    make_float4(acc_dq[d][4 * g] * p.scale, acc_dq[d][4 * g + 1] * p.scale, acc_dq[d][4 * g + 2] * p.scale,
-                                acc_dq[d][4 * g + 3] * p.scale);
+            for (int g = 0; g < 4; ++g) {
+                const float v[4] = {acc_dq[d][4 * g] * p.scale, acc_dq[d][4 * g + 1] * p.scale, acc_dq[d][4 * g + 2] * p.scale,
+                                    acc_dq[d][4 * g + 3] * p.scale};
+                const int col = head * DH + d * 32 + 8 * g + 4 * h;
+                if (p.dq) *reinterpret_cast<float4*>(p.dq + b * p.dq_bs + (long)qi * p.dq_ts + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.g_tp3) tp3::store4(p.g_tp3, p.g_kb, m, col, v);
+            }
     }
 }
 
@@ -495,26 +502,68 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p
         __syncthreads();
     }
     if (ki < T) {
-        float* okb = p.dk + b * p.dk_bs + (long)ki * p.dk_ts + head * DH;
-        float* ovb = p.dv + b * p.dv_bs + (long)ki * p.dv_ts + head * DH;
+        const long m = (long)b * T + ki;
+        const int D = p.H * DH;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int col = d * 32 + 8 * g + 4 * h;
-                *reinterpret_cast<float4*>(okb + col) = make_float4(acc_dk[d][4 * g] * p.scale, acc_dk[d][4 * g + 1] * p.scale,
-                                                                    acc_dk[d][4 * g + 2] * p.scale, acc_dk[d][4 * g + 3] * p.scale);
-                *reinterpret_cast<float4*>(ovb + col) = make_float4(acc_dv[d][4 * g], acc_dv[d][4 * g + 1], acc_dv[d][4 * g + 2],
-                                                                    acc_dv[d][4 * g + 3]);
+                const int col = head * DH + d * 32 + 8 * g + 4 * h;
+                const float vk[4] = {acc_dk[d][4 * g] * p.scale, acc_dk[d][4 * g + 1] * p.scale, acc_dk[d][4 * g + 2] * p.scale,
+                                     acc_dk[d][4 * g + 3] * p.scale};
+                const float vv[4] = {acc_dv[d][4 * g], acc_dv[d][4 * g + 1], acc_dv[d][4 * g + 2], acc_dv[d][4 * g + 3]};
+                if (p.dk) *reinterpret_cast<float4*>(p.dk + b * p.dk_bs + (long)ki * p.dk_ts + col) = make_float4(vk[0], vk[1], vk[2], vk[3]);
+                if (p.dv) *reinterpret_cast<float4*>(p.dv + b * p.dv_bs + (long)ki * p.dv_ts + col) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                if (p.g_tp3) {
+                    tp3::store4(p.g_tp3, p.g_kb, m, D + col, vk);
+                    tp3::store4(p.g_tp3, p.g_kb, m, 2 * D + col, vv);
+                }
             }
+    }
+}
+
+// delta[b,h,t] = sum_d dO * O with O read from its tp3 image: one wave per (32-row block, head); lane (r, hh) rebuilds 8 columns
+// of 4 k-blocks (32 of the head's 64 columns), the two lane halves are summed by one cross-half shuffle
+__global__ __launch_bounds__(256) void attn_delta_tp3_kernel(const unsigned char* __restrict__ o_tp3, int o_kb, const float* __restrict__ d_o,
+                                                             int ldo, float* __restrict__ delta, int B, int H, int T) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long M = (long)B * T;
+    const long rbs = (M + 31) / 32;
+    const long item = (long)blockIdx.x * 4 + wave;   // (row block, head)
+    if (item >= rbs * H) return;
+    const long rb = item / H;
+    const int head = (int)(item % H);
+    const int r = lane & 31, hh = lane >> 5;
+    const long m = rb * 32 + r;
+    float acc = 0.f;
+    if (m < M) {
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const int kb = head * 4 + kq;
+            const unsigned char* src = o_tp3 + (rb * o_kb + kb) * (long)tp3::BLK + lane * 16;
+            uint4 pl[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) pl[s] = *reinterpret_cast<const uint4*>(src + s * tp3::PIECE);
+            float ov[8];
+            tp3::join8(pl, ov);
+            const float* g = d_o + m * ldo + kb * 16 + hh * 8;
+            const float4 a = *reinterpret_cast<const float4*>(g), c = *reinterpret_cast<const float4*>(g + 4);
+            acc += (ov[0] * a.x + ov[1] * a.y) + (ov[2] * a.z + ov[3] * a.w) + (ov[4] * c.x + ov[5] * c.y) + (ov[6] * c.z + ov[7] * c.w);
+        }
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    if (m < M && hh == 0) {
+        const long bb = m / T, t = m % T;
+        delta[(bb * H + head) * T + t] = acc;
     }
 }
 
 }  // namespace
 
 // internal entry (dispatched from tvl_attn_fwd): d_h = 64, no causal / key mask
-int tvl_attn_fwd_bf16s_impl(const tvlAttnFwdArgs* a, hipStream_t s) {
+int tvl_attn_fwd_bf16s_impl(const tvlAttnFwdArgs* a, void* o_tp3, hipStream_t s) {
     Params p;
+    p.o_tp3 = reinterpret_cast<unsigned char*>(o_tp3); p.o_kb = a->H * DH / 16;
     p.q = a->q; p.k = a->k; p.v = a->v; p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs;
     p.q_ts = a->q_ts; p.k_ts = a->k_ts; p.v_ts = a->v_ts; p.o = a->o; p.ldo = a->ldo; p.lse = a->lse;
     p.B = a->B; p.H = a->H; p.T = a->T; p.scale = a->scale;
@@ -524,8 +573,14 @@ int tvl_attn_fwd_bf16s_impl(const tvlAttnFwdArgs* a, hipStream_t s) {
 }
 
 // dQ + dK/dV kernels (delta is computed by the caller's pre-pass)
-int tvl_attn_bwd_bf16s_impl(const tvlAttnBwdArgs* a, hipStream_t s) {
+int tvl_attn_bwd_bf16s_impl(const tvlAttnBwdArgs* a, const void* o_tp3, void* dqkv_tp3, hipStream_t s) {
     BwdParams p;
+    p.g_tp3 = reinterpret_cast<unsigned char*>(dqkv_tp3); p.g_kb = 3 * a->H * DH / 16;
+    if (o_tp3) {  // delta from the tp3 image of O (the fp32 O was never written)
+        const long items = (((long)a->B * a->T + 31) / 32) * a->H;
+        hipLaunchKernelGGL(attn_delta_tp3_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const unsigned char*>(o_tp3),
+                           a->H * DH / 16, a->d_o, a->ldo, a->delta, a->B, a->H, a->T);
+    }
     p.q = a->q; p.k = a->k; p.v = a->v; p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs;
     p.q_ts = a->q_ts; p.k_ts = a->k_ts; p.v_ts = a->v_ts; p.d_o = a->d_o; p.ldo = a->ldo; p.lse = a->lse; p.delta = a->delta;
     p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.dq_bs = a->dq_bs; p.dk_bs = a->dk_bs; p.dv_bs = a->dv_bs;

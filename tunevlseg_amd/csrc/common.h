@@ -9,8 +9,10 @@
 
 void tvl_set_error(const char* fmt, ...);
 // split-bf16 attention (attention_bf16s.hip), dispatched from tvl_attn_fwd / tvl_attn_bwd for d_h = 64 without masks
-int tvl_attn_fwd_bf16s_impl(const tvlAttnFwdArgs* a, hipStream_t s);
-int tvl_attn_bwd_bf16s_impl(const tvlAttnBwdArgs* a, hipStream_t s);
+// o_tp3 / dqkv_tp3 (may be null): additional outputs as tp3 images (include/tvl_hip.h); with o_tp3 given to the backward, delta
+// is computed from it (a->o is not read)
+int tvl_attn_fwd_bf16s_impl(const tvlAttnFwdArgs* a, void* o_tp3, hipStream_t s);
+int tvl_attn_bwd_bf16s_impl(const tvlAttnBwdArgs* a, const void* o_tp3, void* dqkv_tp3, hipStream_t s);
 int tvl_attn_mode_bf16s(void);
 
 #define TVL_REQUIRE(cond, ...)                \

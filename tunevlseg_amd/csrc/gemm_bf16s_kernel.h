@@ -1,7 +1,7 @@
 // fp32-in / fp32-out GEMM on the bf16 matrix cores by operand splitting (gfx950, v_mfma_f32_32x32x16_bf16).
 //
 // Each fp32 operand element is split, while its tile is staged to LDS, into S bf16 pieces
-//     x = x1 + x2 + ... + xS      (pieces 1..S-1 by truncation of the running residual, the last by round-to-nearest)
+//     x = x1 + x2 + ... + xS      (every piece = round-to-nearest bf16 of the running residual)
 // and the product is accumulated in fp32 over the piece pairs (i, j) with i + j <= S + 1:
 //     S = 1  plain bf16 operands                 1 MFMA  per 32x32x16 step   (16x the f32-MFMA rate)
 //     S = 2  a1b1 + a1b2 + a2b1                  3 MFMAs                     rel. error ~2^-16 per product
@@ -154,18 +154,18 @@ __device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
     return __builtin_bit_cast(unsigned, t);
 }
 
-// split 4 consecutive k-elements into S planes; plane s gets two dwords (4 bf16)
+// split 4 consecutive k-elements into S planes; plane s gets two dwords (4 bf16).  Every plane is the round-to-nearest bf16 of
+// the running residual (see tp3.h): with rounding the dropped piece products are <= 2^-27 |a||b| for S = 3 (2^-24 with truncation)
 template <int S>
 __device__ __forceinline__ void split4(const float4 v, uint2 (&out)[S]) {
     float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        if (s == S - 1) {
-            out[s] = make_uint2(pack_rn(x[0], x[1]), pack_rn(x[2], x[3]));
-        } else {
-            out[s] = make_uint2(pack_trunc(fbits(x[0]), fbits(x[1])), pack_trunc(fbits(x[2]), fbits(x[3])));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = x[i] - bfloat(fbits(x[i]) & 0xFFFF0000u);
+        const unsigned lo = pack_rn(x[0], x[1]), hi = pack_rn(x[2], x[3]);
+        out[s] = make_uint2(lo, hi);
+        if (s < S - 1) {
+            x[0] -= bfloat(lo << 16); x[1] -= bfloat(lo & 0xFFFF0000u);
+            x[2] -= bfloat(hi << 16); x[3] -= bfloat(hi & 0xFFFF0000u);
         }
     }
 }

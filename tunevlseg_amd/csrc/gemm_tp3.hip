@@ -54,8 +54,8 @@ __global__ void tp3_unpack_kernel(const unsigned char* __restrict__ in, long row
             const unsigned ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[2 * e] += bfloat(ww[e] << 16);
-                acc[2 * e + 1] += bfloat(ww[e] & 0xFFFF0000u);
+                acc[2 * e] += tp3::bfloat(ww[e] << 16);
+                acc[2 * e + 1] += tp3::bfloat(ww[e] & 0xFFFF0000u);
             }
         }
         float* yr = y + row * ldy + kb * 16 + h * 8;

@@ -30,17 +30,17 @@
 #include <stdlib.h>
 #include <utility>
 #include "common.h"
+#include "tp3.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
 constexpr int NTH = 512;
 constexpr int NWAVE = 8;
-constexpr int PIECE = 1024;       // bytes: one MFMA operand (32 rows x 16 k bf16)
-constexpr int BLK = 3 * PIECE;    // one (32 x 16) block, three pieces
+using tp3::PIECE;
+using tp3::BLK;
 
 struct Tp3Params {
     int M, N, K;
@@ -83,30 +83,8 @@ __device__ __forceinline__ void wait_groups(int groups, bool extra) {
     else { if (extra) wait_vm<2 * (n0 + 1)>(); else wait_vm<2 * n0>(); }
 }
 
-__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
-__device__ __forceinline__ float bfloat(unsigned u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ unsigned pack_trunc(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
-__device__ __forceinline__ unsigned pack_rn(float lo, float hi) {
-    bf16x2 t = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(unsigned, t);
-}
-
-// 4 consecutive k-elements -> 3 pieces of 4 bf16 (8 bytes) each
-__device__ __forceinline__ void split4(const float (&v)[4], uint2 (&out)[3]) {
-    float x[4] = {v[0], v[1], v[2], v[3]};
-    out[0] = make_uint2(pack_trunc(fbits(x[0]), fbits(x[1])), pack_trunc(fbits(x[2]), fbits(x[3])));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] -= bfloat(fbits(x[i]) & 0xFFFF0000u);
-    out[1] = make_uint2(pack_trunc(fbits(x[0]), fbits(x[1])), pack_trunc(fbits(x[2]), fbits(x[3])));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] -= bfloat(fbits(x[i]) & 0xFFFF0000u);
-    out[2] = make_uint2(pack_rn(x[0], x[1]), pack_rn(x[2], x[3]));
-}
-
-// byte offset of 4 consecutive elements (row, col .. col+3), col % 4 == 0, inside a tp3 image with kblocks = cols / 16
-__device__ __forceinline__ long tp3_off(long row, int col, int kblocks) {
-    return ((row >> 5) * kblocks + (col >> 4)) * (long)BLK + ((((col >> 3) & 1) * 32 + (int)(row & 31)) * 16 + (col & 4) * 2);
-}
+using tp3::split4;
+__device__ __forceinline__ long tp3_off(long row, int col, int kblocks) { return tp3::off4(row, col, kblocks); }
 
 // Epilogue modes.  EPI < 0: every option read from the arguments at run time (any combination the C ABI allows).  EPI >= 0: a
 // bit set of the options below, resolved at compile time -- the epilogue is cold, straight-line code executed once per tile, and

@@ -2,6 +2,7 @@
 // registers (float4 per lane), two-pass variance like torch.  HBM-bound: each row is read once
 // and written once (fwd), or dy/x read once and dx written once (bwd).
 #include "common.h"
+#include "tp3.h"
 
 namespace {
 
@@ -155,6 +156,166 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// ---- LayerNorm whose result feeds tvl_gemm_tp3 ---------------------------------------------------------------------------
+// One workgroup = one 32-row block of the tp3 image.  Phase 1 is the kernel above (one wave per row, the row in registers,
+// coalesced reads): it leaves the row statistics in LDS.  Phase 2 walks the block in fragment order -- lane (r, h) takes 8
+// consecutive columns of row r (re-read from L2), normalises, splits into three bf16 pieces and the wave writes one 1-KiB
+// piece per store instruction (fully coalesced).  The fp32 result is never materialised: its only consumer is the GEMM.
+template <int LN_MAXV>
+__global__ __launch_bounds__(256) void ln_fwd_tp3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, unsigned char* __restrict__ out,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows, int cols,
+                                                         float eps) {
+    __shared__ float s_mean[32], s_rstd[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rb = blockIdx.x;
+    const float inv_n = 1.0f / (float)cols;
+    const int nv = cols >> 2;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int rl = wave * 8 + rr;
+        const long row = rb * 32 + rl;
+        float mean = 0.f, rstd = 0.f;
+        if (row < rows) {
+            const float* xr = x + row * cols;
+            float4 v[LN_MAXV];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) {
+                    v[i] = reinterpret_cast<const float4*>(xr)[c];
+                    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                }
+            }
+            mean = wave_sum(s) * inv_n;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) {
+                    const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                    q += (a * a + b * b) + (cc * cc + d * d);
+                }
+            }
+            rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+            if (lane == 0) {
+                if (mean_out) mean_out[row] = mean;
+                if (rstd_out) rstd_out[row] = rstd;
+            }
+        }
+        if (lane == 0) { s_mean[rl] = mean; s_rstd[rl] = rstd; }
+    }
+    __syncthreads();
+    const int r = lane & 31, h = lane >> 5;
+    const long row = rb * 32 + r;
+    const bool live = row < rows;
+    const float mean = s_mean[r], rstd = s_rstd[r];
+    const int KB = cols >> 4;
+    const float* xr = x + (live ? row : 0) * cols;
+    for (int kb = wave; kb < KB; kb += 4) {
+        const int c0 = kb * 16 + h * 8;
+        float v[8];
+        const float4 a = *reinterpret_cast<const float4*>(xr + c0), b = *reinterpret_cast<const float4*>(xr + c0 + 4);
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (beta) { b0 = *reinterpret_cast<const float4*>(beta + c0); b1 = *reinterpret_cast<const float4*>(beta + c0 + 4); }
+        v[0] = (a.x - mean) * rstd * g0.x + b0.x; v[1] = (a.y - mean) * rstd * g0.y + b0.y;
+        v[2] = (a.z - mean) * rstd * g0.z + b0.z; v[3] = (a.w - mean) * rstd * g0.w + b0.w;
+        v[4] = (b.x - mean) * rstd * g1.x + b1.x; v[5] = (b.y - mean) * rstd * g1.y + b1.y;
+        v[6] = (b.z - mean) * rstd * g1.z + b1.z; v[7] = (b.w - mean) * rstd * g1.w + b1.w;
+        if (!live) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        uint4 pl[3];
+        tp3::split8(v, pl);
+        unsigned char* o = out + (rb * KB + kb) * (long)tp3::BLK + lane * 16;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(o + s * tp3::PIECE) = pl[s];
+    }
+}
+
+// LayerNorm backward (+ residual gradient) writing dx twice: fp32 (the residual stream's gradient, read by the next
+// LayerNorm backward) and tp3 (the A operand of the next data-gradient GEMM).  Phase 1 = ln_bwd_kernel's row pass; phase 2
+// re-reads the block's fresh dx rows (this CU's own stores, drained and fenced) in fragment order.
+template <int LN_MAXV>
+__global__ __launch_bounds__(256) void ln_bwd_tp3_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                         const float* __restrict__ dres, float* __restrict__ dx, unsigned char* __restrict__ out,
+                                                         long rows, int cols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rb = blockIdx.x;
+    const float inv_n = 1.0f / (float)cols;
+    const int nv = cols >> 2;
+    for (int rr = 0; rr < 8; ++rr) {
+        const long row = rb * 32 + wave * 8 + rr;
+        if (row >= rows) break;
+        const float* xr = x + row * cols;
+        const float* dyr = dy + row * cols;
+        float* dxr = dx + row * cols;
+        const float* rres = dres ? dres + row * cols : nullptr;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float4 g[LN_MAXV], xh[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const float4 d = reinterpret_cast<const float4*>(dyr)[c];
+                const float4 xv = reinterpret_cast<const float4*>(xr)[c];
+                const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
+                xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                g[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+            }
+        }
+        const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                float4 o;
+                o.x = rstd * (g[i].x - m1 - xh[i].x * m2);
+                o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
+                o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
+                o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+                if (rres) {
+                    const float4 r4 = reinterpret_cast<const float4*>(rres)[c];
+                    o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
+                }
+                reinterpret_cast<float4*>(dxr)[c] = o;
+            }
+        }
+    }
+    // the block's dx rows are re-read by other waves of this workgroup: drain the stores, then make them visible (the lines
+    // were never in this CU's L1, but the order store -> load across waves still needs the fence + barrier)
+    __threadfence_block();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int r = lane & 31, h = lane >> 5;
+    const long row = rb * 32 + r;
+    const bool live = row < rows;
+    const int KB = cols >> 4;
+    const float* dxr = dx + (live ? row : 0) * cols;
+    for (int kb = wave; kb < KB; kb += 4) {
+        const int c0 = kb * 16 + h * 8;
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dxr + c0));  // past this CU's L1
+        const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dxr + c0 + 4));
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        if (!live) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        uint4 pl[3];
+        tp3::split8(v, pl);
+        unsigned char* o = out + (rb * KB + kb) * (long)tp3::BLK + lane * 16;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(o + s * tp3::PIECE) = pl[s];
+    }
+}
+
 }  // namespace
 
 extern "C" int tvl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
@@ -185,5 +346,34 @@ extern "C" int tvl_layernorm_bwd(const float* dy, const float* x, const float* g
     else if (vec) hipLaunchKernelGGL((ln_bwd_kernel<true, 8>), dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, cols);
     else hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, cols);
     TVL_LAUNCH_CHECK("tvl_layernorm_bwd");
+    return 0;
+}
+
+extern "C" int tvl_layernorm_fwd_tp3(const float* x, const float* gamma, const float* beta, void* y_tp3, float* mean, float* rstd,
+                                     int64_t rows, int32_t cols, float eps, tvlStream_t stream) {
+    TVL_REQUIRE(x && gamma && y_tp3, "tvl_layernorm_fwd_tp3: null pointer");
+    TVL_REQUIRE(rows > 0 && cols > 0 && cols % 16 == 0 && cols <= 2048, "tvl_layernorm_fwd_tp3: need cols %% 16 == 0 and cols <= 2048 (rows=%ld cols=%d)", (long)rows, cols);
+    TVL_REQUIRE(tvl_aligned16(x) && tvl_aligned16(y_tp3) && tvl_aligned16(gamma) && (!beta || tvl_aligned16(beta)), "tvl_layernorm_fwd_tp3: operands must be 16-byte aligned");
+    const unsigned grid = (unsigned)((rows + 31) / 32);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned char* out = reinterpret_cast<unsigned char*>(y_tp3);
+    if (cols <= 1024) hipLaunchKernelGGL(ln_fwd_tp3_kernel<4>, dim3(grid), dim3(256), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps);
+    else hipLaunchKernelGGL(ln_fwd_tp3_kernel<8>, dim3(grid), dim3(256), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps);
+    TVL_LAUNCH_CHECK("tvl_layernorm_fwd_tp3");
+    return 0;
+}
+
+extern "C" int tvl_layernorm_bwd_tp3(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                     const float* dres, float* dx, void* dx_tp3, int64_t rows, int32_t cols, tvlStream_t stream) {
+    TVL_REQUIRE(dy && x && gamma && mean && rstd && dx && dx_tp3, "tvl_layernorm_bwd_tp3: null pointer");
+    TVL_REQUIRE(rows > 0 && cols > 0 && cols % 16 == 0 && cols <= 2048, "tvl_layernorm_bwd_tp3: need cols %% 16 == 0 and cols <= 2048 (rows=%ld cols=%d)", (long)rows, cols);
+    TVL_REQUIRE(tvl_aligned16(x) && tvl_aligned16(dy) && tvl_aligned16(dx) && tvl_aligned16(dx_tp3) && tvl_aligned16(gamma) && (!dres || tvl_aligned16(dres)),
+                "tvl_layernorm_bwd_tp3: operands must be 16-byte aligned");
+    const unsigned grid = (unsigned)((rows + 31) / 32);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned char* out = reinterpret_cast<unsigned char*>(dx_tp3);
+    if (cols <= 1024) hipLaunchKernelGGL(ln_bwd_tp3_kernel<4>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols);
+    else hipLaunchKernelGGL(ln_bwd_tp3_kernel<8>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols);
+    TVL_LAUNCH_CHECK("tvl_layernorm_bwd_tp3");
     return 0;
 }

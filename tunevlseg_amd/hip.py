@@ -133,6 +133,10 @@ _SIGS = {
     "tvl_colsum": [_P, _P, _L, _I, _I],
     "tvl_copy2d": [_P, _I, _P, _I, _L, _I],
     "tvl_conv3x3_bf16s": [C.POINTER(GemmArgs), C.POINTER(ConvGeom), _I],
+    "tvl_layernorm_fwd_tp3": [_P, _P, _P, _P, _P, _P, _L, _I, _F],
+    "tvl_layernorm_bwd_tp3": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
+    "tvl_attn_fwd_tp3": [C.POINTER(AttnFwdArgs), _P],
+    "tvl_attn_bwd_tp3": [C.POINTER(AttnBwdArgs), _P, _P],
     "tvl_tp3_pack": [_P, _L, _L, _I, _P],
     "tvl_tp3_unpack": [_P, _L, _I, _P, _L],
     "tvl_gemm_tp3": [C.POINTER(GemmTp3Args)],
@@ -471,9 +475,64 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None, dgamma=None, dbeta=No
     return dx
 
 
+def layernorm_fwd_tp3(x2d, gamma, beta, eps: float, want_stats=True):
+    """LayerNorm whose only consumer is a tp3 GEMM: returns (Tp3 image of y, mean, rstd); y is never written in fp32."""
+    rows, cols = x2d.shape
+    y = Tp3(rows, cols, x2d.device)
+    mean = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
+    rstd = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
+    _call("tvl_layernorm_fwd_tp3", _p(x2d), _p(gamma), _p(beta), y.buf.data_ptr(), _p(mean), _p(rstd), rows, cols, float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd_tp3(dy2d, x2d, gamma, mean, rstd, dres=None):
+    """dx = [dres +] LN'(dy) as fp32 (the residual stream's gradient) AND as the Tp3 operand of the next data-gradient GEMM."""
+    rows, cols = x2d.shape
+    dx = torch.empty_like(x2d)
+    dxt = Tp3(rows, cols, x2d.device)
+    _call("tvl_layernorm_bwd_tp3", _p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), dxt.buf.data_ptr(), rows, cols)
+    return dx, dxt
+
+
+TP3_MIN_ROWS = int(os.environ.get("TVL_TP3_MIN_ROWS", "1024"))  # below this the layer is launch-latency bound either way
+
+
+def tp3_path_ok(M: int, D: int, F: int, dh: int, causal: bool, key_mask) -> bool:
+    """Can an encoder layer run on the tp3 kernels (GEMM ring + LayerNorm / attention that write tp3)?  d_h = 64 without masks,
+    widths that are multiples of 32, enough rows to fill the chip, fp32-equivalent arithmetic selected."""
+    return (GEMM_MODE == "bf16x6" and os.environ.get("TVL_ATTN_MODE", "")[:1] != "f" and os.environ.get("TVL_TP3", "1") != "0"
+            and dh == 64 and not causal and key_mask is None and D % 32 == 0 and F % 32 == 0 and D >= 64 and M >= TP3_MIN_ROWS)
+
+
 # --------------------------------------------------------------------------------------
 # attention over a packed [B, T, 3*H*dh] QKV buffer
 # --------------------------------------------------------------------------------------
+def attn_fwd_packed_tp3(qkv: torch.Tensor, B: int, T: int, H: int, dh: int, scale: float, want_lse=True):
+    """Unmasked d_h = 64 attention whose output feeds the out_proj tp3 GEMM: returns (Tp3 image of O [B*T, H*dh], lse)."""
+    D = H * dh
+    o = Tp3(B * T, D, qkv.device)
+    lse = torch.empty((B, H, T), device=qkv.device, dtype=torch.float32) if want_lse else None
+    base = _p(qkv)
+    a = AttnFwdArgs(base, base + 4 * D, base + 8 * D, 3 * D * T, 3 * D * T, 3 * D * T, 3 * D, 3 * D, 3 * D, None, D, _p(lse),
+                    None, B, H, T, dh, 0, float(scale))
+    _call("tvl_attn_fwd_tp3", C.byref(a), o.buf.data_ptr())
+    return o, lse
+
+
+def attn_bwd_packed_tp3(qkv, o_tp3: Tp3, d_o, lse, B: int, T: int, H: int, dh: int, scale: float) -> Tp3:
+    """Backward of the above: delta from the Tp3 O, dQ | dK | dV as the Tp3 image of the packed gradient [B*T, 3*H*dh]."""
+    D = H * dh
+    dqkv = Tp3(B * T, 3 * D, qkv.device)
+    delta = torch.empty((B, H, T), device=qkv.device, dtype=torch.float32)
+    base = _p(qkv)
+    s3 = 3 * D
+    a = AttnBwdArgs(base, base + 4 * D, base + 8 * D, s3 * T, s3 * T, s3 * T, s3, s3, s3, None, _p(d_o), D, _p(lse), _p(delta),
+                    None, None, None, 0, 0, 0, 0, 0, 0, None, B, H, T, dh, 0, float(scale))
+    _call("tvl_attn_bwd_tp3", C.byref(a), o_tp3.buf.data_ptr(), dqkv.buf.data_ptr())
+    return dqkv
+
+
+
 def attn_fwd_packed(qkv: torch.Tensor, B: int, T: int, H: int, dh: int, scale: float, causal=False, key_mask=None, want_lse=True):
     D = H * dh
     o = torch.empty((B * T, D), device=qkv.device, dtype=torch.float32)

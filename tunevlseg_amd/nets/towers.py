@@ -56,7 +56,7 @@ def vision_tower(model: CLIPSegBackbone, pixel_values: torch.Tensor, learner=Non
     max_idx = max(model.extract_layers)
     states = [x]
     for idx in range(1, v.num_hidden_layers + 1):
-        x = ops.EncoderLayerFn.apply(x, prep["vision_layers"][idx - 1], spec)
+        x = ops.encoder_layer(x, prep["vision_layers"][idx - 1], spec)
         if prompts is not None and idx < depth:
             x = learner.mutate_image_hidden_states(x, index=idx)
         states.append(x)
@@ -103,7 +103,7 @@ def text_tower(model: CLIPSegBackbone, input_ids: torch.Tensor, attention_mask: 
         key_mask = am.to(torch.int32).contiguous()
     spec = ops.AttnSpec(t.num_attention_heads, _ACT[t.hidden_act], t.layer_norm_eps, causal=True, key_mask=key_mask)
     for idx in range(1, t.num_hidden_layers + 1):
-        x = ops.EncoderLayerFn.apply(x, prep["text_layers"][idx - 1], spec)
+        x = ops.encoder_layer(x, prep["text_layers"][idx - 1], spec)
         if n and idx < depth:
             x = learner.mutate_text_hidden_states(x, index=idx, image_features=image_features)
     x = ops.layer_norm(x, tm.final_layer_norm.weight.detach(), tm.final_layer_norm.bias.detach(), t.layer_norm_eps)

@@ -36,6 +36,17 @@ class LayerWeights:
     wo_t: torch.Tensor | None = None
     w1_t: torch.Tensor | None = None
     w2_t: torch.Tensor | None = None
+    _tp3: dict | None = None
+
+    def tp3(self) -> dict:
+        """The eight weight operands of the layer's tp3 GEMMs (forward: W as stored [N, K]; data gradients: W^T), packed once."""
+        if self._tp3 is None:
+            t = lambda w: w.detach().t().contiguous()  # noqa: E731
+            self._tp3 = {k: hip.tp3_pack(w) for k, w in (
+                ("wqkv", self.wqkv), ("wo", self.wo), ("w1", self.w1), ("w2", self.w2),
+                ("wqkv_t", self.wqkv_t if self.wqkv_t is not None else t(self.wqkv)), ("wo_t", self.wo_t if self.wo_t is not None else t(self.wo)),
+                ("w1_t", self.w1_t if self.w1_t is not None else t(self.w1)), ("w2_t", self.w2_t if self.w2_t is not None else t(self.w2)))}
+        return self._tp3
 
 
 @dataclass
@@ -54,6 +65,80 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # pre-LN encoder layer (HF CLIPSegEncoderLayer, modeling_clipseg.py:341-371)
 # ----------------------------------------------------------------------------------------------
+def _tp3_of(t2d: torch.Tensor) -> "hip.Tp3":
+    """The Tp3 image of a gradient matrix: the one its producer attached (LayerNorm backward writes both forms), else a pack pass."""
+    cached = getattr(t2d, "_tvl_tp3", None)
+    if cached is not None and cached[0] == (t2d.data_ptr(), t2d._version, tuple(t2d.shape)):
+        return cached[1]
+    return hip.tp3_pack(t2d)
+
+
+class EncoderLayerTp3Fn(Fn):
+    """The same layer on the tp3 kernels (hip.tp3_path_ok): every GEMM operand is handed over pre-split and pre-tiled by its
+    producer -- LayerNorm and attention write Tp3 images directly, fc1's epilogue writes QuickGELU(z) as Tp3 (+ z in fp32 for
+    the backward), the fc2 data gradient writes dz as Tp3 -- so no activation is split twice and no fp32 copy exists that
+    only a GEMM would read."""
+
+    @staticmethod
+    def forward(ctx, h, lw: LayerWeights, spec: AttnSpec):
+        h = _c(h)
+        B, T, D = h.shape
+        M = B * T
+        H = spec.heads
+        dh = D // H
+        need = ctx.needs_input_grad[0]
+        W = lw.tp3()
+        h2d = h.view(M, D)
+        x1, mean1, rstd1 = hip.layernorm_fwd_tp3(h2d, lw.ln1_w, lw.ln1_b, spec.eps, want_stats=need)
+        qkv, _ = hip.gemm_tp3(x1, W["wqkv"], bias=lw.bqkv)
+        del x1
+        o, lse = hip.attn_fwd_packed_tp3(qkv, B, T, H, dh, dh**-0.5, want_lse=need)
+        h2, _ = hip.gemm_tp3(o, W["wo"], bias=lw.bo, residual=h2d)
+        x2, mean2, rstd2 = hip.layernorm_fwd_tp3(h2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
+        z = torch.empty((M, lw.w1.shape[0]), device=h.device, dtype=torch.float32) if need else None
+        _, a = hip.gemm_tp3(x2, W["w1"], want_f32=False, want_tp3=True, bias=lw.b1, act=spec.act, pre_out=z)
+        del x2
+        out = torch.empty((B, T, D), device=h.device, dtype=torch.float32)  # a base tensor: deep prompts overwrite rows in place
+        hip.gemm_tp3(a, W["w2"], out=out.view(M, D), bias=lw.b2, residual=h2)
+        if need:
+            ctx.save_for_backward(h2d, mean1, rstd1, qkv, o.buf, lse, h2, mean2, rstd2, z)
+            ctx.lw, ctx.spec, ctx.shape = lw, spec, (B, T, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h2d, mean1, rstd1, qkv, o_buf, lse, h2, mean2, rstd2, z = ctx.saved_tensors
+        lw, spec = ctx.lw, ctx.spec
+        B, T, D = ctx.shape
+        M = B * T
+        H = spec.heads
+        dh = D // H
+        W = lw.tp3()
+        dout2d = _c(dout).view(M, D)
+        _, dz = hip.gemm_tp3(_tp3_of(dout2d), W["w2_t"], want_f32=False, want_tp3=True, dact=spec.act, dact_aux=z)
+        dx2, _ = hip.gemm_tp3(dz, W["w1_t"])
+        del dz
+        dh2, dh2_t = hip.layernorm_bwd_tp3(dx2, h2, lw.ln2_w, mean2, rstd2, dres=dout2d)
+        del dx2
+        do, _ = hip.gemm_tp3(dh2_t, W["wo_t"])
+        del dh2_t
+        dqkv = hip.attn_bwd_packed_tp3(qkv, hip.Tp3(M, D, o_buf.device, o_buf), do, lse, B, T, H, dh, dh**-0.5)
+        del do
+        dx1, _ = hip.gemm_tp3(dqkv, W["wqkv_t"])
+        del dqkv
+        dh_in, dh_in_t = hip.layernorm_bwd_tp3(dx1, h2d, lw.ln1_w, mean1, rstd1, dres=dh2)
+        dh_in._tvl_tp3 = ((dh_in.data_ptr(), dh_in._version, (M, D)), dh_in_t)  # the next layer's backward starts with a tp3 GEMM on it
+        return dh_in.view(B, T, D), None, None
+
+
+def encoder_layer(h, lw: LayerWeights, spec: AttnSpec):
+    """One pre-LN encoder layer; picks the tp3 kernels when the shape qualifies."""
+    B, T, D = h.shape
+    if hip.tp3_path_ok(B * T, D, lw.w1.shape[0], D // spec.heads, spec.causal, spec.key_mask):
+        return EncoderLayerTp3Fn.apply(h, lw, spec)
+    return EncoderLayerFn.apply(h, lw, spec)
+
+
 class EncoderLayerFn(Fn):
     @staticmethod
     def forward(ctx, h, lw: LayerWeights, spec: AttnSpec):
