@@ -25,6 +25,9 @@ def run_oracle(fx):
         return logits.detach(), loss.detach(), params
     cfg, sd = config_of(fx), state_of(fx)
     params = trainable_of(fx)
+    for k, v in params.items():  # no_freeze_last_layer: the (trainable) transposed conv of the fixture replaces the frozen one
+        if k.startswith("model."):
+            sd[k[len("model."):]] = v
     learner = oracle_learner(fx, params)
     pix, ids, am, mask = inputs_of(fx)
     kind = fx["meta"]["net"]
@@ -64,7 +67,7 @@ def test_oracle_matches_reference_tiny(name):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("name", golden_names("rd64_"))
+@pytest.mark.parametrize("name", [n for n in golden_names("rd64_") if not n.endswith("_b32")])  # compact full-batch fixtures: HIP-vs-reference only
 def test_oracle_matches_reference_full_size(name):
     check(load_golden(name))
 
@@ -75,6 +78,6 @@ def test_cris_oracle_matches_reference_tiny(name):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("name", golden_names("cris_rn50_"))
+@pytest.mark.parametrize("name", [n for n in golden_names("cris_rn50_") if not n.endswith("_b8")])
 def test_cris_oracle_matches_reference_full_size(name):
     check(load_golden(name))

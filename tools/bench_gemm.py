@@ -18,6 +18,8 @@ if len(sys.argv) > 1 and sys.argv[1] != "f32":  # split-bf16 runs data gradients
 
 
 TP3 = len(sys.argv) > 1 and sys.argv[1].startswith("tp3")
+if TP3:  # the two GEMMs whose epilogue moves the most bytes, with their real epilogues (ops.EncoderLayerTp3Fn)
+    SHAPES += [("fc1* NT", hip.NT, M, 3072, 768), ("dz*  NT", hip.NT, M, 3072, 768), ("out* NT", hip.NT, M, 768, 768)]
 
 
 def main():
@@ -41,17 +43,26 @@ def main():
         C = torch.empty(m, n, device="cuda")
         if TP3:  # operands handed over pre-tiled (activations by their producer, weights once)
             A, B = hip.tp3_pack(A), hip.tp3_pack(B)
-        bufs[name] = (A, B, C)
+        extra = {}
+        if name.startswith("fc1*"):
+            extra = dict(want_f32=False, out_tp3=hip.Tp3(m, n, "cuda"), bias=torch.randn(n, device="cuda"), act=hip.ACT_QUICK_GELU, pre_out=C)
+        elif name.startswith("dz*"):
+            extra = dict(want_f32=False, out_tp3=hip.Tp3(m, n, "cuda"), dact=hip.ACT_QUICK_GELU, dact_aux=torch.randn(m, n, device="cuda"))
+        elif name.startswith("out*"):
+            extra = dict(out=C, bias=torch.randn(n, device="cuda"), residual=torch.randn(m, n, device="cuda"))
+        elif TP3:
+            extra = dict(out=C)
+        bufs[name] = (A, B, C, extra)
     rounds = 5
     times = {s[0]: [] for s in SHAPES}
     for r in range(rounds + 1):
         for name, layout, m, n, k in SHAPES:
-            A, B, C = bufs[name]
+            A, B, C, extra = bufs[name]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
                 if TP3:
-                    hip.gemm_tp3(A, B, out=C)
+                    hip.gemm_tp3(A, B, **extra)
                 else:
                     hip.gemm(layout, m, n, k, A, A.shape[1], B, B.shape[1], C, n)
             e1.record()

@@ -422,8 +422,9 @@ extern "C" int tvl_pixel_unshuffle_bwd(const float* dlogits, float a, float* dco
 extern "C" int tvl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int32_t step_t, float grad_scale, tvlStream_t stream) {
     TVL_REQUIRE(p && g && m && v && n > 0 && step_t >= 1, "tvl_adamw: bad arguments");
-    const float bc1 = 1.0f - powf(beta1, (float)step_t);
-    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step_t));
+    // bias corrections in double on the host, as torch.optim.AdamW computes them (fp32 powf is ~1e-5 off in the step size at small t)
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step_t));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step_t));
     hipLaunchKernelGGL(adamw_kernel, GRID_FOR((long)n), dim3(256), 0, S_(stream), p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay,
                        bc1, bc2_sqrt, grad_scale);
     TVL_LAUNCH_CHECK("tvl_adamw");

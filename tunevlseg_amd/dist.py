@@ -85,6 +85,82 @@ class FlatParams:
         return 1.0 / w
 
 
+class GradExchange:
+    """Gradient exchange overlapped with the backward pass (north_star: "RCCL all-reduce of prompt-parameter grads ...
+    overlapped with the backward"; reference: Lightning DDP's bucketed reducer, configs/trainer/ddp.yaml:4-9).
+
+    The flat gradient is cut into contiguous buckets (whole parameters, >= ``bucket_bytes`` each).  A post-accumulate-grad hook
+    per parameter counts arrivals; the moment a bucket's last gradient has been accumulated its SUM all-reduce is enqueued
+    asynchronously (RCCL runs it on its own stream, behind an event on the compute stream), so for deep prompts the slices of
+    the upper layers travel while the lower layers are still in backward.  ``finish()`` enqueues what never fired (parameters
+    without a gradient this step), waits for every collective and returns the 1/world scale the optimiser applies.  With
+    gradient accumulation the hooks stay disarmed until the boundary micro-step, so only the accumulated total is exchanged.
+    """
+
+    def __init__(self, flat: FlatParams, bucket_bytes: int | None = None):
+        if bucket_bytes is None:  # 1 MiB: VPT-10 is one bucket, MaPLe depth 9 (3 MB of gradients) three
+            bucket_bytes = int(os.environ.get("TVL_DDP_BUCKET_BYTES", 1 << 20))
+        self.flat = flat
+        self.armed = True
+        self.buckets: list[tuple[int, int, int]] = []  # (start, end, number of parameters)
+        self.bucket_of: list[int] = []
+        start, count = 0, 0
+        for i, (off, k) in enumerate(flat.offsets):
+            self.bucket_of.append(len(self.buckets))
+            count += 1
+            if (off + k - start) * 4 >= bucket_bytes or i == len(flat.offsets) - 1:
+                self.buckets.append((start, off + k, count))
+                start, count = off + k, 0
+        self._arrived = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._works: list = []
+        self.launched_in_backward = 0  # statistic: buckets whose all-reduce was enqueued from inside backward (tests / DESIGN.md)
+        for i, prm in enumerate(flat.params):
+            prm.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
+
+    def _launch(self, b: int) -> None:
+        s, e, _ = self.buckets[b]
+        self._works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        self._launched[b] = True
+
+    def _on_grad(self, i: int) -> None:
+        if not self.armed or world_size() == 1:
+            return
+        b = self.bucket_of[i]
+        self._arrived[b] += 1
+        if self._arrived[b] == self.buckets[b][2] and not self._launched[b]:
+            self._launch(b)
+            self.launched_in_backward += 1
+
+    def finish(self) -> float:
+        w = world_size()
+        if w > 1:
+            for b in range(len(self.buckets)):
+                if not self._launched[b]:
+                    self._launch(b)
+            for wk in self._works:
+                wk.wait()
+        self._works.clear()
+        self._arrived = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        return 1.0 / w
+
+
+def reduce_sums(values: list[float]) -> list[float]:
+    """SUM of a few python floats over the ranks (validation loss totals, stop flags); identity for world size 1."""
+    if world_size() == 1:
+        return list(values)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
+def barrier() -> None:
+    if world_size() > 1:
+        dist.barrier()
+
+
 def allreduce_counts(counts: torch.Tensor) -> torch.Tensor:
     """Integer confusion counts: exact SUM across ranks (torchmetrics JaccardIndex state sync)."""
     if world_size() > 1:

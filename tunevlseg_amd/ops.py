@@ -65,12 +65,12 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # pre-LN encoder layer (HF CLIPSegEncoderLayer, modeling_clipseg.py:341-371)
 # ----------------------------------------------------------------------------------------------
-def _tp3_of(t2d: torch.Tensor) -> "hip.Tp3":
-    """The Tp3 image of a gradient matrix: the one its producer attached (LayerNorm backward writes both forms), else a pack pass."""
+def _tp3_of(t2d: torch.Tensor):
+    """The Tp3 image its producer attached to a gradient tensor (LayerNorm backward writes both forms), if still valid."""
     cached = getattr(t2d, "_tvl_tp3", None)
-    if cached is not None and cached[0] == (t2d.data_ptr(), t2d._version, tuple(t2d.shape)):
+    if cached is not None and cached[0] == (t2d.data_ptr(), t2d._version, t2d.numel()):
         return cached[1]
-    return hip.tp3_pack(t2d)
+    return None
 
 
 class EncoderLayerTp3Fn(Fn):
@@ -115,7 +115,8 @@ class EncoderLayerTp3Fn(Fn):
         dh = D // H
         W = lw.tp3()
         dout2d = _c(dout).view(M, D)
-        _, dz = hip.gemm_tp3(_tp3_of(dout2d), W["w2_t"], want_f32=False, want_tp3=True, dact=spec.act, dact_aux=z)
+        dout_t = _tp3_of(dout) or hip.tp3_pack(dout2d)   # attached by the layer above's LayerNorm backward, unless autograd summed into it
+        _, dz = hip.gemm_tp3(dout_t, W["w2_t"], want_f32=False, want_tp3=True, dact=spec.act, dact_aux=z)
         dx2, _ = hip.gemm_tp3(dz, W["w1_t"])
         del dz
         dh2, dh2_t = hip.layernorm_bwd_tp3(dx2, h2, lw.ln2_w, mean2, rstd2, dres=dout2d)
@@ -127,8 +128,9 @@ class EncoderLayerTp3Fn(Fn):
         dx1, _ = hip.gemm_tp3(dqkv, W["wqkv_t"])
         del dqkv
         dh_in, dh_in_t = hip.layernorm_bwd_tp3(dx1, h2d, lw.ln1_w, mean1, rstd1, dres=dh2)
-        dh_in._tvl_tp3 = ((dh_in.data_ptr(), dh_in._version, (M, D)), dh_in_t)  # the next layer's backward starts with a tp3 GEMM on it
-        return dh_in.view(B, T, D), None, None
+        g = dh_in.view(B, T, D)
+        g._tvl_tp3 = ((g.data_ptr(), g._version, g.numel()), dh_in_t)  # the layer below starts its backward with a tp3 GEMM on this
+        return g, None, None
 
 
 def encoder_layer(h, lw: LayerWeights, spec: AttnSpec):

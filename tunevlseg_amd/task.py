@@ -168,37 +168,30 @@ class ImageTextMaskModule(nn.Module):
             self.metrics[f"{stage}_iou"].reset()
         return out
 
-    # ---- optimiser groups: reference ``get_optim_groups`` (image_text_mask_module.py:304-361) ----
+    # ---- optimiser groups (reference ``get_optim_groups``, image_text_mask_module.py:304-361) ----
     def get_optim_groups(self):
-        if self.hparams["weight_decay"] <= 0:
+        """Without weight decay: all parameters in one group.  With it: weights of ``nn.Linear`` / conv modules and fused
+        attention ``*proj_weight`` tensors decay; everything else (prompt vectors, ``residual_ratio``, norm weights, biases,
+        embeddings and the frozen backbone tensors, which live in plain containers) does not."""
+        wd = self.hparams["weight_decay"]
+        if wd <= 0:
             return self.parameters()
-        decay, no_decay = set(), set()
-        whitelist = (nn.Linear, nn.modules.conv._ConvNd)
-        blacklist = (nn.Embedding, nn.GroupNorm, nn.LayerNorm, nn.modules.batchnorm._NormBase)
-        for mn, m in self.named_modules():
-            for pn, _ in m.named_parameters():
-                fpn = f"{mn}.{pn}" if mn else pn
-                if pn.endswith("proj_weight"):
-                    decay.add(fpn)
-                elif pn.endswith("weight"):
-                    if isinstance(m, whitelist):
-                        decay.add(fpn)
-                    elif isinstance(m, blacklist):
-                        no_decay.add(fpn)
-                else:
-                    no_decay.add(fpn)
-        param_dict = dict(self.named_parameters())
-        # frozen backbone tensors live in plain containers (not nn.Linear): they never decay and never train
-        for fpn, p in param_dict.items():
-            if fpn not in decay and fpn not in no_decay:
-                no_decay.add(fpn)
-        inter = decay & no_decay
-        if inter:
-            raise ValueError(f"parameters {inter} made it into both decay/no_decay sets!")
-        return [
-            {"params": [param_dict[pn] for pn in sorted(decay)], "weight_decay": self.hparams["weight_decay"]},
-            {"params": [param_dict[pn] for pn in sorted(no_decay)], "weight_decay": 0.0},
-        ]
+        decaying_modules = (nn.Linear, nn.modules.conv._ConvNd)
+
+        def decays(module: nn.Module, leaf: str) -> bool:
+            return leaf.endswith("proj_weight") or (leaf.endswith("weight") and isinstance(module, decaying_modules))
+
+        owner = {}  # full parameter name -> does it decay?  (a tensor reachable under two names must agree with itself)
+        for prefix, module in self.named_modules():
+            for leaf, _ in module.named_parameters(recurse=False):
+                full = f"{prefix}.{leaf}" if prefix else leaf
+                verdict = decays(module, leaf)
+                if owner.setdefault(full, verdict) != verdict:
+                    raise ValueError(f"parameter {full} made it into both decay/no_decay sets!")
+        named = dict(self.named_parameters())
+        yes = [named[k] for k in sorted(named) if owner.get(k, False)]
+        no = [named[k] for k in sorted(named) if not owner.get(k, False)]
+        return [{"params": yes, "weight_decay": wd}, {"params": no, "weight_decay": 0.0}]
 
     def configure_optimizers(self) -> dict[str, Any]:
         optimizer = self.optimizer(self.get_optim_groups())
@@ -210,38 +203,61 @@ class ImageTextMaskModule(nn.Module):
 
 
 class FusedAdamW:
-    """``torch.optim.AdamW`` semantics over :class:`tunevlseg_amd.dist.FlatParams` (one HIP launch per group per step).
+    """``torch.optim.AdamW`` semantics over ONE :class:`tunevlseg_amd.dist.FlatParams` buffer.
 
-    Parameter groups keep their own ``weight_decay`` (decay / no-decay split of ``get_optim_groups``); frozen
-    parameters passed in by the reference-style ``self.parameters()`` call are skipped, as AdamW skips grad-less ones.
+    All trainable parameters of all groups are re-homed into one flat fp32 buffer (group after group), so the data-parallel
+    exchange is one bucketed, backward-overlapped all-reduce (:class:`tunevlseg_amd.dist.GradExchange`) whatever the number of
+    groups, and each group -- a contiguous segment with its own ``lr`` / ``weight_decay`` (decay / no-decay split of
+    ``get_optim_groups``) -- is one ``tvl_adamw`` launch.  Frozen parameters passed in by the reference-style
+    ``self.parameters()`` call are skipped, as AdamW skips grad-less ones.
     """
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
         groups = list(params)
         if groups and not isinstance(groups[0], dict):
             groups = [{"params": groups}]
+        kept = [(g, [p for p in g["params"] if p.requires_grad]) for g in groups]
+        kept = [(g, ps) for g, ps in kept if ps]
+        if not kept:
+            raise ValueError("no trainable parameters")
+        self.flat = tdist.FlatParams([p for _, ps in kept for p in ps])
+        self.m = torch.zeros_like(self.flat.data)
+        self.v = torch.zeros_like(self.flat.data)
+        self.exchange = tdist.GradExchange(self.flat)
         self.param_groups = []
-        for g in groups:
-            ps = [p for p in g["params"] if p.requires_grad]
-            if not ps:
-                continue
-            flat = tdist.FlatParams(ps)
-            self.param_groups.append({"flat": flat, "params": ps, "lr": g.get("lr", lr), "betas": g.get("betas", betas),
+        off = 0
+        for g, ps in kept:
+            n = sum(p.numel() for p in ps)
+            self.param_groups.append({"params": ps, "span": (off, off + n), "lr": g.get("lr", lr), "betas": g.get("betas", betas),
                                       "eps": g.get("eps", eps), "weight_decay": g.get("weight_decay", weight_decay),
-                                      "m": torch.zeros_like(flat.data), "v": torch.zeros_like(flat.data)})
+                                      "m": self.m[off:off + n], "v": self.v[off:off + n]})
+            off += n
         self.step_count = 0
 
     def zero_grad(self, set_to_none: bool = False) -> None:
-        for g in self.param_groups:
-            g["flat"].zero_grad()
+        self.flat.zero_grad()
+
+    def set_exchange_armed(self, armed: bool) -> None:
+        """Gradient accumulation: disarm on the micro-steps that do not end in ``step()`` (Lightning's ``no_sync``)."""
+        self.exchange.armed = armed
 
     def step(self) -> None:
         self.step_count += 1
+        scale = self.exchange.finish()  # DDP: SUM over ranks (enqueued during backward), averaged inside the update kernel
         for g in self.param_groups:
-            flat = g["flat"]
-            scale = flat.allreduce_grads()  # DDP: SUM over ranks, averaged inside the update kernel
-            hip.adamw(flat.data, flat.grad, g["m"], g["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
-                      self.step_count, scale)
+            a, b = g["span"]
+            hip.adamw(self.flat.data[a:b], self.flat.grad[a:b], g["m"], g["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                      g["weight_decay"], self.step_count, scale)
+
+    def state_dict(self) -> dict[str, Any]:
+        return {"step": self.step_count, "m": self.m.cpu(), "v": self.v.cpu(), "lr": [g["lr"] for g in self.param_groups]}
+
+    def load_state_dict(self, sd: Mapping[str, Any]) -> None:
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["m"].to(self.m.device))
+        self.v.copy_(sd["v"].to(self.v.device))
+        for g, lr in zip(self.param_groups, sd["lr"]):
+            g["lr"] = lr
 
 
 class ReduceLROnPlateau:
@@ -253,6 +269,12 @@ class ReduceLROnPlateau:
             raise NotImplementedError("mode='min' only")
         self.optimizer, self.factor, self.patience, self.threshold, self.min_lr = optimizer, factor, patience, threshold, min_lr
         self.best, self.num_bad = float("inf"), 0
+
+    def state_dict(self) -> dict[str, float]:
+        return {"best": self.best, "num_bad": self.num_bad}
+
+    def load_state_dict(self, sd: Mapping[str, float]) -> None:
+        self.best, self.num_bad = float(sd["best"]), int(sd["num_bad"])
 
     def step(self, metric: float) -> None:
         if metric < self.best * (1.0 - self.threshold):

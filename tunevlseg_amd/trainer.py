@@ -8,6 +8,7 @@ Batches are dicts with ``image``, ``mask``, ``input_ids``, ``attention_mask`` al
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from pathlib import Path
 from typing import Any, Iterable
@@ -15,109 +16,168 @@ from typing import Any, Iterable
 import torch
 
 from . import dist as tdist
-from .task import FusedAdamW, ImageTextMaskModule, ReduceLROnPlateau
+from .task import ReduceLROnPlateau
+
+
+@contextlib.contextmanager
+def evaluation_mode(module: torch.nn.Module):
+    """``module.eval()`` + ``no_grad`` for validation / test / predict (Lightning runs those stages in eval mode), restoring every
+    submodule's own flag afterwards: the frozen towers stay in eval during training while the learner trains (dropout of the
+    SharedAttn learner's encoder layer: on in fit, off here)."""
+    modes = [(m, m.training) for m in module.modules()]
+    module.eval()
+    try:
+        with torch.no_grad():
+            yield
+    finally:
+        for m, was in modes:
+            m.training = was
 
 
 class Trainer:
     def __init__(self, max_epochs: int = 10, min_epochs: int = 1, accumulate_grad_batches: int = 1, check_val_every_n_epoch: int = 1,
-                 default_root_dir: str | None = None, early_stopping_patience: int | None = 12, monitor: str = "val_dice",
-                 monitor_mode: str = "max", log_fn=print, **_ignored: Any) -> None:
+                 default_root_dir: str | None = None, early_stopping_patience: int | None = 12, early_stopping_min_delta: float = 1e-4,
+                 monitor: str = "val_dice", monitor_mode: str = "max", log_fn=print, **_ignored: Any) -> None:
         self.max_epochs, self.min_epochs = max_epochs, min_epochs
         self.accumulate = max(1, int(accumulate_grad_batches))
         self.check_val_every_n_epoch = check_val_every_n_epoch
         self.root = Path(default_root_dir) if default_root_dir else None
-        self.patience = early_stopping_patience
+        # EarlyStopping(monitor=val_loss, patience=12, min_delta=1e-4, mode=min) -- configs/callbacks/default.yaml:17-21
+        self.patience, self.min_delta = early_stopping_patience, float(early_stopping_min_delta)
         self.monitor, self.monitor_mode = monitor, monitor_mode
         self.log = log_fn if tdist.env_world()[0] == 0 else (lambda *a, **k: None)
         self.best_score: float | None = None
         self.best_path: Path | None = None
         self.callback_metrics: dict[str, float] = {}
+        self.wait_count, self.best_val_loss = 0, math.inf
 
     # ------------------------------------------------------------------ checkpoints
     @staticmethod
-    def trainable_state(module: ImageTextMaskModule) -> dict[str, torch.Tensor]:
+    def trainable_state(module) -> dict[str, torch.Tensor]:
         """Lightning saves the full state_dict; the frozen 150 M backbone never changes, so only trainable tensors are
         written here (same key names: ``net.context_learner.context_vectors`` ...)."""
         return {k: p.detach().cpu().clone() for k, p in module.named_parameters() if p.requires_grad}
 
-    def save(self, module, opt: FusedAdamW, epoch: int, name: str) -> Path | None:
-        if self.root is None or tdist.env_world()[0] != 0:
+    def save(self, module, opt, epoch: int, name: str, sched=None) -> Path | None:
+        """Rank 0 writes ``<root>/<name>.ckpt``; EVERY rank returns the path once the file is complete (barrier), so that
+        ``test(ckpt_path="best")`` loads the same weights everywhere."""
+        if self.root is None:
             return None
-        self.root.mkdir(parents=True, exist_ok=True)
         path = self.root / f"{name}.ckpt"
-        torch.save({"epoch": epoch, "state_dict": self.trainable_state(module), "optimizer_step": opt.step_count,
-                    "adam": [{"m": g["m"].cpu(), "v": g["v"].cpu(), "lr": g["lr"]} for g in opt.param_groups],
-                    "callback_metrics": dict(self.callback_metrics)}, path)
+        if tdist.env_world()[0] == 0:
+            self.root.mkdir(parents=True, exist_ok=True)
+            ck = {"epoch": epoch, "state_dict": self.trainable_state(module), "callback_metrics": dict(self.callback_metrics),
+                  "early_stopping": {"wait_count": self.wait_count, "best_val_loss": self.best_val_loss},
+                  "checkpoint_callback": {"best_score": self.best_score}}
+            if hasattr(opt, "state_dict"):
+                ck["optimizer"] = opt.state_dict()
+            if sched is not None and hasattr(sched, "state_dict"):
+                ck["lr_scheduler"] = sched.state_dict()
+            tmp = path.with_suffix(".tmp")
+            torch.save(ck, tmp)
+            tmp.replace(path)
+        tdist.barrier()
         return path
 
-    @staticmethod
-    def load(module, path: str | Path, opt: FusedAdamW | None = None) -> dict:
+    def load(self, module, path: str | Path, opt=None, sched=None) -> dict:
+        """Restores trainable tensors (matched by name against parameters AND buffers; a reference Lightning checkpoint carries
+        the frozen backbone and buffers too: equal-shaped entries are copied, unknown ones reported), optimiser moments,
+        scheduler and early-stopping state."""
         ck = torch.load(path, map_location="cpu", weights_only=False)
-        own = dict(module.named_parameters())
+        own = {**dict(module.named_buffers()), **dict(module.named_parameters())}
+        unknown = []
         with torch.no_grad():
             for k, v in ck["state_dict"].items():
-                own[k].copy_(v.to(own[k].device))
-        if opt is not None:
-            opt.step_count = ck.get("optimizer_step", 0)
-            for g, s in zip(opt.param_groups, ck.get("adam", [])):
-                g["m"].copy_(s["m"].to(g["m"].device))
-                g["v"].copy_(s["v"].to(g["v"].device))
-                g["lr"] = s["lr"]
+                if k in own and tuple(own[k].shape) == tuple(v.shape):
+                    own[k].copy_(v.to(own[k].device))
+                else:
+                    unknown.append(k)
+        if unknown:
+            self.log(f"checkpoint {path}: {len(unknown)} entries without a matching tensor here were skipped, e.g. {unknown[:3]}")
+        if opt is not None and "optimizer" in ck and hasattr(opt, "load_state_dict"):
+            opt.load_state_dict(ck["optimizer"])
+        if sched is not None and "lr_scheduler" in ck and hasattr(sched, "load_state_dict"):
+            sched.load_state_dict(ck["lr_scheduler"])
+        es = ck.get("early_stopping")
+        if es:
+            self.wait_count, self.best_val_loss = int(es["wait_count"]), float(es["best_val_loss"])
+        self.best_score = ck.get("checkpoint_callback", {}).get("best_score", self.best_score)
         return ck
 
     # ------------------------------------------------------------------ loops
-    def _run_eval(self, module: ImageTextMaskModule, loader: Iterable, stage: str) -> dict[str, float]:
+    def _run_eval(self, module, loader: Iterable, stage: str) -> dict[str, float]:
         step = module.validation_step if stage == "val" else module.test_step
         total, n = 0.0, 0
-        for i, batch in enumerate(loader):
-            loss = step(batch, i)
-            total += float(torch.nan_to_num(loss.detach(), nan=float("inf")).item()) * len(batch["image"])
-            n += len(batch["image"])
-        out = module.epoch_metrics(stage)
-        out[f"{stage}_loss"] = total / max(n, 1)  # rank-local, as the reference logs it (sync_dist unset)
+        with evaluation_mode(module):
+            for i, batch in enumerate(loader):
+                loss = step(batch, i)
+                total += float(torch.nan_to_num(loss.detach(), nan=float("inf")).item()) * len(batch["image"])
+                n += len(batch["image"])
+            out = module.epoch_metrics(stage)
+        # every rank sees its own shard of the data: the scheduler, the early-stopping test and the logs must all read ONE number,
+        # the sample-weighted mean over ranks (Lightning syncs the stopping decision; a rank-local loss desynchronises the LR)
+        total, n = tdist.reduce_sums([total, float(n)])
+        out[f"{stage}_loss"] = total / max(n, 1.0)
         return out
 
-    def fit(self, module: ImageTextMaskModule, train_loader: Iterable, val_loader: Iterable | None = None, ckpt_path: str | None = None):
+    def fit(self, module, train_loader: Iterable, val_loader: Iterable | None = None, ckpt_path: str | None = None):
         module.setup("fit")
         conf = module.configure_optimizers()
-        opt: FusedAdamW = conf["optimizer"]
+        opt = conf["optimizer"]
         sched = conf.get("lr_scheduler", {}).get("scheduler")
         start_epoch = 0
         if ckpt_path:
-            start_epoch = self.load(module, ckpt_path, opt)["epoch"] + 1
-        bad_epochs, best_val_loss = 0, math.inf
+            start_epoch = self.load(module, ckpt_path, opt, sched)["epoch"] + 1
+        arm = getattr(opt, "set_exchange_armed", lambda armed: None)
         for epoch in range(start_epoch, self.max_epochs):
             opt.zero_grad()
-            running, n_batches = 0.0, 0
+            running, n_batches, pending = 0.0, 0, 0
+            n_train = len(train_loader) if hasattr(train_loader, "__len__") else None
             for i, batch in enumerate(train_loader):
+                boundary = (i + 1) % self.accumulate == 0 or (n_train is not None and i + 1 == n_train)
+                arm(boundary)  # the gradient all-reduce rides on the backward of the micro-step that ends in step()
                 loss = module.training_step(batch, i)
                 (loss / self.accumulate).backward()
-                if (i + 1) % self.accumulate == 0:
+                pending += 1
+                if boundary:
                     opt.step()
                     opt.zero_grad()
+                    pending = 0
                 running += float(loss.detach().item())
                 n_batches += 1
+            if pending:  # loader without a length: the leftover micro-batches of the epoch still make a step
+                arm(True)
+                opt.step()
+                opt.zero_grad()
             metrics = module.epoch_metrics("train")
             metrics["train_loss"] = running / max(n_batches, 1)
+            stop = False
             if val_loader is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
                 metrics.update(self._run_eval(module, val_loader, "val"))
-                if isinstance(sched, ReduceLROnPlateau):
+                if isinstance(sched, ReduceLROnPlateau) or hasattr(sched, "step"):
                     sched.step(metrics["val_loss"])
                 score = metrics.get(self.monitor)
                 improved = score is not None and (self.best_score is None or (
                     score > self.best_score if self.monitor_mode == "max" else score < self.best_score))
-                if improved:
+                self.callback_metrics = metrics
+                if improved:  # the metrics are all-reduced, so every rank takes the same branch (save() holds a barrier)
                     self.best_score = score
-                    self.best_path = self.save(module, opt, epoch, "best") or self.best_path
-                if metrics["val_loss"] < best_val_loss:
-                    best_val_loss, bad_epochs = metrics["val_loss"], 0
+                    self.best_path = self.save(module, opt, epoch, "best", sched) or self.best_path
+                # Lightning EarlyStopping: improvement = monitor < best - min_delta; stop when wait_count >= patience
+                if not math.isfinite(metrics["val_loss"]):
+                    stop = True
+                elif metrics["val_loss"] < self.best_val_loss - self.min_delta:
+                    self.best_val_loss, self.wait_count = metrics["val_loss"], 0
                 else:
-                    bad_epochs += 1
+                    self.wait_count += 1
+                    stop = self.patience is not None and self.wait_count >= self.patience
             self.callback_metrics = metrics
-            self.save(module, opt, epoch, "last")
+            self.save(module, opt, epoch, "last", sched)
             self.log(f"epoch {epoch}: " + " ".join(f"{k}={v:.5f}" for k, v in sorted(metrics.items())))
-            if self.patience is not None and bad_epochs > self.patience and epoch + 1 >= self.min_epochs:
-                self.log(f"early stopping at epoch {epoch} (val_loss did not improve for {bad_epochs} epochs)")
+            # one decision for all ranks (they computed it from reduced numbers; the reduction makes that an invariant, not a hope)
+            stop = tdist.reduce_sums([1.0 if stop else 0.0])[0] > 0
+            if stop and epoch + 1 >= self.min_epochs:
+                self.log(f"early stopping at epoch {epoch} (val_loss did not improve by {self.min_delta} for {self.wait_count} checks)")
                 break
         return self.callback_metrics
 
