@@ -178,8 +178,11 @@ int tvl_upconv_taps_bwd(const float* dout, float* dtaps, int32_t ldg, float* wor
 /* per-sample sums over N = H*W pixels, one pass:
  *   fsum[b] = {sum p*t, sum p, sum t, sum bce}  (float64 x4)   p = sigmoid(logit)
  *   isum[b] = {TP, FP, FN, TN} of (p > thr) vs (int64)t  (int64 x4, bit-exact)
- * label (may be NULL): uint8 thresholded map */
-int tvl_dicece_stats(const float* logits, const float* target, double* fsum, int64_t* isum, uint8_t* label,
+ * label (may be NULL): uint8 thresholded map.  work: tvl_dicece_work_doubles(B, N) doubles -- per-workgroup partial sums, added in
+ * a fixed order by a second kernel, so fsum (hence the loss) is bitwise reproducible; the integer counts are exact anyway.
+ * Definitions pinned by the hand-derived known-answer vectors tests/golden/loss_metric_kav.json. */
+int64_t tvl_dicece_work_doubles(int32_t B, int64_t N);
+int tvl_dicece_stats(const float* logits, const float* target, double* fsum, int64_t* isum, uint8_t* label, double* work,
                      int32_t B, int64_t N, float thr, tvlStream_t stream);
 /* dlogits = gscale * ( lambda_dice * dDice/dlogit + lambda_ce * (p - t)/(B*N) ), using fsum from tvl_dicece_stats */
 int tvl_dicece_bwd(const float* logits, const float* target, const double* fsum, float* dlogits,

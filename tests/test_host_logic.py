@@ -158,3 +158,29 @@ def test_weight_draw_is_deterministic():
     assert all(torch.equal(a[k], b[k]) for k in a)
     c = init_clipseg_state_dict(CLIPSegConfig.tiny(), 6)
     assert not torch.equal(a["decoder.film_mul.weight"], c["decoder.film_mul.weight"])
+
+
+def _kav():
+    import json
+    from pathlib import Path
+
+    return json.loads((Path(__file__).resolve().parent / "golden" / "loss_metric_kav.json").read_text())
+
+
+@pytest.mark.parametrize("case", [c for c in _kav()["cases"] if c["asserted"]], ids=lambda c: c["name"])
+def test_oracle_loss_and_metrics_match_hand_derived_vectors(case):
+    """Rows L1 / L2: the oracle's DiceCE / Dice(samples) / binary IoU against vectors derived by hand from the published monai /
+    torchmetrics definitions (tests/golden/make_loss_kav.py) -- the pin that does not pass through this repo's own restatement."""
+    kav = _kav()
+    x = torch.tensor(case["logits"], dtype=torch.float32)[:, None, :, None]   # [B, 1, N, 1]
+    t = torch.tensor(case["mask"], dtype=torch.float32)[:, None, :, None]
+    e = case["expect"]
+    assert abs(O.dice_ce_loss(x, t, kav["lambda_dice"], kav["lambda_ce"]).item() - e["loss"]) < 2e-6
+    tp, fp, fn, tn = O.confusion_counts(torch.sigmoid(x), t.long(), kav["threshold"])
+    assert torch.stack((tp, fp, fn, tn), 1).tolist() == e["counts_tp_fp_fn_tn"]
+    assert abs(O.dice_samples(tp, fp, fn).item() - e["metric_dice_samples"]) < 1e-12
+    assert abs(O.jaccard_binary(tp, fp, fn).item() - e["metric_iou"]) < 1e-12
+    d, j = DiceSamples(), JaccardBinary()
+    counts = torch.stack((tp, fp, fn, tn), 1)
+    d.update(counts); j.update(counts)
+    assert abs(d.compute() - e["metric_dice_samples"]) < 1e-12 and abs(j.compute() - e["metric_iou"]) < 1e-12

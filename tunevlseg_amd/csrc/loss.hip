@@ -8,9 +8,11 @@
 
 namespace {
 
-// grid (chunks, B)
+// grid (chunks, B).  Float sums: every workgroup writes its four partial sums to `part` [B][chunks][4]; dicece_finish_kernel adds
+// them in chunk order, so the loss is bitwise reproducible (an atomicAdd(double) here made its last bits depend on arrival order).
+// The integer counts stay on atomics: integer addition is exact in any order.
 __global__ __launch_bounds__(256) void dicece_stats_kernel(const float* __restrict__ logits, const float* __restrict__ target,
-                                                           double* __restrict__ fsum, long long* __restrict__ isum,
+                                                           double* __restrict__ part, long long* __restrict__ isum,
                                                            uint8_t* __restrict__ label, long N, float thr) {
     __shared__ double sf[4][4];
     __shared__ long long si[4][4];
@@ -46,10 +48,19 @@ __global__ __launch_bounds__(256) void dicece_stats_kernel(const float* __restri
     __syncthreads();
     if (threadIdx.x < 4) {
         const int k = threadIdx.x;
-        atomicAdd(&fsum[b * 4 + k], (sf[0][k] + sf[1][k]) + (sf[2][k] + sf[3][k]));
+        part[((long)b * gridDim.x + blockIdx.x) * 4 + k] = (sf[0][k] + sf[1][k]) + (sf[2][k] + sf[3][k]);
         atomicAdd(reinterpret_cast<unsigned long long*>(&isum[b * 4 + k]),
                   (unsigned long long)((si[0][k] + si[1][k]) + (si[2][k] + si[3][k])));
     }
+}
+
+__global__ void dicece_finish_kernel(const double* __restrict__ part, double* __restrict__ fsum, int B, int chunks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (b, k)
+    if (i >= B * 4) return;
+    const int b = i >> 2, k = i & 3;
+    double s = 0.0;
+    for (int c = 0; c < chunks; ++c) s += part[((long)b * chunks + c) * 4 + k];
+    fsum[i] = s;
 }
 
 __global__ __launch_bounds__(256) void dicece_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ target,
@@ -76,18 +87,24 @@ __global__ __launch_bounds__(256) void dicece_bwd_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" int tvl_dicece_stats(const float* logits, const float* target, double* fsum, int64_t* isum, uint8_t* label, int32_t B,
-                                int64_t N, float thr, tvlStream_t stream) {
-    TVL_REQUIRE(logits && target && fsum && isum && B > 0 && N > 0, "tvl_dicece_stats: bad arguments");
+static long dicece_chunks(long N) {
+    long chunks = (N + 256 * 8 - 1) / (256 * 8);
+    return chunks > 256 ? 256 : chunks;
+}
+
+extern "C" int64_t tvl_dicece_work_doubles(int32_t B, int64_t N) { return B > 0 && N > 0 ? (int64_t)B * dicece_chunks((long)N) * 4 : -1; }
+
+extern "C" int tvl_dicece_stats(const float* logits, const float* target, double* fsum, int64_t* isum, uint8_t* label, double* work,
+                                int32_t B, int64_t N, float thr, tvlStream_t stream) {
+    TVL_REQUIRE(logits && target && fsum && isum && work && B > 0 && N > 0, "tvl_dicece_stats: bad arguments");
     TVL_REQUIRE(B <= 65535, "tvl_dicece_stats: batch too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(fsum, 0, sizeof(double) * 4 * B, s);
-    if (e == hipSuccess) e = hipMemsetAsync(isum, 0, sizeof(int64_t) * 4 * B, s);
+    hipError_t e = hipMemsetAsync(isum, 0, sizeof(int64_t) * 4 * B, s);
     TVL_REQUIRE(e == hipSuccess, "tvl_dicece_stats: memset failed: %s", hipGetErrorString(e));
-    long chunks = (N + 256 * 8 - 1) / (256 * 8);
-    if (chunks > 256) chunks = 256;
-    hipLaunchKernelGGL(dicece_stats_kernel, dim3((unsigned)chunks, B), dim3(256), 0, s, logits, target, fsum,
+    const long chunks = dicece_chunks((long)N);
+    hipLaunchKernelGGL(dicece_stats_kernel, dim3((unsigned)chunks, B), dim3(256), 0, s, logits, target, work,
                        reinterpret_cast<long long*>(isum), label, (long)N, thr);
+    hipLaunchKernelGGL(dicece_finish_kernel, dim3((unsigned)((B * 4 + 63) / 64)), dim3(64), 0, s, (const double*)work, fsum, B, (int)chunks);
     TVL_LAUNCH_CHECK("tvl_dicece_stats");
     return 0;
 }

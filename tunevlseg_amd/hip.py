@@ -117,7 +117,7 @@ _SIGS = {
     "tvl_pixel_unshuffle_bwd": [_P, _F, _P, _I, _I, _I],
     "tvl_upconv_taps_fwd": [_P, _I, _P, _P, _I, _I, _I, _I],
     "tvl_upconv_taps_bwd": [_P, _P, _I, _P, _I, _I, _I, _I],
-    "tvl_dicece_stats": [_P, _P, _P, _P, _P, _I, _L, _F],
+    "tvl_dicece_stats": [_P, _P, _P, _P, _P, _P, _I, _L, _F],
     "tvl_dicece_bwd": [_P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _P],
     "tvl_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F],
     "tvl_fill": [_P, _F, _L],
@@ -151,7 +151,7 @@ _SIGS = {
     "tvl_dynconv_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
     "tvl_dynconv_bwd": [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
 }
-EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", *_SIGS]
+EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_dicece_work_doubles", *_SIGS]
 
 _lib = None
 
@@ -171,6 +171,8 @@ def load():
     lib.tvl_abi_version.restype = C.c_int
     lib.tvl_dynconv_bwd_work_floats.argtypes = [_I, _I, _I, _I]
     lib.tvl_dynconv_bwd_work_floats.restype = C.c_int64
+    lib.tvl_dicece_work_doubles.argtypes = [_I, _L]
+    lib.tvl_dicece_work_doubles.restype = C.c_int64
     lib.tvl_tp3_bytes.argtypes = [_L, _I]
     lib.tvl_tp3_bytes.restype = C.c_int64
     for name, sig in _SIGS.items():
@@ -655,8 +657,9 @@ def dicece_stats(logits, target, thr: float, want_label=False):
     fsum = torch.empty((B, 4), device=logits.device, dtype=torch.float64)
     isum = torch.empty((B, 4), device=logits.device, dtype=torch.int64)
     label = torch.empty(logits.shape, device=logits.device, dtype=torch.uint8) if want_label else None
-    _call("tvl_dicece_stats", _p(logits), _p(target), _p(fsum, torch.float64), _p(isum, torch.int64), _p(label, torch.uint8), B, N,
-          float(thr))
+    work = torch.empty(load().tvl_dicece_work_doubles(B, N), device=logits.device, dtype=torch.float64)
+    _call("tvl_dicece_stats", _p(logits), _p(target), _p(fsum, torch.float64), _p(isum, torch.int64), _p(label, torch.uint8),
+          _p(work, torch.float64), B, N, float(thr))
     return fsum, isum, label
 
 
