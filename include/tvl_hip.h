@@ -189,6 +189,12 @@ int tvl_dicece_bwd(const float* logits, const float* target, const double* fsum,
                    int32_t B, int64_t N, float lambda_dice, float lambda_ce, float smooth_nr, float smooth_dr,
                    const float* gscale, tvlStream_t stream);
 
+/* last-layer mix with the TRAINABLE residual_ratio read on the device (reference base_clipseg.py:150-155, coop_cris.py:240-242):
+ * out = (1 - ratio[0]) * main + ratio[0] * extra;   y = (one_minus ? 1 - ratio[0] : ratio[0]) * x  (its gradient passes).
+ * No host read of the scalar: the step stays free of device->host synchronisation and can be captured into a hipGraph. */
+int tvl_mix(const float* main, const float* extra, const float* ratio, float* out, int64_t n, tvlStream_t stream);
+int tvl_scale_dev(const float* x, const float* ratio, int32_t one_minus, float* y, int64_t n, tvlStream_t stream);
+
 /* ---- optimiser + misc ---- */
 /* torch.optim.AdamW step over a flat fp32 buffer (decoupled weight decay); step_t is 1-based */
 int tvl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -184,3 +184,23 @@ def test_oracle_loss_and_metrics_match_hand_derived_vectors(case):
     counts = torch.stack((tp, fp, fn, tn), 1)
     d.update(counts); j.update(counts)
     assert abs(d.compute() - e["metric_dice_samples"]) < 1e-12 and abs(j.compute() - e["metric_iou"]) < 1e-12
+
+
+def test_projection_plan_builds_reference_shaped_holders():
+    """ProjectionPlan -> holder: state_dict keys as in reference checkpoints (``<pos>.weight`` / bare Linear), bias rules, and the
+    He-initialised hidden Linears (drawn after all hidden layers exist, before the output Linear)."""
+    from tunevlseg_amd.nets.context_learner import ProjectionPlan
+
+    bare = ProjectionPlan.mlp(12, 10, None, False).build()
+    assert isinstance(bare, nn.Linear) and set(bare.state_dict()) == {"weight", "bias"}
+    mlp = ProjectionPlan.mlp(12, 10, 8, True, final_bias=False).build()  # CoCoOp meta-net: Linear, ReLU, Linear(no bias), LayerNorm(no bias)
+    assert set(mlp.state_dict()) == {"0.weight", "0.bias", "2.weight", "3.weight"}
+    deep = ProjectionPlan.mlp(12, 10, (8, 6), False).build()
+    assert [type(m).__name__ for m in deep] == ["Linear", "ReLU", "Linear", "ReLU", "Linear"] and deep[4].bias is not None
+    lora = ProjectionPlan.low_rank(12, 10, 4, True).build()
+    assert set(lora.state_dict()) == {"0.weight", "1.weight", "2.weight", "2.bias"} and lora[0].weight.shape == (4, 12)
+    wide = ProjectionPlan.low_rank(12, 10, 16, False).build()  # rank above the output width: a single bias-free Linear
+    assert len(wide) == 1 and wide[0].weight.shape == (10, 12) and wide[0].bias is None
+    torch.manual_seed(0)
+    a = ProjectionPlan.mlp(64, 10, 256, False).build()
+    assert abs(a[0].weight.std().item() - (2.0 / 64) ** 0.5) < 0.02  # kaiming_normal_(nonlinearity="relu"): std = sqrt(2 / fan_in)

@@ -278,29 +278,20 @@ class UpconvFn(Fn):
 
 
 class MixFn(Fn):
-    """``(1 - r) * main + r * extra`` with a trainable scalar r (coop_cris.py:240-242)."""
+    """``(1 - r) * main + r * extra`` with a trainable scalar r (coop_cris.py:240-242); r is read on the device."""
 
     @staticmethod
     def forward(ctx, main, extra, ratio):
-        r = float(ratio.item()) if isinstance(ratio, torch.Tensor) else float(ratio)
-        out = _c(extra).clone()
-        hip.axpby(_c(main), 1.0 - r, out, r)
-        ctx.r = r
-        ctx.save_for_backward(main, extra)
-        return out
+        main, extra = _c(main), _c(extra)
+        ratio = ratio.detach() if isinstance(ratio, torch.Tensor) else torch.tensor(float(ratio), device=main.device)
+        ctx.save_for_backward(main, extra, ratio)
+        return hip.mix(main, extra, ratio)
 
     @staticmethod
     def backward(ctx, d):
-        main, extra = ctx.saved_tensors
+        main, extra, ratio = ctx.saved_tensors
         d = _c(d)
-        r = ctx.r
-        dmain = dextra = dr = None
-        if ctx.needs_input_grad[0]:
-            dmain = torch.zeros_like(d)
-            hip.axpby(d, 1.0 - r, dmain, 0.0)
-        if ctx.needs_input_grad[1]:
-            dextra = torch.zeros_like(d)
-            hip.axpby(d, r, dextra, 0.0)
-        if ctx.needs_input_grad[2]:
-            dr = (hip.dot(d, extra) - hip.dot(d, main)).view(())
+        dmain = hip.scale_dev(d, ratio, True) if ctx.needs_input_grad[0] else None
+        dextra = hip.scale_dev(d, ratio, False) if ctx.needs_input_grad[1] else None
+        dr = (hip.dot(d, extra) - hip.dot(d, main)).view(()) if ctx.needs_input_grad[2] else None
         return dmain, dextra, dr

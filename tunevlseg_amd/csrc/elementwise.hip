@@ -197,6 +197,17 @@ __global__ void pixel_unshuffle_kernel(const float* __restrict__ dlogits, float 
     }
 }
 
+// ---- (1 - r) * main + r * extra with r read on the device (trainable residual_ratio: no host round trip) ----
+__global__ void mix_kernel(const float* __restrict__ main_, const float* __restrict__ extra, const float* __restrict__ ratio,
+                           float* __restrict__ out, long n) {
+    const float r = ratio[0], a = 1.0f - r;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a * main_[i] + r * extra[i];
+}
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ ratio, int one_minus, float* __restrict__ y, long n) {
+    const float s = one_minus ? 1.0f - ratio[0] : ratio[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = s * x[i];
+}
+
 // ---- optimiser / misc -----------------------------------------------------------------------
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                              float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
@@ -416,6 +427,19 @@ extern "C" int tvl_pixel_unshuffle_bwd(const float* dlogits, float a, float* dco
     TVL_REQUIRE(dlogits && dcols && B > 0 && G > 0 && ps > 0, "tvl_pixel_unshuffle_bwd: bad arguments");
     hipLaunchKernelGGL(pixel_unshuffle_kernel, GRID_FOR((long)B * G * ps * G * ps), dim3(256), 0, S_(stream), dlogits, a, dcols, B, G, ps);
     TVL_LAUNCH_CHECK("tvl_pixel_unshuffle_bwd");
+    return 0;
+}
+
+extern "C" int tvl_mix(const float* main_, const float* extra, const float* ratio, float* out, int64_t n, tvlStream_t stream) {
+    TVL_REQUIRE(main_ && extra && ratio && out && n > 0, "tvl_mix: bad arguments");
+    hipLaunchKernelGGL(mix_kernel, GRID_FOR((long)n), dim3(256), 0, S_(stream), main_, extra, ratio, out, (long)n);
+    TVL_LAUNCH_CHECK("tvl_mix");
+    return 0;
+}
+extern "C" int tvl_scale_dev(const float* x, const float* ratio, int32_t one_minus, float* y, int64_t n, tvlStream_t stream) {
+    TVL_REQUIRE(x && ratio && y && n > 0, "tvl_scale_dev: bad arguments");
+    hipLaunchKernelGGL(scale_dev_kernel, GRID_FOR((long)n), dim3(256), 0, S_(stream), x, ratio, one_minus, y, (long)n);
+    TVL_LAUNCH_CHECK("tvl_scale_dev");
     return 0;
 }
 

@@ -119,6 +119,8 @@ _SIGS = {
     "tvl_upconv_taps_bwd": [_P, _P, _I, _P, _I, _I, _I, _I],
     "tvl_dicece_stats": [_P, _P, _P, _P, _P, _P, _I, _L, _F],
     "tvl_dicece_bwd": [_P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _P],
+    "tvl_mix": [_P, _P, _P, _P, _L],
+    "tvl_scale_dev": [_P, _P, _I, _P, _L],
     "tvl_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F],
     "tvl_fill": [_P, _F, _L],
     "tvl_axpby": [_P, _F, _P, _F, _L],
@@ -670,6 +672,19 @@ def dicece_bwd(logits, target, fsum, lambda_dice, lambda_ce, smooth_nr, smooth_d
     _call("tvl_dicece_bwd", _p(logits), _p(target), _p(fsum, torch.float64), _p(dl), B, N, float(lambda_dice), float(lambda_ce),
           float(smooth_nr), float(smooth_dr), _p(gscale))
     return dl
+
+
+def mix(main, extra, ratio):
+    """(1 - ratio) * main + ratio * extra, ``ratio`` a 0-d / 1-element DEVICE tensor (no host sync)."""
+    out = torch.empty_like(main)
+    _call("tvl_mix", _p(main), _p(extra), _p(ratio.reshape(1)), _p(out), main.numel())
+    return out
+
+
+def scale_dev(x, ratio, one_minus: bool):
+    y = torch.empty_like(x)
+    _call("tvl_scale_dev", _p(x), _p(ratio.reshape(1)), int(one_minus), _p(y), x.numel())
+    return y
 
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_t: int, grad_scale: float = 1.0):

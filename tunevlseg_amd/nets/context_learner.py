@@ -9,8 +9,8 @@ their math runs through the HIP ops of ``tunevlseg_amd.ops``.
 from __future__ import annotations
 
 import copy
-import itertools
 from abc import ABC, abstractmethod
+from dataclasses import dataclass
 from collections.abc import Iterable, Sequence
 from typing import Final, Literal
 
@@ -20,23 +20,92 @@ from torch import nn
 from .. import hip, ops
 
 
+@dataclass(frozen=True)
+class ProjectionPlan:
+    """What a prompt projection is made of, decided before any module exists.
+
+    ``steps`` is a tuple of ``("linear", in, out, bias, kaiming)`` / ``("relu",)`` / ``("norm", dim, bias)`` entries.  The builder
+    turns it into the ``nn.Linear`` / ``nn.Sequential`` parameter holder whose ``state_dict`` keys the reference checkpoints use
+    (``projection_layers.<depth>[.<position>].weight``); :func:`run_projection` evaluates the holder with HIP ops.
+    Layout rules (reference ``base_projector_learner.py:65-139``): no hidden width -> one bare Linear; an MLP ends in a Linear that
+    drops its bias when a LayerNorm follows; hidden Linears are He-initialised; the low-rank form is two bias-free-then-biased
+    Linears through ``min(out, rank)`` and degenerates to a single Linear when the rank exceeds the output width.
+    """
+
+    steps: tuple
+
+    @classmethod
+    def mlp(cls, in_dim: int, out_dim: int, hidden, final_norm: bool, final_bias: bool = True) -> "ProjectionPlan":
+        if hidden is None:
+            return cls((("linear", in_dim, out_dim, True, False),))
+        widths = (in_dim, *((hidden,) if isinstance(hidden, int) else tuple(hidden)))
+        steps = []
+        for fan_in, fan_out in zip(widths, widths[1:]):
+            steps += [("linear", fan_in, fan_out, True, True), ("relu",)]
+        steps.append(("linear", widths[-1], out_dim, final_bias and not final_norm, False))
+        if final_norm:
+            steps.append(("norm", out_dim, final_bias))
+        return cls(tuple(steps))
+
+    @classmethod
+    def low_rank(cls, in_dim: int, out_dim: int, rank: int, final_norm: bool, final_bias: bool = True) -> "ProjectionPlan":
+        steps = [("linear", in_dim, min(out_dim, rank), False, False)]
+        if rank <= out_dim:
+            steps.append(("linear", rank, out_dim, final_bias and not final_norm, False))
+        if final_norm:
+            steps.append(("norm", out_dim, final_bias))
+        return cls(tuple(steps))
+
+    def build(self) -> nn.Module:
+        made, hidden = [], []
+        for step in self.steps:
+            if step[0] == "linear":
+                _, fan_in, fan_out, bias, kaiming = step
+                if not kaiming and hidden:
+                    # all hidden Linears exist, the output Linear does not yet: He-initialise them now, in order -- the point and
+                    # the order at which the reference draws these random numbers
+                    for h in hidden:
+                        nn.init.kaiming_normal_(h.weight.data, nonlinearity="relu")
+                    hidden = []
+                made.append(nn.Linear(fan_in, fan_out, bias=bias))
+                if kaiming:
+                    hidden.append(made[-1])
+            elif step[0] == "relu":
+                made.append(nn.ReLU(inplace=True))
+            else:
+                made.append(nn.LayerNorm(step[1], bias=step[2]))
+        if len(self.steps) == 1 and self.steps[0][0] == "linear" and self.steps[0][3]:
+            return made[0]  # the bare nn.Linear of ``intermediate_dim=None``: keys without a position index
+        return nn.Sequential(*made)
+
+
+def per_depth(make_module, depth: int, shared: bool, clone_first: bool = False) -> nn.ModuleList:
+    """One projection per prompt depth: the SAME object ``depth`` times when shared (unified projection), otherwise independent
+    modules -- freshly built, or deep copies of the first one (``clone_first``: every depth then starts from identical weights)."""
+    if shared:
+        return nn.ModuleList([make_module()] * depth)
+    if clone_first:
+        first = make_module()
+        return nn.ModuleList([copy.deepcopy(first) for _ in range(depth)])
+    return nn.ModuleList([make_module() for _ in range(depth)])
+
+
 def run_projection(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
-    """Evaluate an ``nn.Linear`` / ``nn.Sequential(Linear, ReLU, ..., LayerNorm)`` holder with HIP kernels."""
-    layers = [module] if isinstance(module, nn.Linear) else list(module)
-    i = 0
-    while i < len(layers):
-        m = layers[i]
-        if isinstance(m, nn.Linear):
-            act = hip.ACT_NONE
-            if i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
-                act = hip.ACT_RELU
-                i += 1
-            x = ops.linear(x, m.weight, m.bias, act)
-        elif isinstance(m, nn.LayerNorm):
-            x = ops.layer_norm(x, m.weight, m.bias, m.eps)
+    """Evaluate a projection holder (bare ``nn.Linear`` or ``nn.Sequential`` of Linear / ReLU / LayerNorm) with HIP kernels; a
+    Linear directly followed by a ReLU runs as one fused launch."""
+    chain = [module] if isinstance(module, nn.Linear) else list(module)
+    pos = 0
+    while pos < len(chain):
+        holder = chain[pos]
+        if isinstance(holder, nn.Linear):
+            fuse_relu = pos + 1 < len(chain) and isinstance(chain[pos + 1], nn.ReLU)
+            x = ops.linear(x, holder.weight, holder.bias, hip.ACT_RELU if fuse_relu else hip.ACT_NONE)
+            pos += 2 if fuse_relu else 1
+        elif isinstance(holder, nn.LayerNorm):
+            x = ops.layer_norm(x, holder.weight, holder.bias, holder.eps)
+            pos += 1
         else:  # pragma: no cover
-            raise TypeError(f"unsupported projection layer {type(m).__name__}")
-        i += 1
+            raise TypeError(f"unsupported projection layer {type(holder).__name__}")
     return x
 
 
@@ -49,19 +118,18 @@ class BaseUnimodalLearner(nn.Module, ABC):
                  context_dim: int | None = None, context_initializer: str | list[str] | None = None, tokenizer=None,
                  embedding_layer=None, vector_std: float = 0.02, **kwargs) -> None:
         self.verify_prompt_depth(prompt_depth=prompt_depth, max_network_depth=max_network_depth)
-        context_vectors = self.get_context_vectors(
-            num_context=num_context, context_dim=context_dim, context_initializer=context_initializer, tokenizer=tokenizer,
-            embedding_layer=embedding_layer, prompt_depth=prompt_depth, vector_std=vector_std)
-        if context_vectors.ndim != 3:
+        start = self.get_context_vectors(num_context=num_context, context_dim=context_dim, context_initializer=context_initializer,
+                                         tokenizer=tokenizer, embedding_layer=embedding_layer, prompt_depth=prompt_depth,
+                                         vector_std=vector_std)
+        # the drawn / looked-up tensor decides the shape (an initializer phrase overrides num_context and context_dim)
+        if start.ndim != 3:
             raise ValueError("The number of dimensions of `context_vectors` must be 3")
-        generated_prompt_depth, num_context, context_dim = context_vectors.shape
-        if generated_prompt_depth != prompt_depth:
+        if start.shape[0] != prompt_depth:
             raise ValueError("The number of rows of `context_vectors` must be `prompt_depth`")
         super().__init__()
         self.prompt_depth = prompt_depth
-        self.num_context = num_context
-        self.context_dim = context_dim
-        self.context_vectors = nn.Parameter(context_vectors.detach().clone().to(torch.float32))
+        _, self.num_context, self.context_dim = start.shape
+        self.context_vectors = nn.Parameter(start.detach().clone().to(torch.float32))
 
     @classmethod
     def verify_prompt_depth(cls, prompt_depth: int, max_network_depth: int) -> None:
@@ -180,56 +248,36 @@ class CoOpContextLearner(BaseUnimodalLearner):
 
 
 class BaseProjectorLearner(CoOpContextLearner):
-    """reference ``base_projector_learner.py:10-139``"""
+    """reference ``base_projector_learner.py:10-139``: prompts pushed through one projection per depth (see ProjectionPlan)."""
 
     def __init__(self, *, proj_in_dim: int | None, proj_out_dim: int | None, prompt_depth: int = CoOpContextLearner.MIN_PROMPT_DEPTH,
                  use_unified_projection: bool = True, intermediate_dim: int | Iterable[int] | None = None, use_proj_norm: bool = False,
                  use_lora_proj: bool = False, use_final_bias: bool = True, **kwargs) -> None:
+        low_rank = self._wants_low_rank(use_lora_proj, intermediate_dim)
+        super().__init__(prompt_depth=prompt_depth, **kwargs)
+        fan_in = self.context_dim if proj_in_dim is None else proj_in_dim
+        fan_out = self.context_dim if proj_out_dim is None else proj_out_dim
+        plan = (ProjectionPlan.low_rank if low_rank else ProjectionPlan.mlp)(fan_in, fan_out, intermediate_dim, use_proj_norm, use_final_bias)
+        self.projection_layers = per_depth(plan.build, prompt_depth, shared=use_unified_projection)
+
+    @staticmethod
+    def _wants_low_rank(use_lora_proj: bool, intermediate_dim) -> bool:
         if use_lora_proj and intermediate_dim is not None and not isinstance(intermediate_dim, int):
             raise ValueError("Lora projection is only available for a single layer.")
-        super().__init__(prompt_depth=prompt_depth, **kwargs)
-        init_kwargs = {
-            "in_dim": proj_in_dim if proj_in_dim is not None else self.context_dim,
-            "out_dim": proj_out_dim if proj_out_dim is not None else self.context_dim,
-            "intermediate_dim": intermediate_dim,
-            "use_final_norm": use_proj_norm,
-            "use_final_bias": use_final_bias,
-        }
-        getter = self.get_lora_projection if use_lora_proj and intermediate_dim is not None else self.get_mlp_projection
-        self.projection_layers = nn.ModuleList(
-            (getter(**init_kwargs),) * prompt_depth if use_unified_projection else (getter(**init_kwargs) for _ in range(prompt_depth)))
+        return bool(use_lora_proj) and intermediate_dim is not None
 
     def get_transformed_context(self, in_context: torch.Tensor | None = None, index: int = 0) -> torch.Tensor:
-        if in_context is None:
-            in_context = self.context_vectors[index]
-        return run_projection(self.projection_layers[index], in_context)
+        source = self.context_vectors[index] if in_context is None else in_context
+        return run_projection(self.projection_layers[index], source)
+
+    # the two factory names of the reference's public surface, kept as thin fronts of ProjectionPlan
+    @staticmethod
+    def get_lora_projection(in_dim: int, out_dim: int, intermediate_dim: int, use_final_norm: bool, use_final_bias: bool = True) -> nn.Module:
+        return ProjectionPlan.low_rank(in_dim, out_dim, intermediate_dim, use_final_norm, use_final_bias).build()
 
     @staticmethod
-    def get_lora_projection(in_dim: int, out_dim: int, intermediate_dim: int, use_final_norm: bool, use_final_bias: bool = True) -> nn.Sequential:
-        layers = nn.Sequential()
-        min_dim = min(out_dim, intermediate_dim)
-        layers.append(nn.Linear(in_dim, min_dim, bias=False))
-        if intermediate_dim <= out_dim:
-            layers.append(nn.Linear(intermediate_dim, out_dim, bias=(not use_final_norm) and use_final_bias))
-        if use_final_norm:
-            layers.append(nn.LayerNorm(out_dim, bias=use_final_bias))
-        return layers
-
-    @staticmethod
-    def get_mlp_projection(in_dim: int, out_dim: int, intermediate_dim, use_final_norm: bool, use_final_bias: bool = True):
-        if intermediate_dim is None:
-            return nn.Linear(in_dim, out_dim)
-        intermediate_dim = (intermediate_dim,) if isinstance(intermediate_dim, int) else tuple(intermediate_dim)
-        layers = nn.Sequential(nn.Linear(in_dim, intermediate_dim[0]), nn.ReLU(inplace=True))
-        for i, o in itertools.pairwise(intermediate_dim):
-            layers.extend((nn.Linear(i, o), nn.ReLU(inplace=True)))
-        for layer in layers:
-            if isinstance(layer, nn.Linear):
-                nn.init.kaiming_normal_(layer.weight.data, nonlinearity="relu")
-        layers.append(nn.Linear(intermediate_dim[-1], out_dim, bias=(not use_final_norm) and use_final_bias))
-        if use_final_norm:
-            layers.append(nn.LayerNorm(out_dim, bias=use_final_bias))
-        return layers
+    def get_mlp_projection(in_dim: int, out_dim: int, intermediate_dim, use_final_norm: bool, use_final_bias: bool = True) -> nn.Module:
+        return ProjectionPlan.mlp(in_dim, out_dim, intermediate_dim, use_final_norm, use_final_bias).build()
 
 
 class CoCoOpContextLearner(BaseProjectorLearner):
@@ -286,36 +334,32 @@ class BaseSharedLearner(CoOpContextLearner, BaseVisualLearner):
 
 
 class SharedSeparateLearner(BaseSharedLearner):
-    """reference ``shared_separate_learner.py:11-98``: one shared prompt, two MLPs (textual / visual)."""
+    """reference ``shared_separate_learner.py:11-98``: one shared prompt, two projections per depth (textual / visual)."""
 
     def __init__(self, *, textual_dim: int, visual_dim: int, shared_dim: int = 64, prompt_depth: int = BaseSharedLearner.MIN_PROMPT_DEPTH,
                  use_unified_projection: bool = True, intermediate_dim: int | Iterable[int] | None = None, use_proj_norm: bool = False,
                  use_lora_proj: bool = False, **kwargs) -> None:
-        if use_lora_proj and intermediate_dim is not None and not isinstance(intermediate_dim, int):
-            raise ValueError("Lora projection is only available for a single layer.")
+        low_rank = BaseProjectorLearner._wants_low_rank(use_lora_proj, intermediate_dim)
         kwargs["context_dim"] = shared_dim
         super().__init__(prompt_depth=prompt_depth, **kwargs)
-        getter = (BaseProjectorLearner.get_lora_projection if use_lora_proj and intermediate_dim is not None
-                  else BaseProjectorLearner.get_mlp_projection)
-        init_kwargs = {"in_dim": shared_dim, "out_dim": textual_dim, "intermediate_dim": intermediate_dim, "use_final_norm": use_proj_norm}
-        self.textual_projection_layers = self.get_projection_layers(getter(**init_kwargs), prompt_depth, use_unified_projection)
-        init_kwargs["out_dim"] = visual_dim
-        self.visual_projection_layers = self.get_projection_layers(getter(**init_kwargs), prompt_depth, use_unified_projection)
+        plan_for = lambda width: (ProjectionPlan.low_rank if low_rank else ProjectionPlan.mlp)(  # noqa: E731
+            shared_dim, width, intermediate_dim, use_proj_norm)
+        # independent depths are deep copies of ONE freshly built module per modality (all depths start from the same weights)
+        self.textual_projection_layers = per_depth(plan_for(textual_dim).build, prompt_depth, use_unified_projection, clone_first=True)
+        self.visual_projection_layers = per_depth(plan_for(visual_dim).build, prompt_depth, use_unified_projection, clone_first=True)
 
     @staticmethod
     def get_projection_layers(single_layer: nn.Module, prompt_depth: int, use_unified_projection) -> nn.ModuleList:
-        return nn.ModuleList((single_layer,) * prompt_depth if use_unified_projection
-                             else (copy.deepcopy(single_layer) for _ in range(prompt_depth)))
+        return per_depth(lambda: single_layer, prompt_depth, use_unified_projection, clone_first=True)
+
+    def _through(self, stack: nn.ModuleList, in_context: torch.Tensor | None, index: int) -> torch.Tensor:
+        return run_projection(stack[index], self.context_vectors[index] if in_context is None else in_context)
 
     def get_textual_context(self, in_context: torch.Tensor | None = None, image_features: torch.Tensor | None = None, index: int = 0):
-        if in_context is None:
-            in_context = self.context_vectors[index]
-        return run_projection(self.textual_projection_layers[index], in_context)
+        return self._through(self.textual_projection_layers, in_context, index)
 
     def get_visual_context(self, in_context: torch.Tensor | None = None, index: int = 0) -> torch.Tensor:
-        if in_context is None:
-            in_context = self.context_vectors[index]
-        return run_projection(self.visual_projection_layers[index], in_context)
+        return self._through(self.visual_projection_layers, in_context, index)
 
 
 class SharedAttnLearner(BaseSharedLearner):
@@ -332,21 +376,21 @@ class SharedAttnLearner(BaseSharedLearner):
                  use_unified_projection: bool = True, **kwargs) -> None:
         if unified_projector is None:
             raise NotImplementedError("You need to provide a transformer encoder layer for the unified projection layer from the config.")
-        context_dim = textual_dim + visual_dim
-        kwargs["context_dim"] = context_dim
+        kwargs["context_dim"] = textual_dim + visual_dim
         super().__init__(prompt_depth=prompt_depth, **kwargs)
-        transformer_layer = unified_projector(d_model=context_dim)
-        if getattr(transformer_layer.self_attn, "batch_first", False):
+        self.textual_dim, self.visual_dim = textual_dim, visual_dim
+        self.projection_layers = per_depth(lambda: self._checked_layer(unified_projector(d_model=self.context_dim)), prompt_depth,
+                                           use_unified_projection, clone_first=True)
+        # each depth is evaluated once per step; the half the OTHER tower will ask for waits here, keyed by (depth, modality)
+        self._handoff: dict[tuple[int, str], torch.Tensor] = {}
+
+    @staticmethod
+    def _checked_layer(layer: nn.Module) -> nn.Module:
+        if getattr(layer.self_attn, "batch_first", False):
             raise NotImplementedError("batch_first=True (real attention over the prompt tokens) is not used by the reference configs")
-        act = getattr(transformer_layer, "activation", None)
-        if getattr(act, "__name__", "relu") != "relu":
+        if getattr(getattr(layer, "activation", None), "__name__", "relu") != "relu":
             raise NotImplementedError("only the default relu activation of nn.TransformerEncoderLayer is implemented")
-        self.projection_layers = nn.ModuleList((transformer_layer,) * prompt_depth if use_unified_projection
-                                               else (copy.deepcopy(transformer_layer) for _ in range(prompt_depth)))
-        self._computed_textual_context_cache: dict[int, torch.Tensor] = {}
-        self._computed_visual_context_cache: dict[int, torch.Tensor] = {}
-        self.textual_dim = textual_dim
-        self.visual_dim = visual_dim
+        return layer
 
     def _run_layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor) -> torch.Tensor:
         E = x.shape[-1]
@@ -370,25 +414,25 @@ class SharedAttnLearner(BaseSharedLearner):
         x = n1(ops.add(x, sa(x)))
         return n2(ops.add(x, ff(x)))
 
-    def _get_combined_transformed_context(self, is_curr_branch_textual: bool, in_context: torch.Tensor | None = None, index: int = 0):
-        read_cache = self._computed_textual_context_cache if is_curr_branch_textual else self._computed_visual_context_cache
-        cached = read_cache.pop(index, None)
-        if cached is not None:
-            return cached
-        if in_context is None:
-            in_context = self.context_vectors[index].unsqueeze(0)
-        if in_context.ndim != 3:
+    def _half(self, want: str, in_context: torch.Tensor | None = None, index: int = 0) -> torch.Tensor:
+        """The ``want`` ("text" | "vision") column block of depth ``index``'s transformed prompt.  Whichever tower asks first runs
+        the layer and leaves the other block for its sibling (``_handoff``); the sibling's request consumes it."""
+        waiting = self._handoff.pop((index, want), None)
+        if waiting is not None:
+            return waiting
+        tokens = self.context_vectors[index].unsqueeze(0) if in_context is None else in_context
+        if tokens.ndim != 3:
             raise ValueError("The tensor needs to have 3 dimensions: (batch, context_len, hidden_dim)")
-        out = self._run_layer(self.projection_layers[index], in_context.squeeze(0))
-        textual, visual = ops.split_cols(out, self.textual_dim)
-        if is_curr_branch_textual:
-            self._computed_visual_context_cache[index] = visual
-            return textual
-        self._computed_textual_context_cache[index] = textual
-        return visual
+        text_block, vision_block = ops.split_cols(self._run_layer(self.projection_layers[index], tokens.squeeze(0)), self.textual_dim)
+        mine, theirs, other = (text_block, vision_block, "vision") if want == "text" else (vision_block, text_block, "text")
+        self._handoff[(index, other)] = theirs
+        return mine
+
+    def _get_combined_transformed_context(self, is_curr_branch_textual: bool, in_context: torch.Tensor | None = None, index: int = 0):
+        return self._half("text" if is_curr_branch_textual else "vision", in_context, index)
 
     def get_textual_context(self, image_features: torch.Tensor | None = None, *args, **kwargs) -> torch.Tensor:
-        return self._get_combined_transformed_context(*args, is_curr_branch_textual=True, **kwargs)
+        return self._half("text", *args, **kwargs)
 
     def get_visual_context(self, *args, **kwargs) -> torch.Tensor:
-        return self._get_combined_transformed_context(*args, is_curr_branch_textual=False, **kwargs)
+        return self._half("vision", *args, **kwargs)

@@ -446,7 +446,8 @@ class FilmFn(Fn):
 
 class SegHeadFn(Fn):
     """Strip CLS/prompt tokens -> ConvTranspose2d(C->1, k=s=ps) [+ new last layer] (base_clipseg.py:132-155,
-    vpt_clipseg.py:287-302).  mix: 0 none, 1 ``logits += f(out)`` (VPT), 2 ``(1-r) logits + r f(out)`` (Base/MaPLe)."""
+    vpt_clipseg.py:287-302).  mix: 0 none, 1 ``logits += f(out)`` (VPT), 2 ``(1-r) logits + r f(out)`` (Base/MaPLe); the
+    trainable ``r`` is read on the device (``tvl_mix`` / ``tvl_scale_dev``): no ``.item()``, no host synchronisation."""
 
     @staticmethod
     def forward(ctx, tokens, wt, bt, conv_w, conv_b, ratio, mix, G, ps):
@@ -458,8 +459,7 @@ class SegHeadFn(Fn):
         wt2d = _c(wt).view(Cc, ps * ps)
         cols = torch.empty((Mrows, ps * ps), device=tokens.device, dtype=torch.float32)
         hip.gemm(hip.NN, Mrows, ps * ps, Cc, tok2d, Cc, wt2d, ps * ps, cols, ps * ps, a_map=amap)
-        extra = tconv = None
-        a, r = 1.0, 0.0
+        extra = tconv = rdev = None
         k = 0
         if mix:
             k = conv_w.shape[-1]
@@ -467,28 +467,30 @@ class SegHeadFn(Fn):
             taps = torch.empty((Mrows, k * k), device=tokens.device, dtype=torch.float32)
             hip.gemm(hip.NN, Mrows, k * k, Cc, tok2d, Cc, w2, k * k, taps, k * k, a_map=amap)
             extra = hip.upconv_taps_fwd(taps, conv_b, B, G, ps, k)
-            if mix == 2:
-                r = float(ratio.item()) if isinstance(ratio, torch.Tensor) else float(ratio)
-                a = 1.0 - r
-                if ctx.needs_input_grad[5]:
-                    tconv = hip.pixel_shuffle_fwd(cols, bt, None, 1.0, 0.0, B, G, ps)
-            else:
-                r = 1.0
-        logits = hip.pixel_shuffle_fwd(cols, bt, extra, a, r, B, G, ps)
-        ctx.save_for_backward(tokens, wt2d, conv_w if mix else None, extra if tconv is not None else None, tconv)
-        ctx.meta = (B, T, Cc, G, ps, k, mix, a, r)
+        if mix == 2:
+            rdev = ratio.detach().to(torch.float32) if isinstance(ratio, torch.Tensor) else torch.tensor(float(ratio), device=tokens.device)
+            tconv = hip.pixel_shuffle_fwd(cols, bt, None, 1.0, 0.0, B, G, ps)
+            logits = hip.mix(tconv, extra, rdev)
+        else:
+            logits = hip.pixel_shuffle_fwd(cols, bt, extra, 1.0, 1.0 if mix else 0.0, B, G, ps)
+        keep = mix == 2 and ctx.needs_input_grad[5]
+        ctx.save_for_backward(tokens, wt2d, conv_w if mix else None, extra if keep else None, tconv if keep else None, rdev)
+        ctx.meta = (B, T, Cc, G, ps, k, mix)
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
-        tokens, wt2d, conv_w, extra, tconv = ctx.saved_tensors
-        B, T, Cc, G, ps, k, mix, a, r = ctx.meta
+        tokens, wt2d, conv_w, extra, tconv, rdev = ctx.saved_tensors
+        B, T, Cc, G, ps, k, mix = ctx.meta
         dlogits = _c(dlogits)
         Mrows = B * G * G
         amap = hip.RowMap(G * G, T, 1)
         need = ctx.needs_input_grad
         dtok = dwt = dbt = dcw = dcb = dratio = None
-        dcols = hip.pixel_unshuffle_bwd(dlogits, a, B, G, ps)
+        # gradients reaching the two branches: d_main for the transposed conv, d_extra for the new last layer
+        d_main = hip.scale_dev(dlogits, rdev, True) if mix == 2 else dlogits
+        d_extra = hip.scale_dev(dlogits, rdev, False) if mix == 2 else dlogits
+        dcols = hip.pixel_unshuffle_bwd(d_main, 1.0, B, G, ps)
         if need[0]:
             dtok = torch.zeros((B * T, Cc), device=dlogits.device, dtype=torch.float32)
             hip.gemm(hip.NT, Mrows, Cc, ps * ps, dcols, ps * ps, wt2d, ps * ps, dtok, Cc, c_map=amap)
@@ -497,20 +499,18 @@ class SegHeadFn(Fn):
             hip.gemm(hip.TN, Cc, ps * ps, Mrows, tokens.view(B * T, Cc), Cc, dcols, ps * ps, dwt, ps * ps, a_map=amap)
             dwt = dwt.view(Cc, 1, ps, ps)
         if need[2]:
-            dbt = hip.dot(dlogits)
-            if a != 1.0:
-                dbt = dbt * a
+            dbt = hip.dot(d_main)
         if mix:
-            dtaps = hip.upconv_taps_bwd(dlogits, B, G, ps, k)  # gradient w.r.t. taps of `extra` (unscaled)
+            dtaps = hip.upconv_taps_bwd(d_extra, B, G, ps, k)
             w2 = _c(conv_w).view(Cc, k * k)
             if need[0]:
-                hip.gemm(hip.NT, Mrows, Cc, k * k, dtaps, k * k, w2, k * k, dtok, Cc, residual=dtok, ldr=Cc, alpha=r, c_map=amap)
+                hip.gemm(hip.NT, Mrows, Cc, k * k, dtaps, k * k, w2, k * k, dtok, Cc, residual=dtok, ldr=Cc, c_map=amap)
             if need[3]:
                 dcw = torch.empty((Cc, k * k), device=dlogits.device, dtype=torch.float32)
-                hip.gemm(hip.TN, Cc, k * k, Mrows, tokens.view(B * T, Cc), Cc, dtaps, k * k, dcw, k * k, alpha=r, a_map=amap)
+                hip.gemm(hip.TN, Cc, k * k, Mrows, tokens.view(B * T, Cc), Cc, dtaps, k * k, dcw, k * k, a_map=amap)
                 dcw = dcw.view(1, Cc, k, k)
             if need[4]:
-                dcb = hip.dot(dlogits) * r
+                dcb = hip.dot(d_extra)
             if mix == 2 and need[5]:
                 dratio = (hip.dot(dlogits, extra) - hip.dot(dlogits, tconv)).view(())
         if dtok is not None:
