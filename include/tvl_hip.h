@@ -189,6 +189,13 @@ int tvl_dicece_bwd(const float* logits, const float* target, const double* fsum,
                    int32_t B, int64_t N, float lambda_dice, float lambda_ce, float smooth_nr, float smooth_dr,
                    const float* gscale, tvlStream_t stream);
 
+/* ---- input side (row f2): decoded uint8 sample -> network input, on the device ----
+ * tvl_normalize_u8: albumentations Normalize(mean, std, max_pixel_value=255) + ToTensorV2 of the reference's transforms
+ *   (configs/experiment/coop/clipseg.yaml:78-127): img [B,H,W,3] uint8 (host-pointer mean3 / std3) -> out [B,3,H,W] float.
+ * tvl_mask_u8: mask [n] uint8 -> float / 255 (reference image_text_mask_dataset.py:66-71). */
+int tvl_normalize_u8(const uint8_t* img, float* out, int32_t B, int32_t H, int32_t W, const float* mean3, const float* std3, tvlStream_t stream);
+int tvl_mask_u8(const uint8_t* mask, float* out, int64_t n, tvlStream_t stream);
+
 /* last-layer mix with the TRAINABLE residual_ratio read on the device (reference base_clipseg.py:150-155, coop_cris.py:240-242):
  * out = (1 - ratio[0]) * main + ratio[0] * extra;   y = (one_minus ? 1 - ratio[0] : ratio[0]) * x  (its gradient passes).
  * No host read of the scalar: the step stays free of device->host synchronisation and can be captured into a hipGraph. */

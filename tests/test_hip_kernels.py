@@ -504,3 +504,18 @@ def test_dicece_loss_is_bitwise_reproducible(hip):
     first = ops.DiceCELossFn.apply(x, t, 1.0, 0.2, 0.5)[0]
     for _ in range(5):
         assert torch.equal(ops.DiceCELossFn.apply(x, t, 1.0, 0.2, 0.5)[0], first)
+
+
+def test_input_side_normalize_and_mask(hip):
+    """Row f2 on the device: uint8 HWC image -> normalised NCHW float, uint8 mask -> float / 255; the loss sees the float mask,
+    the metrics its .long() (only grey level 255 counts as foreground)."""
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (3, 37, 41, 3), generator=g, dtype=torch.uint8)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    ref = ((img.double() / 255 - torch.tensor(mean, dtype=torch.float64)) / torch.tensor(std, dtype=torch.float64)).permute(0, 3, 1, 2)
+    close(hip.normalize_u8(img.cuda(), mean, std), ref, 1e-6, "normalize_u8")
+    m = torch.randint(0, 256, (3, 37, 41), generator=g, dtype=torch.uint8)
+    m[0, :5] = 255
+    out = hip.mask_u8(m.cuda())
+    assert torch.equal(out.cpu(), (m.float() / 255)[:, None])
+    assert torch.equal(out.long().cpu(), (m == 255).long()[:, None])

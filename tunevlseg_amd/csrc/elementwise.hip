@@ -197,6 +197,24 @@ __global__ void pixel_unshuffle_kernel(const float* __restrict__ dlogits, float 
     }
 }
 
+// ---- input side: decoded uint8 sample -> network input (albumentations Normalize + ToTensorV2 of the reference's transforms) ----
+// image [B,H,W,3] uint8 -> [B,3,H,W] float, (x/255 - mean[c]) / std[c]; one thread = 4 consecutive pixels of one (b, c) plane row
+__global__ void normalize_u8_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, long pixels_per_image, int B,
+                                    float m0, float m1, float m2, float s0, float s1, float s2) {
+    const long total = (long)B * pixels_per_image;
+    const float mean[3] = {m0, m1, m2}, inv[3] = {1.0f / (255.0f * s0), 1.0f / (255.0f * s1), 1.0f / (255.0f * s2)};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / pixels_per_image, p = i - b * pixels_per_image;
+        const uint8_t* px = img + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(b * 3 + c) * pixels_per_image + p] = ((float)px[c] - 255.0f * mean[c]) * inv[c];
+    }
+}
+// mask [B,H,W] uint8 -> [B,1,H,W] float = x / 255 (image_text_mask_dataset.py:66-71); the metrics' mask.long() keeps only 255
+__global__ void mask_u8_kernel(const uint8_t* __restrict__ m, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)m[i] / 255.0f;
+}
+
 // ---- (1 - r) * main + r * extra with r read on the device (trainable residual_ratio: no host round trip) ----
 __global__ void mix_kernel(const float* __restrict__ main_, const float* __restrict__ extra, const float* __restrict__ ratio,
                            float* __restrict__ out, long n) {
@@ -427,6 +445,22 @@ extern "C" int tvl_pixel_unshuffle_bwd(const float* dlogits, float a, float* dco
     TVL_REQUIRE(dlogits && dcols && B > 0 && G > 0 && ps > 0, "tvl_pixel_unshuffle_bwd: bad arguments");
     hipLaunchKernelGGL(pixel_unshuffle_kernel, GRID_FOR((long)B * G * ps * G * ps), dim3(256), 0, S_(stream), dlogits, a, dcols, B, G, ps);
     TVL_LAUNCH_CHECK("tvl_pixel_unshuffle_bwd");
+    return 0;
+}
+
+extern "C" int tvl_normalize_u8(const uint8_t* img, float* out, int32_t B, int32_t H, int32_t W, const float* mean3, const float* std3,
+                                tvlStream_t stream) {
+    TVL_REQUIRE(img && out && mean3 && std3 && B > 0 && H > 0 && W > 0, "tvl_normalize_u8: bad arguments");
+    TVL_REQUIRE(std3[0] > 0.f && std3[1] > 0.f && std3[2] > 0.f, "tvl_normalize_u8: std must be positive");
+    hipLaunchKernelGGL(normalize_u8_kernel, GRID_FOR((long)B * H * W), dim3(256), 0, S_(stream), img, out, (long)H * W, B, mean3[0], mean3[1],
+                       mean3[2], std3[0], std3[1], std3[2]);
+    TVL_LAUNCH_CHECK("tvl_normalize_u8");
+    return 0;
+}
+extern "C" int tvl_mask_u8(const uint8_t* mask, float* out, int64_t n, tvlStream_t stream) {
+    TVL_REQUIRE(mask && out && n > 0, "tvl_mask_u8: bad arguments");
+    hipLaunchKernelGGL(mask_u8_kernel, GRID_FOR((long)n), dim3(256), 0, S_(stream), mask, out, (long)n);
+    TVL_LAUNCH_CHECK("tvl_mask_u8");
     return 0;
 }
 

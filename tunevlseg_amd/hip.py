@@ -119,6 +119,8 @@ _SIGS = {
     "tvl_upconv_taps_bwd": [_P, _P, _I, _P, _I, _I, _I, _I],
     "tvl_dicece_stats": [_P, _P, _P, _P, _P, _P, _I, _L, _F],
     "tvl_dicece_bwd": [_P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _P],
+    "tvl_normalize_u8": [_P, _P, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)],
+    "tvl_mask_u8": [_P, _P, _L],
     "tvl_mix": [_P, _P, _P, _P, _L],
     "tvl_scale_dev": [_P, _P, _I, _P, _L],
     "tvl_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F],
@@ -672,6 +674,25 @@ def dicece_bwd(logits, target, fsum, lambda_dice, lambda_ce, smooth_nr, smooth_d
     _call("tvl_dicece_bwd", _p(logits), _p(target), _p(fsum, torch.float64), _p(dl), B, N, float(lambda_dice), float(lambda_ce),
           float(smooth_nr), float(smooth_dr), _p(gscale))
     return dl
+
+
+def normalize_u8(img_u8: torch.Tensor, mean, std) -> torch.Tensor:
+    """Decoded images [B,H,W,3] uint8 -> normalised network input [B,3,H,W] float: ((x / 255) - mean) / std per channel."""
+    B, H, W, Cc = img_u8.shape
+    if Cc != 3 or img_u8.dtype != torch.uint8:
+        raise RuntimeError(f"normalize_u8 wants [B,H,W,3] uint8, got {tuple(img_u8.shape)} {img_u8.dtype}")
+    out = torch.empty((B, 3, H, W), device=img_u8.device, dtype=torch.float32)
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    _call("tvl_normalize_u8", _p(img_u8, torch.uint8), _p(out), B, H, W, m3, s3)
+    return out
+
+
+def mask_u8(mask_u8_: torch.Tensor) -> torch.Tensor:
+    """Decoded grey-level masks [B,H,W] uint8 -> [B,1,H,W] float in [0, 1] (value / 255)."""
+    B, H, W = mask_u8_.shape
+    out = torch.empty((B, 1, H, W), device=mask_u8_.device, dtype=torch.float32)
+    _call("tvl_mask_u8", _p(mask_u8_, torch.uint8), _p(out), mask_u8_.numel())
+    return out
 
 
 def mix(main, extra, ratio):
