@@ -96,3 +96,39 @@ def test_constructor_surface_and_errors():
     assert pm.tolist() == [[False, False, False, False, False, True, True]]  # 2 zeros prepended (coop_context_learner.py:82-114)
     with pytest.raises(ValueError):  # wrong image size is refused up front, before any kernel runs
         net2(text_input={"input_ids": torch.tensor([[5, 3, 9, 0, 0]])}, image_input=torch.zeros(1, 3, 64, 64))
+
+
+def test_checkpoints_under_the_reference_file_layouts(tmp_path):
+    """``clip_pretrain`` is a bare CLIP state dict (the RN50.pt archive has no ``backbone.`` prefix and no neck /
+    decoder / projector) and ``cris_pretrain`` the full model, loaded strictly (only BatchNorm's num_batches_tracked may be extra)."""
+    cfg = CRISConfig.tiny()
+    full = init_cris_state_dict(cfg, 77)
+    clip_only = {k[len("backbone."):]: v for k, v in full.items() if k.startswith("backbone.")}
+    clip_only["input_resolution"] = torch.tensor(224)  # scalars the TorchScript archive carries besides the weights
+    clip_file, cris_file = tmp_path / "RN50_like.pt", tmp_path / "cris_best_single.pth"
+    torch.save(clip_only, clip_file)
+    other = init_cris_state_dict(cfg, 78)
+    cris_sd = {**other, "neck.f1_v_proj.1.num_batches_tracked": torch.tensor(5)}
+    torch.save(cris_sd, cris_file)
+    w = CRISWeights.from_spec(str(clip_file), overrides={"config": cfg})
+    own = w.state_dict()
+    assert all(torch.equal(own[k], full[k]) for k in full if k.startswith("backbone."))       # the CLIP part came from the file
+    seeded = init_cris_state_dict(cfg, 0)
+    assert all(torch.equal(own[k], seeded[k]) for k in full if not k.startswith("backbone."))  # the rest awaits cris_pretrain
+    from tunevlseg_amd.nets import COOPCRIS
+    from tunevlseg_amd.nets.context_learner import CoOpContextLearner
+
+    net = COOPCRIS(model_cfg={"clip_pretrain": str(clip_file), "cris_pretrain": str(cris_file), "config": cfg, "img_size": cfg.img_size},
+                   context_learner=partial(CoOpContextLearner, prompt_depth=1, num_context=2))
+    got = {k: v for k, v in net.state_dict().items() if k in other}
+    assert got and all(torch.equal(got[k], other[k]) for k in got)  # strict load of the full CRIS checkpoint over it
+    bad = dict(other)
+    bad.pop("proj.txt.weight")
+    torch.save(bad, cris_file)
+    with pytest.raises(RuntimeError):  # a checkpoint with a missing tensor is an error, not a silent partial load
+        COOPCRIS(model_cfg={"clip_pretrain": str(clip_file), "cris_pretrain": str(cris_file), "config": cfg, "img_size": cfg.img_size},
+                 context_learner=partial(CoOpContextLearner, prompt_depth=1, num_context=2))
+    clip_only["visual.bogus.weight"] = torch.zeros(1)
+    torch.save(clip_only, clip_file)
+    with pytest.raises(RuntimeError):
+        CRISWeights.from_spec(str(clip_file), overrides={"config": cfg})

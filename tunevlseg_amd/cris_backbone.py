@@ -49,6 +49,13 @@ def linear_matrices(w2: torch.Tensor, b: torch.Tensor | None) -> FrozenLinear:
     return FrozenLinear(w2, None if b is None else b.contiguous(), w2.t().contiguous())
 
 
+def _numel(shape) -> int:
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
+
+
 class CRISWeights(_Node):
     def __init__(self, config: CRISConfig, state_dict: Mapping[str, torch.Tensor] | None = None, seed: int = 0):
         super().__init__()
@@ -100,16 +107,42 @@ class CRISWeights(_Node):
             for k, v in ov.items():
                 setattr(cfg, k, v)
             return cls(cfg, None, seed=int(opts.get("seed", 0)))
-        try:
-            sd = torch.load(spec, map_location="cpu")
-        except Exception as e:  # pragma: no cover - needs a real checkpoint
-            raise RuntimeError(
-                f"cannot load CRIS weights from {spec!r} ({type(e).__name__}: {e}). Pass a state-dict file under the reference's "
-                "module names, or 'random:rn50:seed=0' for seeded random weights.") from e
-        cfg = _preset("rn50")
+        cfg = (overrides or {}).get("config") if isinstance((overrides or {}).get("config"), CRISConfig) else _preset("rn50")
         for k, v in ov.items():
             setattr(cfg, k, v)
-        return cls(cfg, sd)
+        return cls(cfg, cls.read_checkpoint(spec, cfg))
+
+    @staticmethod
+    def read_checkpoint(path, cfg: CRISConfig, seed: int = 0) -> dict[str, torch.Tensor]:
+        """A weight file under the reference's names.  Two forms reach ``clip_pretrain`` (``configs/model/coop/cris.yaml``):
+        OpenAI's TorchScript CLIP archive ``pretrain/RN50.pt`` (the reference reads it with ``torch.jit.load(...).state_dict()`` and
+        ``build_model``, ``cris_model/__init__.py:66-70``) -- keys ``visual.*``, ``transformer.*``, ``token_embedding.weight`` ...
+        without the ``backbone.`` prefix and without neck / decoder / projector -- or a full CRIS state dict.  CLIP-only files are
+        prefixed; what they do not contain starts from the seeded initialisation and is expected from ``cris_pretrain``."""
+        try:
+            sd = torch.jit.load(path, map_location="cpu").state_dict()
+        except Exception:
+            try:
+                sd = torch.load(path, map_location="cpu", weights_only=False)
+            except Exception as e:  # pragma: no cover - needs a corrupt file
+                raise RuntimeError(f"cannot load CRIS / CLIP weights from {path!r} ({type(e).__name__}: {e}). Pass the CLIP RN50 archive, a "
+                                   "state-dict file under the reference's module names, or 'random:rn50:seed=0'.") from e
+        if isinstance(sd, Mapping) and "state_dict" in sd and not any(k.startswith(("backbone.", "visual.")) for k in sd):
+            sd = sd["state_dict"]
+        sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+        if not any(k.startswith("backbone.") for k in sd):  # a bare CLIP model
+            skip = ("input_resolution", "context_length", "vocab_size")  # scalars of the TorchScript archive
+            sd = {f"backbone.{k}": v for k, v in sd.items() if k not in skip}
+        full = init_cris_state_dict(cfg, seed)
+        wanted = {name: tuple(shape) for name, shape, _, _ in cris_param_specs(cfg)}
+        bad = [k for k, v in sd.items() if k in wanted and tuple(v.shape) != wanted[k] and v.numel() != _numel(wanted[k])]
+        if bad:
+            raise RuntimeError(f"{path}: tensors do not match the {type(cfg).__name__} geometry: {bad[:4]}")
+        unknown = [k for k in sd if k not in wanted and not k.endswith("num_batches_tracked")]
+        if unknown:
+            raise RuntimeError(f"{path}: unexpected keys {unknown[:4]} (+{max(0, len(unknown) - 4)} more)")
+        full.update({k: v.float() for k, v in sd.items() if k in wanted})
+        return full
 
     # ------------------------------------------------------------------ GEMM-ready frozen weights
     def prepared(self) -> dict[str, Any]:

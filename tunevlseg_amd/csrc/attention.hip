@@ -549,7 +549,7 @@ extern "C" int tvl_attn_fwd(const tvlAttnFwdArgs* a, tvlStream_t stream) {
     dim3 grid((a->T + 127) / 128, a->H, a->B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (a->dh == 64 && !a->causal && !a->key_mask && p.Tk == p.T && tvl_attn_mode_bf16s()) {
-        tvl_attn_fwd_bf16s_impl(a, nullptr, s);
+        TVL_REQUIRE(tvl_attn_fwd_bf16s_impl(a, nullptr, s) == 0, "tvl_attn_fwd: split-bf16 launch failed");
         TVL_LAUNCH_CHECK("tvl_attn_fwd(bf16s)");
         return 0;
     }
@@ -596,7 +596,7 @@ extern "C" int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream) {
         TVL_LAUNCH_CHECK("tvl_attn_bwd(delta)");
     }
     if (a->dh == 64 && !a->causal && !a->key_mask && p.Tk == p.T && tvl_attn_mode_bf16s()) {
-        tvl_attn_bwd_bf16s_impl(a, nullptr, nullptr, s);
+        TVL_REQUIRE(tvl_attn_bwd_bf16s_impl(a, nullptr, nullptr, s) == 0, "tvl_attn_bwd: split-bf16 launch failed");
         TVL_LAUNCH_CHECK("tvl_attn_bwd(bf16s)");
         return 0;
     }
@@ -618,7 +618,7 @@ extern "C" int tvl_attn_fwd_tp3(const tvlAttnFwdArgs* a, void* o_tp3, tvlStream_
     TVL_REQUIRE(strides_ok(a->q, a->q_bs, a->q_ts) && strides_ok(a->k, a->k_bs, a->k_ts) && strides_ok(a->v, a->v_bs, a->v_ts) && tvl_aligned16(o_tp3) &&
                     (!a->o || (tvl_aligned16(a->o) && a->ldo % 4 == 0 && a->ldo >= a->H * 64)),
                 "tvl_attn_fwd_tp3: operands must be 16-byte aligned with strides divisible by 4");
-    tvl_attn_fwd_bf16s_impl(a, o_tp3, reinterpret_cast<hipStream_t>(stream));
+    TVL_REQUIRE(tvl_attn_fwd_bf16s_impl(a, o_tp3, reinterpret_cast<hipStream_t>(stream)) == 0, "tvl_attn_fwd_tp3: launch failed");
     TVL_LAUNCH_CHECK("tvl_attn_fwd_tp3");
     return 0;
 }
@@ -632,7 +632,7 @@ extern "C" int tvl_attn_bwd_tp3(const tvlAttnBwdArgs* a, const void* o_tp3, void
                     a->ldo % 4 == 0 && tvl_aligned16(o_tp3) && tvl_aligned16(dqkv_tp3),
                 "tvl_attn_bwd_tp3: operands must be 16-byte aligned with strides divisible by 4");
     TVL_REQUIRE(!a->dq && !a->dk && !a->dv, "tvl_attn_bwd_tp3: the gradient leaves as the tp3 image only (dq/dk/dv must be NULL)");
-    tvl_attn_bwd_bf16s_impl(a, o_tp3, dqkv_tp3, reinterpret_cast<hipStream_t>(stream));
+    TVL_REQUIRE(tvl_attn_bwd_bf16s_impl(a, o_tp3, dqkv_tp3, reinterpret_cast<hipStream_t>(stream)) == 0, "tvl_attn_bwd_tp3: launch failed");
     TVL_LAUNCH_CHECK("tvl_attn_bwd_tp3");
     return 0;
 }

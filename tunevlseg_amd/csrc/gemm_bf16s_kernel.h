@@ -578,11 +578,13 @@ int launch_v(const GemmParams& p0, hipStream_t s) {
     constexpr size_t stage_bytes = (size_t)STAGES * S * (BM + BN) * (BK + 8) * sizeof(__bf16);
     constexpr size_t epi_bytes = (size_t)NWAVES * 32 * 36 * sizeof(float);  // per-wave scratch of the coalesced epilogue
     constexpr size_t smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
-    static bool attr_set = false;
+    static int attr_dev_mask = 0;  // the > 64 KiB dynamic-LDS opt-in is a per-device function attribute
     auto kern = gemm_bf16s_kernel<BM, BN, WGM, S, VEC, BK, STAGES, CONV>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    if (!(attr_dev_mask & (1 << dev))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 1;
+        attr_dev_mask |= 1 << dev;
     }
     const long nwg = (long)p.tiles_m * p.tiles_n;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NTHREADS), smem, s, p);

@@ -32,8 +32,11 @@ class COOPCRIS(nn.Module):
         cfg = dict(model_cfg)
         weights = CRISWeights.from_spec(cfg.get("clip_pretrain"), overrides=cfg)
         if cfg.get("cris_pretrain") is not None and not isinstance(cfg.get("clip_pretrain"), (CRISWeights, Mapping)):
-            sd = torch.load(cfg["cris_pretrain"], map_location="cpu") if not isinstance(cfg["cris_pretrain"], Mapping) else cfg["cris_pretrain"]
-            weights.load_state_dict(sd, strict=False)
+            sd = cfg["cris_pretrain"] if isinstance(cfg["cris_pretrain"], Mapping) else torch.load(cfg["cris_pretrain"], map_location="cpu", weights_only=False)
+            # strict, as the reference loads it (cris_model/__init__.py:66-70); BatchNorm's num_batches_tracked counters are the only
+            # entries this (eval-only, BN-folded) parameter tree does not hold
+            sd = {k: v for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+            weights.load_state_dict(sd, strict=True)
         self._weights = [weights]  # not a submodule: its four subtrees are registered under the reference's names below
         self.config = weights.config
         self.img_size = int(cfg.get("img_size", weights.config.img_size))
