@@ -26,7 +26,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 GFLOP_PER_IMAGE_TRAIN = 167.1  # VPT-10 shallow 352^2, fwd 80.6 + bwd 86.5 (FlopCounterMode on the reference)
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak (exact-fp32 mode only)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 # fp32 products cost this many bf16 MFMA products in each GEMM mode -> ceiling in algorithmic (fp32) TFLOP/s
 MODE_PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16": PEAK_BF16_MFMA_TFLOPS}
@@ -118,34 +118,65 @@ def build_module(device, num_context: int = 10, prompt_depth: int = 1, seed: int
     return module, opt
 
 
-def cpu_baseline(batch_size: int, steps: int) -> dict:
-    """The CPU oracle (a port of the reference's trainer=cpu path, pinned by the golden fixtures) timed on the host cores."""
+def cpu_baseline(steps32: int = 2, steps4: int = 3) -> dict:
+    """The reference's trainer=cpu path on the host cores of this box: the CPU oracle -- a port pinned by the
+    golden fixtures; the reference's own Python cannot travel -- runs the identical train step (forward, DiceCE, backward, AdamW),
+    fp32, ``set_float32_matmul_precision("medium")`` (reference src/models/__init__.py:6), all host threads.
+    Two bounded samples: the headline workload's own shape (VPT-10 shallow, bs 32) and config C1 (CoOp-4, bs 4)."""
     from oracle import clipseg_oracle as O
     from tunevlseg_amd.config import CLIPSegConfig
     from tunevlseg_amd.weights import init_clipseg_state_dict
 
-    torch.set_float32_matmul_precision("medium")  # reference src/models/__init__.py:6
+    torch.set_float32_matmul_precision("medium")
     cores = torch.get_num_threads()
     cfg = CLIPSegConfig.rd64()
     sd = init_clipseg_state_dict(cfg, 0)
-    ctx = (torch.randn(1, 10, 768) * 0.02).requires_grad_(True)
-    opt = torch.optim.AdamW([ctx], lr=2e-4)
-    b = make_batch(batch_size, 352, 7, "cpu")
 
-    def step():
-        opt.zero_grad()
-        logits = O.vpt_forward(sd, cfg, {"kind": "vpt", "ctx": ctx}, b["image"], b["input_ids"], b["attention_mask"])
-        O.dice_ce_loss(logits, b["mask"]).backward()
-        opt.step()
+    def timed(step, warm: int, n: int) -> list[float]:
+        for _ in range(warm):
+            step()
+        out = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            step()
+            out.append(time.perf_counter() - t0)
+        return out
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    dt = time.perf_counter() - t0
+    def median(v):
+        v = sorted(v)
+        return 0.5 * (v[(len(v) - 1) // 2] + v[len(v) // 2])
+
+    # C2 shape: VPT-10 shallow, bs 32, seed 1 (SURVEY §8d)
+    vctx = (torch.randn(1, 10, 768, generator=torch.Generator().manual_seed(1)) * 0.02).requires_grad_(True)
+    vopt = torch.optim.AdamW([vctx], lr=2e-4)
+    b32 = make_batch(32, 352, 1, "cpu")
+
+    def vpt_step():
+        vopt.zero_grad()
+        logits = O.vpt_forward(sd, cfg, {"kind": "vpt", "ctx": vctx}, b32["image"], b32["input_ids"], b32["attention_mask"])
+        O.dice_ce_loss(logits, b32["mask"]).backward()
+        vopt.step()
+
+    t32 = timed(vpt_step, 0, steps32)  # ~40-80 s per step on the host cores: no separate warm-up, every step reported
+    # C1: CoOp-4 (4 context tokens, depth 1), bs 4, seed 0
+    cctx = (torch.randn(1, 4, 512, generator=torch.Generator().manual_seed(0)) * 0.02).requires_grad_(True)
+    copt = torch.optim.AdamW([cctx], lr=2e-4)
+    b4 = make_batch(4, 352, 0, "cpu")
+
+    def coop_step():
+        copt.zero_grad()
+        logits = O.coop_forward(sd, cfg, {"kind": "coop", "ctx": cctx}, b4["image"], b4["input_ids"], b4["attention_mask"])
+        O.dice_ce_loss(logits, b4["mask"]).backward()
+        copt.step()
+
+    t4 = timed(coop_step, 1, steps4)
     torch.set_float32_matmul_precision("highest")
-    return {"value": round(batch_size * steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} train steps of the same VPT-10 352x352 workload at bs={batch_size} (1 warm-up), fp32 torch CPU oracle"}
+    return {"value": round(32 / median(t32), 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"median of {steps32} train steps (no warm-up; each step's seconds listed) of the headline workload's own shape -- VPT-10 shallow, 352x352, bs 32 -- "
+                      "on the fp32 torch CPU oracle",
+            "step_seconds_bs32": [round(t, 2) for t in t32],
+            "c1_coop4_bs4": {"value": round(4 / median(t4), 3), "unit": "images/s",
+                             "sample": f"median of {steps4} train steps (1 warm-up), CLIPSeg + CoOp-4, 352x352, bs 4 (BASELINE configs[0])"}}
 
 
 def main():
@@ -155,8 +186,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps32", type=int, default=2, help="timed CPU-oracle steps at the headline shape (bs 32)")
+    ap.add_argument("--cpu-steps4", type=int, default=3, help="timed CPU-oracle steps of config C1 (CoOp-4, bs 4)")
     ap.add_argument("--workload", choices=("vpt", "cris", "maple"), default="vpt",
                     help="vpt = BASELINE configs[1] (the headline line); cris = configs[2] (CRIS + CoCoOp, 416x416) and maple = configs[3] "
                          "(MaPLe depth 9) are reported for DESIGN.md")
@@ -206,7 +237,8 @@ def main():
         elapsed = float(t.item())
     metrics = module.epoch_metrics("train")
 
-    # ---- roofline of the dominant kernel: HIP events around every GEMM launch of 2 extra (untimed) steps ----
+    # ---- roofline of the dominant kernel: HIP events (on torch's current stream = the launch stream) around every GEMM launch of
+    # 2 extra, untimed steps.  achieved = algorithmic FLOPs (2*M*N*K per launch) / summed launch time.
     hip.gemm_profile_start()
     for _ in range(2):
         step()
@@ -218,17 +250,21 @@ def main():
         gemm_ms = sum(v["ms"] for v in prof.values()) / 2
         split = "bf16s" in name or "tp3" in name
         peak = MODE_PEAK[hip.GEMM_MODE] if split else PEAK_F32_MFMA_TFLOPS
-        # HBM bytes per launch of that kernel from the PMC passes recorded in profiles/ (rocprofv3 --pmc FETCH_SIZE, then
-        # WRITE_SIZE, each in its own run; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM)
-        traffic = None
-        tf = ROOT / "profiles" / ("r1_k_cris_hbm_traffic.json" if cris else "r1_k_hbm_traffic.json")
-        if tf.exists() and not maple:
-            rec = json.loads(tf.read_text()).get(name)
-            traffic = rec["hbm_bytes_per_launch"] if rec else None
+        # HBM bytes per launch of that kernel: recorded by two separate rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE; FETCH_SIZE
+        # doubled per the gfx950 note of MI355X_MICROARCH.md §HBM) and committed under profiles/.  It is a RECORDED number: reported
+        # only when the record names the same kernel instantiation, and always with the file and commit it came from.
+        traffic, traffic_source = None, None
+        tf = ROOT / "profiles" / {"cris": "r2_cris_hbm_traffic.json", "maple": "r2_maple_hbm_traffic.json"}.get(args.workload, "r2_hbm_traffic.json")
+        if tf.exists():
+            rec_all = json.loads(tf.read_text())
+            rec = rec_all.get("kernels", rec_all).get(name.replace(", ", ","))
+            if rec:
+                traffic = rec["hbm_bytes_per_launch"]
+                traffic_source = {"file": str(tf.relative_to(ROOT)), "recorded_at_commit": rec_all.get("commit"), "kind": "recorded (rocprofv3 --pmc), not measured by this run"}
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": name,
-                    "peak_note": "algorithmic fp32 FLOP/s ceiling = dense bf16 MFMA peak / MFMAs per fp32 product" if split
-                    else "dense f32-input MFMA peak", "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "kernel": name,
+                    "peak_note": "algorithmic fp32 FLOP/s ceiling = dense bf16 MFMA peak (2.5 PFLOP/s) / 6 MFMAs per fp32 product" if split
+                    else "dense f32-input MFMA peak",
                     "launches_per_step": d["launches"] // 2, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1),
                     "flops_per_launch": round(d["flops"] / d["launches"]), "all_gemm_ms_per_step": round(gemm_ms, 2),
                     # every GEMM instantiation of the step (one instantiation serves several shapes: the average mixes them)
@@ -256,12 +292,12 @@ def main():
                        "weights": "seeded random init (RN50 CRIS geometry)" if cris else "seeded random init (rd64 geometry)",
                        "use_new_last_layer": cris or maple},
             "step_tflops": round(value * gflop_per_image / 1e3, 2),
-            "step_frac_of_f32_mfma_peak": round(value / world * gflop_per_image / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+            "step_frac_of_ceiling": round(value / world * gflop_per_image / 1e3 / MODE_PEAK[hip.GEMM_MODE], 4),
             "loss": round(float(loss.item()), 6), "train_dice": round(metrics["train_dice"], 6), "train_iou": round(metrics["train_iou"], 6),
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1 and not cris and not maple:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_steps32, args.cpu_steps4)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -125,6 +125,9 @@ int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream);
  * [B*T, H*64] (a->o may be NULL), the backward takes that image for delta = rowsum(dO * O) and writes dQ | dK | dV as the tp3
  * image of the packed gradient [B*T, 3*H*64] -- the A operand of the QKV data-gradient GEMM (a->o, a->dq/dk/dv must be NULL). */
 int tvl_attn_fwd_tp3(const tvlAttnFwdArgs* a, void* o_tp3, tvlStream_t stream);
+/* The same attention with Q, K, V read from the tp3 image of the packed QKV matrix [B*T, 3*H*64] (written by the QKV GEMM's
+ * epilogue): key tiles are filled by LDS-DMA, nothing is split in the kernel.  lse [B,H,T] may be NULL. */
+int tvl_attn_tp3_fwd(const void* qkv_tp3, void* o_tp3, float* lse, int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream);
 int tvl_attn_bwd_tp3(const tvlAttnBwdArgs* a, const void* o_tp3, void* dqkv_tp3, tvlStream_t stream);
 
 /* ---- token plumbing (reference vpt_context_learner.py:46-64, base_visual_learner.py:18-23,

@@ -519,3 +519,15 @@ def test_input_side_normalize_and_mask(hip):
     out = hip.mask_u8(m.cuda())
     assert torch.equal(out.cpu(), (m.float() / 255)[:, None])
     assert torch.equal(out.long().cpu(), (m == 255).long()[:, None])
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 495, 12), (3, 100, 2), (1, 33, 1), (4, 64, 3), (2, 485, 12)])
+def test_attention_on_tp3_qkv(hip, B, T, H):
+    """Attention reading Q / K / V from the tp3 image of the packed QKV matrix (LDS-DMA key tiles aligned to the image's row
+    blocks, neighbouring samples' keys masked) against the fp32-input kernel: same piece arithmetic, different key tiling."""
+    dh, D = 64, H * 64
+    qkv = dev(rnd(B * T, 3 * D, seed=1))
+    o_ref, lse_ref = hip.attn_fwd_packed(qkv, B, T, H, dh, dh**-0.5)
+    o, lse = hip.attn_tp3_fwd(hip.tp3_pack(qkv), B, T, H, dh**-0.5)
+    close(o.float(), o_ref, 2e-6, "attn tp3 fwd O")
+    close(lse, lse_ref, 1e-6, "attn tp3 fwd lse")

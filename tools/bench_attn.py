@@ -32,6 +32,9 @@ def main():
     tf = timeit(lambda: hip.attn_fwd_packed(qkv, B, T, H, dh, dh ** -0.5))
     tb = timeit(lambda: hip.attn_bwd_packed(qkv, o, d_o, lse, B, T, H, dh, dh ** -0.5))
     fl = 4.0 * T * T * dh * H * B
+    qkv_t = hip.tp3_pack(qkv)
+    tf3 = timeit(lambda: hip.attn_tp3_fwd(qkv_t, B, T, H, dh ** -0.5))
+    print(f"fwd on the tp3 QKV image (LDS-DMA key tiles): {tf3*1e3:.1f} us  {fl/tf3/1e9:.1f} TF/s")
     print(f"fwd {tf*1e3:.1f} us  {fl/tf/1e9:.1f} TF/s   bwd {tb*1e3:.1f} us  {2.5*fl/tb/1e9:.1f} TF/s (algorithmic 10 T^2 d)")
 
 

@@ -141,6 +141,7 @@ _SIGS = {
     "tvl_layernorm_bwd_tp3": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
     "tvl_attn_fwd_tp3": [C.POINTER(AttnFwdArgs), _P],
     "tvl_attn_bwd_tp3": [C.POINTER(AttnBwdArgs), _P, _P],
+    "tvl_attn_tp3_fwd": [_P, _P, _P, _I, _I, _I, _F],
     "tvl_tp3_pack": [_P, _L, _L, _I, _P],
     "tvl_tp3_unpack": [_P, _L, _I, _P, _L],
     "tvl_gemm_tp3": [C.POINTER(GemmTp3Args)],
@@ -313,7 +314,10 @@ class Tp3:
             raise RuntimeError(f"tp3 needs cols % 16 == 0, got {cols}")
         self.rows, self.cols = rows, cols
         n = (rows + 31) // 32 * (cols // 16) * 3072
-        self.buf = buf if buf is not None else torch.empty(n, device=device, dtype=torch.uint8)
+        # rows beyond `rows` in the last 32-row block are read by whole-block consumers (attention key tiles: p = 0 times a stale
+        # NaN would poison the sum): an image with padded rows starts zeroed
+        make = torch.zeros if rows % 32 else torch.empty
+        self.buf = buf if buf is not None else make(n, device=device, dtype=torch.uint8)
 
     @property
     def shape(self):
@@ -522,6 +526,17 @@ def attn_fwd_packed_tp3(qkv: torch.Tensor, B: int, T: int, H: int, dh: int, scal
     a = AttnFwdArgs(base, base + 4 * D, base + 8 * D, 3 * D * T, 3 * D * T, 3 * D * T, 3 * D, 3 * D, 3 * D, None, D, _p(lse),
                     None, B, H, T, dh, 0, float(scale))
     _call("tvl_attn_fwd_tp3", C.byref(a), o.buf.data_ptr())
+    return o, lse
+
+
+def attn_tp3_fwd(qkv_t: Tp3, B: int, T: int, H: int, scale: float, want_lse=True):
+    """Attention over the Tp3 image of the packed QKV matrix [B*T, 3*H*64] (d_h = 64): returns (Tp3 image of O, lse)."""
+    D = H * 64
+    if qkv_t.rows != B * T or qkv_t.cols != 3 * D:
+        raise RuntimeError(f"attn_tp3_fwd: QKV image is {qkv_t.shape}, expected {(B * T, 3 * D)}")
+    o = Tp3(B * T, D, qkv_t.buf.device)
+    lse = torch.empty((B, H, T), device=qkv_t.buf.device, dtype=torch.float32) if want_lse else None
+    _call("tvl_attn_tp3_fwd", qkv_t.buf.data_ptr(), o.buf.data_ptr(), _p(lse), B, H, T, float(scale))
     return o, lse
 
 
