@@ -128,6 +128,9 @@ int tvl_attn_fwd_tp3(const tvlAttnFwdArgs* a, void* o_tp3, tvlStream_t stream);
 /* The same attention with Q, K, V read from the tp3 image of the packed QKV matrix [B*T, 3*H*64] (written by the QKV GEMM's
  * epilogue): key tiles are filled by LDS-DMA, nothing is split in the kernel.  lse [B,H,T] may be NULL. */
 int tvl_attn_tp3_fwd(const void* qkv_tp3, void* o_tp3, float* lse, int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream);
+/* diagnostics (tools/bench_attn.py): ablation variants / per-workgroup clock stamps; outputs of variants != 0, 16 are wrong by construction */
+int tvl_attn_tp3_fwd_diag(const void* qkv_tp3, void* o_tp3, float* lse, int32_t B, int32_t H, int32_t T, float scale, int32_t variant,
+                          int64_t* stamps, tvlStream_t stream);
 int tvl_attn_bwd_tp3(const tvlAttnBwdArgs* a, const void* o_tp3, void* dqkv_tp3, tvlStream_t stream);
 
 /* ---- token plumbing (reference vpt_context_learner.py:46-64, base_visual_learner.py:18-23,

@@ -35,6 +35,51 @@ def main():
     qkv_t = hip.tp3_pack(qkv)
     tf3 = timeit(lambda: hip.attn_tp3_fwd(qkv_t, B, T, H, dh ** -0.5))
     print(f"fwd on the tp3 QKV image (LDS-DMA key tiles): {tf3*1e3:.1f} us  {fl/tf3/1e9:.1f} TF/s")
+    if "--diag" in sys.argv:
+        o3 = hip.Tp3(B * T, D, qkv.device)
+        lse3 = torch.empty(B, H, T, device="cuda")
+        nwg = (T + 127) // 128 * H * B
+        stamps = torch.zeros(nwg, 4, dtype=torch.int64, device="cuda")
+
+        def diag(v):
+            hip._call("tvl_attn_tp3_fwd_diag", qkv_t.buf.data_ptr(), o3.buf.data_ptr(), lse3.data_ptr(), B, H, T, dh ** -0.5, v, stamps.data_ptr())
+
+        for v, what in ((0, "product"), (1, "no DMA after the prologue")):
+            t = timeit(lambda: diag(v))
+            print(f"  variant {v:2d} ({what}): {t*1e3:.1f} us")
+        diag(16)
+        torch.cuda.synchronize()
+        raw = stamps.cpu()
+        where = raw[:, 3] >> 40
+        raw[:, 3] &= (1 << 40) - 1
+        raw[:, 2] &= (1 << 40) - 1
+        st = raw.double()
+        cyc, wall = st[:, 1] - st[:, 0], (st[:, 3] - st[:, 2]) * 10.0   # wall clock ticks at 100 MHz -> ns
+        t_start = (st[:, 2] - st[:, 2].min()) * 10.0 / 1e3
+        span = (st[:, 3].max() - st[:, 2].min()) * 10.0
+        ntile = (T + 31) // 32 + 1
+        print(f"  stamps: workgroup duration {cyc.mean():.0f} cycles (min {cyc.min():.0f}, max {cyc.max():.0f}) / {wall.mean()/1e3:.1f} us "
+              f"(min {wall.min()/1e3:.1f}, max {wall.max()/1e3:.1f}); clock {(cyc / wall).mean():.2f} GHz (min {(cyc / wall).min():.2f}, "
+              f"max {(cyc / wall).max():.2f}); first start -> last end {span/1e3:.1f} us; per tile {cyc.mean() / ntile:.0f} cycles")
+        first = t_start < 5.0
+        print(f"  first round: {int(first.sum())} workgroups, {cyc[first].mean():.0f} cycles; later: {cyc[~first].mean():.0f} cycles")
+        print("  start-time histogram (us):", torch.histc(t_start.float(), bins=8, min=0, max=float(span / 1e3)).int().tolist())
+        # per CU: how many workgroups it ran, and how their durations compare
+        cus = {}
+        for w, c, f in zip(where.tolist(), cyc.tolist(), first.tolist()):
+            cus.setdefault(w, []).append((c, f))
+        n_first = [sum(1 for _, f in v if f) for v in cus.values()]
+        print(f"  {len(cus)} distinct (xcc, se, sh, cu); first-round workgroups per CU: " + str({k: n_first.count(k) for k in sorted(set(n_first))})
+              + "; total per CU: " + str({k: [len(v) for v in cus.values()].count(k) for k in sorted({len(v) for v in cus.values()})}))
+        by_n = {}
+        for v in cus.values():
+            nf = sum(1 for _, f in v if f)
+            by_n.setdefault(nf, []).extend(c for c, f in v if f)
+        print("  first-round duration by co-residents:", {k: f"{sum(v)/len(v):.0f}" for k, v in sorted(by_n.items())})
+        xcc = {}
+        for w, c in zip(where.tolist(), cyc.tolist()):
+            xcc.setdefault(w >> 8, []).append(c)
+        print("  mean cycles by XCC:", {k: f"{sum(v)/len(v):.0f} (n={len(v)})" for k, v in sorted(xcc.items())})
     print(f"fwd {tf*1e3:.1f} us  {fl/tf/1e9:.1f} TF/s   bwd {tb*1e3:.1f} us  {2.5*fl/tb/1e9:.1f} TF/s (algorithmic 10 T^2 d)")
 
 

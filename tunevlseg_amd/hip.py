@@ -142,6 +142,7 @@ _SIGS = {
     "tvl_attn_fwd_tp3": [C.POINTER(AttnFwdArgs), _P],
     "tvl_attn_bwd_tp3": [C.POINTER(AttnBwdArgs), _P, _P],
     "tvl_attn_tp3_fwd": [_P, _P, _P, _I, _I, _I, _F],
+    "tvl_attn_tp3_fwd_diag": [_P, _P, _P, _I, _I, _I, _F, _I, _P],
     "tvl_tp3_pack": [_P, _L, _L, _I, _P],
     "tvl_tp3_unpack": [_P, _L, _I, _P, _L],
     "tvl_gemm_tp3": [C.POINTER(GemmTp3Args)],
