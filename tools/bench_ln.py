@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""LayerNorm -> tp3 micro-benchmark at the vision-tower shape (15,840 rows x 768): time and algorithmic HBM rate."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from tunevlseg_amd import hip  # noqa: E402
+
+
+def main():
+    hip.load()
+    rows, cols = 32 * 495, 768
+    torch.manual_seed(0)
+    x = torch.randn(rows, cols, device="cuda")
+    dy = torch.randn(rows, cols, device="cuda")
+    dres = torch.randn(rows, cols, device="cuda")
+    g, b = torch.randn(cols, device="cuda"), torch.randn(cols, device="cuda")
+    _, mean, rstd = hip.layernorm_fwd_tp3(x, g, b, 1e-5)
+
+    def timeit(fn, n=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+
+    n = rows * cols
+    tf = timeit(lambda: hip.layernorm_fwd_tp3(x, g, b, 1e-5))
+    tb = timeit(lambda: hip.layernorm_bwd_tp3(dy, x, g, mean, rstd, dres))
+    bf, bb = n * (4 + 6), n * (4 * 3 + 4 + 6)   # fwd: read x, write tp3; bwd: read dy, x, dres, write dx fp32 + tp3
+    print(f"ln_fwd_tp3 {tf*1e6:.1f} us  {bf/tf/1e12:.2f} TB/s algorithmic   ln_bwd_tp3 {tb*1e6:.1f} us  {bb/tb/1e12:.2f} TB/s algorithmic")
+
+
+if __name__ == "__main__":
+    main()

@@ -161,8 +161,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // coalesced reads): it leaves the row statistics in LDS.  Phase 2 walks the block in fragment order -- lane (r, h) takes 8
 // consecutive columns of row r (re-read from L2), normalises, splits into three bf16 pieces and the wave writes one 1-KiB
 // piece per store instruction (fully coalesced).  The fp32 result is never materialised: its only consumer is the GEMM.
-template <int LN_MAXV>
-__global__ __launch_bounds__(256) void ln_fwd_tp3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// NW waves per workgroup: 16 (two rows per wave in phase 1) keeps ~31 waves per CU in flight at 495 row blocks; with 4 the
+// kernel ran at 8 waves per CU and a third of the HBM rate.
+template <int LN_MAXV, int NW>
+__global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, unsigned char* __restrict__ out,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows, int cols,
                                                          float eps) {
@@ -171,8 +173,8 @@ __global__ __launch_bounds__(256) void ln_fwd_tp3_kernel(const float* __restrict
     const long rb = blockIdx.x;
     const float inv_n = 1.0f / (float)cols;
     const int nv = cols >> 2;
-    for (int rr = 0; rr < 8; ++rr) {
-        const int rl = wave * 8 + rr;
+    for (int rr = 0; rr < 32 / NW; ++rr) {
+        const int rl = wave * (32 / NW) + rr;
         const long row = rb * 32 + rl;
         float mean = 0.f, rstd = 0.f;
         if (row < rows) {
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void ln_fwd_tp3_kernel(const float* __restrict
     const float mean = s_mean[r], rstd = s_rstd[r];
     const int KB = cols >> 4;
     const float* xr = x + (live ? row : 0) * cols;
-    for (int kb = wave; kb < KB; kb += 4) {
+    for (int kb = wave; kb < KB; kb += NW) {
         const int c0 = kb * 16 + h * 8;
         float v[8];
         const float4 a = *reinterpret_cast<const float4*>(xr + c0), b = *reinterpret_cast<const float4*>(xr + c0 + 4);
@@ -238,8 +240,8 @@ __global__ __launch_bounds__(256) void ln_fwd_tp3_kernel(const float* __restrict
 // LayerNorm backward (+ residual gradient) writing dx twice: fp32 (the residual stream's gradient, read by the next
 // LayerNorm backward) and tp3 (the A operand of the next data-gradient GEMM).  Phase 1 = ln_bwd_kernel's row pass; phase 2
 // re-reads the block's fresh dx rows (this CU's own stores, drained and fenced) in fragment order.
-template <int LN_MAXV>
-__global__ __launch_bounds__(256) void ln_bwd_tp3_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+template <int LN_MAXV, int NW>
+__global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const float* __restrict__ dres, float* __restrict__ dx, unsigned char* __restrict__ out,
                                                          long rows, int cols) {
@@ -247,8 +249,8 @@ __global__ __launch_bounds__(256) void ln_bwd_tp3_kernel(const float* __restrict
     const long rb = blockIdx.x;
     const float inv_n = 1.0f / (float)cols;
     const int nv = cols >> 2;
-    for (int rr = 0; rr < 8; ++rr) {
-        const long row = rb * 32 + wave * 8 + rr;
+    for (int rr = 0; rr < 32 / NW; ++rr) {
+        const long row = rb * 32 + wave * (32 / NW) + rr;
         if (row >= rows) break;
         const float* xr = x + row * cols;
         const float* dyr = dy + row * cols;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void ln_bwd_tp3_kernel(const float* __restrict
     const bool live = row < rows;
     const int KB = cols >> 4;
     const float* dxr = dx + (live ? row : 0) * cols;
-    for (int kb = wave; kb < KB; kb += 4) {
+    for (int kb = wave; kb < KB; kb += NW) {
         const int c0 = kb * 16 + h * 8;
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dxr + c0));  // past this CU's L1
@@ -357,8 +359,8 @@ extern "C" int tvl_layernorm_fwd_tp3(const float* x, const float* gamma, const f
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(y_tp3);
-    if (cols <= 1024) hipLaunchKernelGGL(ln_fwd_tp3_kernel<4>, dim3(grid), dim3(256), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps);
-    else hipLaunchKernelGGL(ln_fwd_tp3_kernel<8>, dim3(grid), dim3(256), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps);
+    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps);
     TVL_LAUNCH_CHECK("tvl_layernorm_fwd_tp3");
     return 0;
 }
@@ -372,8 +374,8 @@ extern "C" int tvl_layernorm_bwd_tp3(const float* dy, const float* x, const floa
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(dx_tp3);
-    if (cols <= 1024) hipLaunchKernelGGL(ln_bwd_tp3_kernel<4>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols);
-    else hipLaunchKernelGGL(ln_bwd_tp3_kernel<8>, dim3(grid), dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols);
+    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols);
     TVL_LAUNCH_CHECK("tvl_layernorm_bwd_tp3");
     return 0;
 }
