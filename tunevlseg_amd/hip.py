@@ -380,8 +380,23 @@ def gemm_tp3(A: Tp3, B: Tp3, *, M: int | None = None, out: torch.Tensor | None =
     _call("tvl_gemm_tp3", C.byref(args))
     if _gemm_prof is not None:
         e1.record()
-        _gemm_prof.append((f"gemm_tp3_kernel<{tp3_tile(M, N)}, 256, {GEMM_TP3_VARIANT}>", 2.0 * M * N * K, e0, e1))
+        _gemm_prof.append((tp3_kernel_name(M, N, bias is not None, residual is not None, act, dact, pre_out is not None, Cf is not None,
+                                           Ct is not None, alpha), 2.0 * M * N * K, e0, e1))
     return Cf, Ct
+
+
+_TP3_EPI_BUILT = {32, 33, 35, 85, 69, 72}   # launch_epi's compile-time epilogues (csrc/gemm_tp3_kernel.h); anything else runs the generic -1
+
+
+def tp3_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, alpha=1.0) -> str:
+    """Instantiation tvl_gemm_tp3 launches for a call, spelled as rocprofv3 prints it (bench.py matches profiles/ by this name)."""
+    tile = tp3_tile(M, N)
+    variant = GEMM_TP3_VARIANT or (2 if tile == 256 else 3)
+    epi = (1 if bias else 0) | (2 if residual else 0) | (4 if (act & 0xFF) else 0) | (8 if dact else 0) | (16 if pre_out else 0) | \
+          (32 if c_f32 else 0) | (64 if c_tp3 else 0)
+    if alpha != 1.0 or (act & ~0xFF) or epi not in _TP3_EPI_BUILT:
+        epi = -1
+    return f"gemm_tp3_kernel<{tile}, 256, {variant}, {epi}>"
 
 
 def tp3_tile(M: int, N: int) -> int:
