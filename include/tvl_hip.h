@@ -128,6 +128,12 @@ int tvl_attn_fwd_tp3(const tvlAttnFwdArgs* a, void* o_tp3, tvlStream_t stream);
 /* The same attention with Q, K, V read from the tp3 image of the packed QKV matrix [B*T, 3*H*64] (written by the QKV GEMM's
  * epilogue): key tiles are filled by LDS-DMA, nothing is split in the kernel.  lse [B,H,T] may be NULL. */
 int tvl_attn_tp3_fwd(const void* qkv_tp3, void* o_tp3, float* lse, int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream);
+/* Backward of tvl_attn_tp3_fwd on tp3 operands: packed QKV, O (the forward's output) and dO (tp3 image of [B*T, H*64], e.g. the
+ * out-projection data gradient written by tvl_gemm_tp3 with C_tp3); lse from the forward; delta: [B, H, T] fp32 workspace.
+ * Writes dQ | dK | dV as the tp3 image of the packed gradient [B*T, 3*H*64] (rows beyond B*T of the last block are not touched).
+ * Replaces autograd through HF CLIPSegAttention (modeling_clipseg.py:232-252) for the vision tower, as tvl_attn_bwd_tp3 does. */
+int tvl_attn_tp3_bwd(const void* qkv_tp3, const void* o_tp3, const void* do_tp3, const float* lse, float* delta, void* dqkv_tp3,
+                     int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream);
 /* diagnostics (tools/bench_attn.py): ablation variants / per-workgroup clock stamps; outputs of variants != 0, 16 are wrong by construction */
 int tvl_attn_tp3_fwd_diag(const void* qkv_tp3, void* o_tp3, float* lse, int32_t B, int32_t H, int32_t T, float scale, int32_t variant,
                           int64_t* stamps, tvlStream_t stream);

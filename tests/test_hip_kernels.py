@@ -531,3 +531,17 @@ def test_attention_on_tp3_qkv(hip, B, T, H):
     o, lse = hip.attn_tp3_fwd(hip.tp3_pack(qkv), B, T, H, dh**-0.5)
     close(o.float(), o_ref, 2e-6, "attn tp3 fwd O")
     close(lse, lse_ref, 1e-6, "attn tp3 fwd lse")
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 495, 12), (3, 100, 2), (1, 33, 1), (4, 64, 3), (2, 485, 12)])
+def test_attention_backward_on_tp3_operands(hip, B, T, H):
+    """dQ | dK | dV from tp3 images of QKV, O and dO (query / key tiles aligned to the images' row blocks, neighbouring samples'
+    rows masked, delta formed from the pieces) against the fp32-input backward kernels: same piece arithmetic, different tiling."""
+    dh, D = 64, H * 64
+    qkv = dev(rnd(B * T, 3 * D, seed=2))
+    d_o = dev(rnd(B * T, D, seed=3))
+    o_t, lse = hip.attn_fwd_packed_tp3(qkv, B, T, H, dh, dh**-0.5)
+    ref = hip.attn_bwd_packed_tp3(qkv, o_t, d_o, lse, B, T, H, dh, dh**-0.5).float()
+    got = hip.attn_tp3_bwd(hip.tp3_pack(qkv), o_t, hip.tp3_pack(d_o), lse, B, T, H, dh**-0.5).float()
+    for name, c0 in (("dQ", 0), ("dK", D), ("dV", 2 * D)):
+        close(got[:, c0:c0 + D], ref[:, c0:c0 + D], 5e-6, f"attn tp3 bwd {name}")

@@ -35,6 +35,10 @@ def main():
     qkv_t = hip.tp3_pack(qkv)
     tf3 = timeit(lambda: hip.attn_tp3_fwd(qkv_t, B, T, H, dh ** -0.5))
     print(f"fwd on the tp3 QKV image (LDS-DMA key tiles): {tf3*1e3:.1f} us  {fl/tf3/1e9:.1f} TF/s")
+    o_t, lse_t = hip.attn_tp3_fwd(qkv_t, B, T, H, dh ** -0.5)
+    do_t = hip.tp3_pack(d_o)
+    tb3 = timeit(lambda: hip.attn_tp3_bwd(qkv_t, o_t, do_t, lse_t, B, T, H, dh ** -0.5))
+    print(f"bwd on tp3 QKV / O / dO images (dQ kernel incl. delta + dK/dV kernel): {tb3*1e3:.1f} us  {2.5*fl/tb3/1e9:.1f} TF/s")
     if "--diag" in sys.argv:
         o3 = hip.Tp3(B * T, D, qkv.device)
         lse3 = torch.empty(B, H, T, device="cuda")

@@ -19,6 +19,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -264,6 +265,276 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void attn_fwd_tp3_kernel(FwdP p) {
     }
 }
 
+// ---- backward -------------------------------------------------------------------------------------------------------------
+// Same arithmetic as attn_bwd_dq / dkdv_bf16s_kernel (attention_bf16s.hip): P is recomputed from Q, K and the forward's log-sum-exp,
+// dS = P o (dP - delta), every product is the 6-MFMA piece sum.  Operands arrive as tp3 images: packed QKV [B*T, 3*H*64] (the QKV
+// GEMM's epilogue), O (the forward) and dO (the out-projection data gradient's epilogue); dQ | dK | dV leave as the tp3 image of the
+// packed gradient, the A operand of the QKV data-gradient GEMM.  Nothing is re-split per workgroup and tiles are filled by LDS-DMA.
+struct BwdP {
+    const unsigned char* qkv; int kb;     // tp3 image of packed QKV; kb = 3*H*64/16
+    const unsigned char* o_img;           // tp3 image of O  [B*T, H*64]
+    const unsigned char* do_img; int o_kb;   // tp3 image of dO [B*T, H*64]; o_kb = H*64/16
+    const float* lse;                     // [B, H, T] from the forward
+    float* delta;                         // [B, H, T]: written by the dQ kernel (delta = sum_d dO * O), read by the dK/dV kernel
+    unsigned char* g_img;                 // tp3 image of dQ | dK | dV [B*T, 3*H*64]
+    int B, H, T; float scale;
+};
+
+// transposed fragments out of a piece in the image's own layout (32 rows x 16 k, element (row, k) at (k / 8) * 512 + row * 16 + (k % 8) * 2):
+// {piece 0 lo, hi, piece 1 lo, hi, piece 2 lo, hi} of one 16-row step of a 32-k block; "hi" = rows + 8
+template <int OFF>
+__device__ __forceinline__ void read_t(u32x2 (&f)[6], unsigned a) {
+    f[0] = lds_tr<OFF>(a); f[1] = lds_tr<OFF + 128>(a); f[2] = lds_tr<OFF + PIECE>(a); f[3] = lds_tr<OFF + PIECE + 128>(a);
+    f[4] = lds_tr<OFF + 2 * PIECE>(a); f[5] = lds_tr<OFF + 2 * PIECE + 128>(a);
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_f4(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ void glds4(const void* g, unsigned lds_byte) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(size_t)lds_byte, 4, 0, 0);
+}
+__device__ __forceinline__ void pieces_of(float (&x)[16], bf16x8 (&f0)[3], bf16x8 (&f1)[3]) {
+    unsigned p0[8], p1[8], p2[8];
+    split3<16>(x, p0, p1, p2);
+    f0[0] = frag_of(p0[0], p0[1], p0[2], p0[3]); f0[1] = frag_of(p1[0], p1[1], p1[2], p1[3]); f0[2] = frag_of(p2[0], p2[1], p2[2], p2[3]);
+    f1[0] = frag_of(p0[4], p0[5], p0[6], p0[7]); f1[1] = frag_of(p1[4], p1[5], p1[6], p1[7]); f1[2] = frag_of(p2[4], p2[5], p2[6], p2[7]);
+}
+// A . B accumulated over the four 16-k steps of d_h = 64: A fragments double-buffered out of LDS (piece blocks BLK apart), B in registers
+__device__ __forceinline__ f32x16 mma_rows(unsigned a_rd, const bf16x8 (&bq)[4][3], const f32x16& zero) {
+    bf16x8 ka[3], kb[3];
+    read_k<0>(ka, a_rd); read_k<BLK>(kb, a_rd);
+    wait_k<3>(ka); f32x16 acc = mma6(ka, bq[0], zero);
+    read_k<2 * BLK>(ka, a_rd); wait_k<3>(kb); acc = mma6(kb, bq[1], acc);
+    read_k<3 * BLK>(kb, a_rd); wait_k<3>(ka); acc = mma6(ka, bq[2], acc);
+    wait_k<0>(kb); acc = mma6(kb, bq[3], acc);
+    return acc;
+}
+// acc[d] += T^T . X for both 32-column blocks d of a 32-row tile T (transposed reads at t_rd), X = the piece fragments of a 32 x 32
+// accumulator-layout matrix (rows 0-15 / 16-31)
+__device__ __forceinline__ void mma_cols(unsigned t_rd, const bf16x8 (&x0)[3], const bf16x8 (&x1)[3], f32x16 (&acc)[2]) {
+    u32x2 va[6], vb[6];
+    read_t<0>(va, t_rd); read_t<0>(vb, t_rd + 256);
+    wait_v<6>(va); acc[0] = mma6_v(va, x0, acc[0]);
+    read_t<2 * BLK>(va, t_rd); wait_v<6>(vb); acc[0] = mma6_v(vb, x1, acc[0]);
+    read_t<2 * BLK>(vb, t_rd + 256); wait_v<6>(va); acc[1] = mma6_v(va, x0, acc[1]);
+    wait_v<0>(vb); acc[1] = mma6_v(vb, x1, acc[1]);
+}
+
+constexpr int BWD_STAGE = 24 * PIECE + 256;   // two 12-piece tiles + 64 floats (log-sum-exp | delta of a query tile; dK/dV kernel only)
+constexpr int BWD_LDS = 2 * BWD_STAGE;
+
+// virtual workgroup id: blocks of one (sample, head) consecutive inside one XCD's share of the grid (as in the forward)
+__device__ __forceinline__ int xcd_vid() {
+    const int total = (int)gridDim.x, L = (int)blockIdx.x, per = total / 8;
+    return L < per * 8 ? (L % 8) * per + L / 8 : L;
+}
+
+// dQ: query-stationary.  Per key tile: S^T = K.Q^T, dP^T = V.dO^T (K, V fragments straight out of the DMA image), dS^T on the
+// accumulators, dQ^T += K^T . dS^T (K^T by transposed reads of the same K pieces).  Also writes delta for the dK/dV kernel.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_tp3_kernel(BwdP p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int T = p.T, D = p.H * DH;
+    const int nqb = (T + 127) / 128;
+    const int vid = xcd_vid();
+    const int qb = vid % nqb, head = (vid / nqb) % p.H, b = vid / (nqb * p.H);
+    const int qi = qb * 128 + wave * 32 + l31;
+    const int qrow = qi < T ? qi : T - 1;
+    const long m_q = (long)b * T + qrow;
+
+    bf16x8 qf[4][3], dof[4][3];
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        row_frags(p.qkv, p.kb, m_q, head * 4 + s, h, qf[s]);
+        row_frags(p.do_img, p.o_kb, m_q, head * 4 + s, h, dof[s]);
+        bf16x8 of[3];
+        row_frags(p.o_img, p.o_kb, m_q, head * 4 + s, h, of);
+        const uint4 a[3] = {__builtin_bit_cast(uint4, dof[s][0]), __builtin_bit_cast(uint4, dof[s][1]), __builtin_bit_cast(uint4, dof[s][2])};
+        const uint4 c[3] = {__builtin_bit_cast(uint4, of[0]), __builtin_bit_cast(uint4, of[1]), __builtin_bit_cast(uint4, of[2])};
+        float x[8], y[8];
+        tp3::join8(a, x);
+        tp3::join8(c, y);
+        dl += (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]) + (x[4] * y[4] + x[5] * y[5]) + (x[6] * y[6] + x[7] * y[7]);
+    }
+    dl += __shfl_xor(dl, 32, 64);   // the two lane halves hold the two 8-column halves of every 16-column step
+    const long stat = ((long)b * p.H + head) * T + qrow;
+    if (h == 0 && qi < T) p.delta[stat] = dl;
+    const float sc2 = p.scale * LOG2E;
+    const float nlse2 = -p.lse[stat] * LOG2E;
+
+    f32x16 acc_dq[2], zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_dq[0][r] = 0.f; acc_dq[1][r] = 0.f; zero[r] = 0.f; }
+
+    const long row_lo = (long)b * T, row_hi = row_lo + T;
+    const int rb_lo = (int)(row_lo >> 5);
+    const int nkt = (int)((row_hi - 1) >> 5) - rb_lo + 1;
+    const int lo_in_blk = (int)(row_lo & 31);
+    const unsigned char* k_src = p.qkv + ((long)rb_lo * p.kb + (D + head * DH) / 16) * BLK + lane * 16;
+    const unsigned char* v_src = p.qkv + ((long)rb_lo * p.kb + (2 * D + head * DH) / 16) * BLK + lane * 16;
+    const long tile_stride = (long)p.kb * BLK;
+    auto issue = [&](int kt) {
+        const unsigned dst = lds0 + (kt & 1) * BWD_STAGE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pc = wave + 4 * i;
+            glds16(k_src + kt * tile_stride + pc * PIECE, dst + pc * PIECE);
+            glds16(v_src + kt * tile_stride + pc * PIECE, dst + (12 + pc) * PIECE);
+        }
+    };
+    const int li = lane & 15, g1 = (lane >> 4) & 1;
+    const unsigned tr_off = ((li & 3) >> 1) * 512 + (4 * h + (li >> 2)) * 16 + (li & 1) * 8 + g1 * BLK;
+
+    issue(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nkt) issue(kt + 1);
+        const unsigned st = lds0 + (kt & 1) * BWD_STAGE;
+        f32x16 sc = mma_rows(st + lane * 16, qf, zero);                  // S^T  [key (register), query (lane)]
+        f32x16 dp = mma_rows(st + 12 * PIECE + lane * 16, dof, zero);    // dP^T
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], sc2, nlse2)) * (dp[r] - dl);
+        if (kt == 0 || kt == nkt - 1) {   // a neighbour sample's keys share the first / last row block
+            const int key0 = 32 * kt + 4 * h - lo_in_blk;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2);
+                ds[r] = (key >= 0 && key < T) ? ds[r] : 0.f;
+            }
+        }
+        bf16x8 x0[3], x1[3];
+        pieces_of(ds, x0, x1);
+        mma_cols(st + tr_off, x0, x1, acc_dq);                           // dQ^T += K^T . dS^T
+    }
+    if (qi < T) {
+        const long m = (long)b * T + qi;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float v[4] = {acc_dq[d][4 * g] * p.scale, acc_dq[d][4 * g + 1] * p.scale, acc_dq[d][4 * g + 2] * p.scale,
+                                    acc_dq[d][4 * g + 3] * p.scale};
+                tp3::store4(p.g_img, p.kb, m, head * DH + d * 32 + 8 * g + 4 * h, v);
+            }
+    }
+}
+
+// dK, dV: key-stationary (K, V fragments of the wave's 32 keys in registers).  Per query tile (a 32-row block of the images):
+// S = Q.K^T, dP = dO.V^T (Q, dO fragments straight out of the DMA image; query on the register, key on the lane),
+// dV^T += dO^T . P, dK^T += Q^T . dS (transposed reads of the same pieces).
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_tp3_kernel(BwdP p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int T = p.T, D = p.H * DH;
+    const int nkb = (T + 127) / 128;
+    const int vid = xcd_vid();
+    const int kblk = vid % nkb, head = (vid / nkb) % p.H, b = vid / (nkb * p.H);
+    const int ki = kblk * 128 + wave * 32 + l31;
+    const bool key_ok = ki < T;
+    const long m_k = (long)b * T + (key_ok ? ki : T - 1);
+
+    bf16x8 kf[4][3], vf[4][3];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        row_frags(p.qkv, p.kb, m_k, (D + head * DH) / 16 + s, h, kf[s]);
+        row_frags(p.qkv, p.kb, m_k, (2 * D + head * DH) / 16 + s, h, vf[s]);
+    }
+    f32x16 acc_dk[2], acc_dv[2], zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_dk[0][r] = 0.f; acc_dk[1][r] = 0.f; acc_dv[0][r] = 0.f; acc_dv[1][r] = 0.f; zero[r] = 0.f; }
+    const float sc2 = p.scale * LOG2E;
+
+    const long row_lo = (long)b * T, row_hi = row_lo + T;
+    const int rb_lo = (int)(row_lo >> 5);
+    const int nqt = (int)((row_hi - 1) >> 5) - rb_lo + 1;
+    const int lo_in_blk = (int)(row_lo & 31);
+    const unsigned char* q_src = p.qkv + ((long)rb_lo * p.kb + (head * DH) / 16) * BLK + lane * 16;
+    const unsigned char* d_src = p.do_img + ((long)rb_lo * p.o_kb + (head * DH) / 16) * BLK + lane * 16;
+    const long q_stride = (long)p.kb * BLK, d_stride = (long)p.o_kb * BLK;
+    const float* stat_base = (lane < 32 ? p.lse : p.delta) + ((long)b * p.H + head) * T;
+    auto issue = [&](int qt) {
+        const unsigned dst = lds0 + (qt & 1) * BWD_STAGE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pc = wave + 4 * i;
+            glds16(q_src + qt * q_stride + pc * PIECE, dst + pc * PIECE);
+            glds16(d_src + qt * d_stride + pc * PIECE, dst + (12 + pc) * PIECE);
+        }
+        if (wave == 0) {   // lanes 0-31: log-sum-exp of the tile's 32 queries, lanes 32-63: their delta (clamped inside the sample)
+            int q = 32 * qt + l31 - lo_in_blk;
+            q = q < 0 ? 0 : (q < T ? q : T - 1);
+            glds4(stat_base + q, dst + 24 * PIECE);
+        }
+    };
+    const int li = lane & 15, g1 = (lane >> 4) & 1;
+    const unsigned tr_off = ((li & 3) >> 1) * 512 + (4 * h + (li >> 2)) * 16 + (li & 1) * 8 + g1 * BLK;
+
+    issue(0);
+    for (int qt = 0; qt < nqt; ++qt) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (qt + 1 < nqt) issue(qt + 1);
+        const unsigned st = lds0 + (qt & 1) * BWD_STAGE;
+        f32x16 sc = mma_rows(st + lane * 16, kf, zero);                  // S   [query (register), key (lane)]
+        f32x16 dp = mma_rows(st + 12 * PIECE + lane * 16, vf, zero);     // dP
+        // rows of S / dP are the tile's queries (r & 3) + 8 (r >> 2) + 4 h: their statistics come as four float4 each
+        f32x4 l4[4], d4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) l4[g] = lds_f4<0>(st + 24 * PIECE + (8 * g + 4 * h) * 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) d4[g] = lds_f4<128>(st + 24 * PIECE + (8 * g + 4 * h) * 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l4[0]), "+v"(l4[1]), "+v"(l4[2]), "+v"(l4[3]), "+v"(d4[0]), "+v"(d4[1]), "+v"(d4[2]), "+v"(d4[3]));
+        float pv[16], dsv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pv[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], sc2, -LOG2E * l4[r >> 2][r & 3]));
+            dsv[r] = pv[r] * (dp[r] - d4[r >> 2][r & 3]);
+        }
+        if (qt == 0 || qt == nqt - 1 || !key_ok) {   // a neighbour sample's queries share the first / last row block
+            const int q0 = 32 * qt + 4 * h - lo_in_blk;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = q0 + (r & 3) + 8 * (r >> 2);
+                const bool ok = key_ok && q >= 0 && q < T;
+                pv[r] = ok ? pv[r] : 0.f;
+                dsv[r] = ok ? dsv[r] : 0.f;
+            }
+        }
+        bf16x8 x0[3], x1[3];
+        pieces_of(pv, x0, x1);
+        mma_cols(st + 12 * PIECE + tr_off, x0, x1, acc_dv);              // dV^T += dO^T . P
+        pieces_of(dsv, x0, x1);
+        mma_cols(st + tr_off, x0, x1, acc_dk);                           // dK^T += Q^T . dS
+    }
+    if (key_ok) {
+        const long m = (long)b * T + ki;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = head * DH + d * 32 + 8 * g + 4 * h;
+                const float vk[4] = {acc_dk[d][4 * g] * p.scale, acc_dk[d][4 * g + 1] * p.scale, acc_dk[d][4 * g + 2] * p.scale,
+                                     acc_dk[d][4 * g + 3] * p.scale};
+                const float vv[4] = {acc_dv[d][4 * g], acc_dv[d][4 * g + 1], acc_dv[d][4 * g + 2], acc_dv[d][4 * g + 3]};
+                tp3::store4(p.g_img, p.kb, m, D + col, vk);
+                tp3::store4(p.g_img, p.kb, m, 2 * D + col, vv);
+            }
+    }
+}
+
 }  // namespace
 
 static int attn_tp3_fwd_launch(const void* qkv_tp3, void* o_tp3, float* lse, int32_t B, int32_t H, int32_t T, float scale, int variant,
@@ -297,4 +568,25 @@ extern "C" int tvl_attn_tp3_fwd(const void* qkv_tp3, void* o_tp3, float* lse, in
 extern "C" int tvl_attn_tp3_fwd_diag(const void* qkv_tp3, void* o_tp3, float* lse, int32_t B, int32_t H, int32_t T, float scale, int32_t variant,
                                      int64_t* stamps, tvlStream_t stream) {
     return attn_tp3_fwd_launch(qkv_tp3, o_tp3, lse, B, H, T, scale, variant, reinterpret_cast<long long*>(stamps), stream);
+}
+
+// Backward of tvl_attn_tp3_fwd: dQ | dK | dV as the tp3 image of the packed gradient.  delta is a [B, H, T] fp32 workspace.
+extern "C" int tvl_attn_tp3_bwd(const void* qkv_tp3, const void* o_tp3, const void* do_tp3, const float* lse, float* delta, void* dqkv_tp3,
+                                int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream) {
+    TVL_REQUIRE(qkv_tp3 && o_tp3 && do_tp3 && lse && delta && dqkv_tp3, "tvl_attn_tp3_bwd: null pointer");
+    TVL_REQUIRE(B > 0 && H > 0 && T > 0, "tvl_attn_tp3_bwd: bad shape");
+    TVL_REQUIRE(tvl_aligned16(qkv_tp3) && tvl_aligned16(o_tp3) && tvl_aligned16(do_tp3) && tvl_aligned16(dqkv_tp3),
+                "tvl_attn_tp3_bwd: tp3 images must be 16-byte aligned");
+    TVL_REQUIRE((long)((T + 127) / 128) * H * B < (1L << 31), "tvl_attn_tp3_bwd: grid too large");
+    BwdP p;
+    p.qkv = reinterpret_cast<const unsigned char*>(qkv_tp3); p.kb = 3 * H * DH / 16;
+    p.o_img = reinterpret_cast<const unsigned char*>(o_tp3); p.do_img = reinterpret_cast<const unsigned char*>(do_tp3); p.o_kb = H * DH / 16;
+    p.lse = lse; p.delta = delta; p.g_img = reinterpret_cast<unsigned char*>(dqkv_tp3);
+    p.B = B; p.H = H; p.T = T; p.scale = scale;
+    dim3 grid((unsigned)((T + 127) / 128 * H * B));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(attn_bwd_dq_tp3_kernel, grid, dim3(256), BWD_LDS, s, p);      // also writes delta ...
+    hipLaunchKernelGGL(attn_bwd_dkdv_tp3_kernel, grid, dim3(256), BWD_LDS, s, p);    // ... which this one reads (same stream)
+    TVL_LAUNCH_CHECK("tvl_attn_tp3_bwd");
+    return 0;
 }

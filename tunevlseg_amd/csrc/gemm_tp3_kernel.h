@@ -385,6 +385,8 @@ int launch_epi(const Tp3Params& p, int epi, hipStream_t s) {
         case E_BIAS | E_QGELU | E_PRE | E_TP3: return launch<BM, 256, VARIANT, E_BIAS | E_QGELU | E_PRE | E_TP3>(p, s);   // fc1 (training)
         case E_BIAS | E_QGELU | E_TP3: return launch<BM, 256, VARIANT, E_BIAS | E_QGELU | E_TP3>(p, s);     // fc1 (no tape)
         case E_DQGELU | E_TP3: return launch<BM, 256, VARIANT, E_DQGELU | E_TP3>(p, s);                     // dz of the backward
+        case E_BIAS | E_TP3: return launch<BM, 256, VARIANT, E_BIAS | E_TP3>(p, s);                         // qkv for the tp3 attention
+        case E_TP3: return launch<BM, 256, VARIANT, E_TP3>(p, s);                                           // dO for the tp3 attention
         default: return launch<BM, 256, VARIANT, -1>(p, s);
     }
 }

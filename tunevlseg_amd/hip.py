@@ -143,6 +143,7 @@ _SIGS = {
     "tvl_attn_bwd_tp3": [C.POINTER(AttnBwdArgs), _P, _P],
     "tvl_attn_tp3_fwd": [_P, _P, _P, _I, _I, _I, _F],
     "tvl_attn_tp3_fwd_diag": [_P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "tvl_attn_tp3_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "tvl_tp3_pack": [_P, _L, _L, _I, _P],
     "tvl_tp3_unpack": [_P, _L, _I, _P, _L],
     "tvl_gemm_tp3": [C.POINTER(GemmTp3Args)],
@@ -385,7 +386,7 @@ def gemm_tp3(A: Tp3, B: Tp3, *, M: int | None = None, out: torch.Tensor | None =
     return Cf, Ct
 
 
-_TP3_EPI_BUILT = {32, 33, 35, 85, 69, 72}   # launch_epi's compile-time epilogues (csrc/gemm_tp3_kernel.h); anything else runs the generic -1
+_TP3_EPI_BUILT = {32, 33, 35, 85, 69, 72, 64, 65}   # launch_epi's compile-time epilogues (csrc/gemm_tp3_kernel.h); anything else runs the generic -1
 
 
 def tp3_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, alpha=1.0) -> str:
@@ -520,6 +521,7 @@ def layernorm_bwd_tp3(dy2d, x2d, gamma, mean, rstd, dres=None):
     return dx, dxt
 
 
+ATTN_TP3 = os.environ.get("TVL_ATTN_TP3", "1") != "0"   # 0: attention of the tp3 layers on the fp32-operand kernels (A/B switch)
 TP3_MIN_ROWS = int(os.environ.get("TVL_TP3_MIN_ROWS", "1024"))  # below this the layer is launch-latency bound either way
 
 
@@ -554,6 +556,18 @@ def attn_tp3_fwd(qkv_t: Tp3, B: int, T: int, H: int, scale: float, want_lse=True
     lse = torch.empty((B, H, T), device=qkv_t.buf.device, dtype=torch.float32) if want_lse else None
     _call("tvl_attn_tp3_fwd", qkv_t.buf.data_ptr(), o.buf.data_ptr(), _p(lse), B, H, T, float(scale))
     return o, lse
+
+
+def attn_tp3_bwd(qkv_t: Tp3, o_t: Tp3, do_t: Tp3, lse, B: int, T: int, H: int, scale: float) -> Tp3:
+    """Backward of attn_tp3_fwd, all operands tp3 images: returns dQ | dK | dV as the Tp3 image of the packed gradient [B*T, 3*H*64]."""
+    D = H * 64
+    for name, t, cols in (("QKV", qkv_t, 3 * D), ("O", o_t, D), ("dO", do_t, D)):
+        if t.rows != B * T or t.cols != cols:
+            raise RuntimeError(f"attn_tp3_bwd: {name} image is {t.shape}, expected {(B * T, cols)}")
+    g = Tp3(B * T, 3 * D, qkv_t.buf.device)
+    delta = torch.empty((B, H, T), device=qkv_t.buf.device, dtype=torch.float32)
+    _call("tvl_attn_tp3_bwd", qkv_t.buf.data_ptr(), o_t.buf.data_ptr(), do_t.buf.data_ptr(), _p(lse), _p(delta), g.buf.data_ptr(), B, H, T, float(scale))
+    return g
 
 
 def attn_bwd_packed_tp3(qkv, o_tp3: Tp3, d_o, lse, B: int, T: int, H: int, dh: int, scale: float) -> Tp3:

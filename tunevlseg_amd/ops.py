@@ -90,9 +90,14 @@ class EncoderLayerTp3Fn(Fn):
         W = lw.tp3()
         h2d = h.view(M, D)
         x1, mean1, rstd1 = hip.layernorm_fwd_tp3(h2d, lw.ln1_w, lw.ln1_b, spec.eps, want_stats=need)
-        qkv, _ = hip.gemm_tp3(x1, W["wqkv"], bias=lw.bqkv)
+        if hip.ATTN_TP3:   # Q | K | V never exist in fp32: the attention kernels read the GEMM epilogue's tp3 image by LDS-DMA
+            _, qkv_t = hip.gemm_tp3(x1, W["wqkv"], want_f32=False, want_tp3=True, bias=lw.bqkv)
+            o, lse = hip.attn_tp3_fwd(qkv_t, B, T, H, dh**-0.5, want_lse=need)
+            qkv = qkv_t.buf
+        else:
+            qkv, _ = hip.gemm_tp3(x1, W["wqkv"], bias=lw.bqkv)
+            o, lse = hip.attn_fwd_packed_tp3(qkv, B, T, H, dh, dh**-0.5, want_lse=need)
         del x1
-        o, lse = hip.attn_fwd_packed_tp3(qkv, B, T, H, dh, dh**-0.5, want_lse=need)
         h2, _ = hip.gemm_tp3(o, W["wo"], bias=lw.bo, residual=h2d)
         x2, mean2, rstd2 = hip.layernorm_fwd_tp3(h2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
         z = torch.empty((M, lw.w1.shape[0]), device=h.device, dtype=torch.float32) if need else None
@@ -121,10 +126,14 @@ class EncoderLayerTp3Fn(Fn):
         del dz
         dh2, dh2_t = hip.layernorm_bwd_tp3(dx2, h2, lw.ln2_w, mean2, rstd2, dres=dout2d)
         del dx2
-        do, _ = hip.gemm_tp3(dh2_t, W["wo_t"])
-        del dh2_t
-        dqkv = hip.attn_bwd_packed_tp3(qkv, hip.Tp3(M, D, o_buf.device, o_buf), do, lse, B, T, H, dh, dh**-0.5)
-        del do
+        o_t = hip.Tp3(M, D, o_buf.device, o_buf)
+        if hip.ATTN_TP3:
+            _, do = hip.gemm_tp3(dh2_t, W["wo_t"], want_f32=False, want_tp3=True)
+            dqkv = hip.attn_tp3_bwd(hip.Tp3(M, 3 * D, qkv.device, qkv), o_t, do, lse, B, T, H, dh**-0.5)
+        else:
+            do, _ = hip.gemm_tp3(dh2_t, W["wo_t"])
+            dqkv = hip.attn_bwd_packed_tp3(qkv, o_t, do, lse, B, T, H, dh, dh**-0.5)
+        del dh2_t, do
         dx1, _ = hip.gemm_tp3(dqkv, W["wqkv_t"])
         del dqkv
         dh_in, dh_in_t = hip.layernorm_bwd_tp3(dx1, h2d, lw.ln1_w, mean1, rstd1, dres=dh2)
