@@ -607,6 +607,12 @@ int launch_tile(int bm, const GemmParams& p, hipStream_t s) {
     if (bm == 192) bm = 96;  // the reduced-precision modes keep the three original tiles
     if (bm == 128) return launch<128, 128, 2, S, VEC>(p, s);
     if (bm == 96) return launch<96, 128, 1, S, VEC>(p, s);
+    // 64x64 tiles serve the launch-latency-bound problems (text tower, decoder: M = B*L rows): a k-step there is one exposed memory
+    // round trip (~1 us) around ~100 cycles of MFMA, so a 64-deep slab halves the kernel's duration; TVL_GEMM_SMALL_BK=32 restores it
+    static const int small_bk = getenv("TVL_GEMM_SMALL_BK") ? atoi(getenv("TVL_GEMM_SMALL_BK")) : 64;
+    if constexpr (S == 3) {
+        if (small_bk == 64) return launch_v<64, 64, 2, S, VEC, 64, 1>(p, s);
+    }
     return launch<64, 64, 2, S, VEC>(p, s);
 }
 
