@@ -48,9 +48,16 @@ def main():
         def diag(v):
             hip._call("tvl_attn_tp3_fwd_diag", qkv_t.buf.data_ptr(), o3.buf.data_ptr(), lse3.data_ptr(), B, H, T, dh ** -0.5, v, stamps.data_ptr())
 
-        for v, what in ((0, "product"), (1, "no DMA after the prologue")):
+        for v, what in ((0, "product"), (2, "no static priority"), (1, "no DMA after the prologue")):
             t = timeit(lambda: diag(v))
             print(f"  variant {v:2d} ({what}): {t*1e3:.1f} us")
+        for pv_ in (32, 34):
+            ph = torch.zeros(nwg, 5, dtype=torch.int64, device="cuda")
+            hip._call("tvl_attn_tp3_fwd_diag", qkv_t.buf.data_ptr(), o3.buf.data_ptr(), lse3.data_ptr(), B, H, T, dh ** -0.5, pv_, ph.data_ptr())
+            torch.cuda.synchronize()
+            m = ph.cpu().double().mean(0) / ((T + 31) // 32 + 1)
+            print(f"  phase cycles per tile, wave 0 of every workgroup (variant {pv_}{' = no static priority' if pv_ & 2 else ''}): barrier wait {m[0]:.0f}, "
+                  f"K reads + S MFMAs {m[1]:.0f}, softmax + split {m[2]:.0f}, P.V MFMAs {m[3]:.0f}, DMA issue + vm wait {m[4]:.0f}; sum {m.sum():.0f}")
         diag(16)
         torch.cuda.synchronize()
         raw = stamps.cpu()

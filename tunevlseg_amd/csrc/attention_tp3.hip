@@ -91,6 +91,12 @@ __device__ __forceinline__ void row_frags(const unsigned char* __restrict__ img,
     for (int p = 0; p < 3; ++p) out[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(src + p * PIECE));
 }
 
+// Two workgroups share a CU and their waves a SIMD.  With equal priority the co-resident waves fall into step (both in the MFMA
+// stretch, then both in the vector stretch) and the two stretches add.  Every second workgroup the dispatcher places on a CU -- it
+// deals one workgroup to each of an XCD's 32 CUs before the second -- therefore runs at a higher static priority: it takes the
+// matrix pipe whenever it wants it, its partner fills the gaps (MI355X_MICROARCH.md, 'Two waves per SIMD', items 2 and 4).
+__device__ __forceinline__ bool prio_of_workgroup() { return ((blockIdx.x >> 3) >> 5) & 1; }
+
 // counted LDS waits that carry the fragments they guard as "+v" operands: the MFMAs that consume those registers depend on the asm
 // and stay below it, while unrelated vector arithmetic remains free to move across (a sched_barrier would pin everything)
 template <int N>
@@ -128,7 +134,8 @@ constexpr int FWD_LDS = 2 * K_STAGE + 2 * V_STAGE;
 // the next tile's S^T issued ahead of this tile's softmax, or with two 4-wave halves held in anti-phase by barriers (5,650 cycles
 // per tile pair: every phase start exposes an LDS round trip).  The way on is a hand-placed stream with <= 5 vector instructions in
 // every MFMA gap (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'); hipcc's scheduler does not produce one around inline asm.
-// V = 0 is the product; 1 (no DMA after the prologue) and 16 (workgroup clock stamps) are diagnostics for tools/bench_attn.py.
+// V = 0 is the product; 1 (no DMA after the prologue), 2 (no static priority) and 16 (workgroup clock stamps) are diagnostics for
+// tools/bench_attn.py.
 constexpr int FWD_THREADS = 256, FWD_Q = 128;
 template <int V>
 __global__ __launch_bounds__(FWD_THREADS, 2) void attn_fwd_tp3_kernel(FwdP p) {
@@ -149,6 +156,9 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void attn_fwd_tp3_kernel(FwdP p) {
 
     long long t0 = 0, w0 = 0;
     if constexpr (V & 16) { t0 = __builtin_readcyclecounter(); w0 = wall_clock64(); }
+    if constexpr (!(V & 2)) {
+        if (prio_of_workgroup()) __builtin_amdgcn_s_setprio(2);
+    }
     bf16x8 qf[4][3];
 #pragma unroll
     for (int s = 0; s < 4; ++s) row_frags(p.qkv, p.kb, m_q, head * 4 + s, h, qf[s]);
@@ -185,10 +195,26 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void attn_fwd_tp3_kernel(FwdP p) {
     const unsigned tr_off = (4 * h + (li >> 2)) * 32 + (li & 3) * 8 + g1 * VCH;
     const unsigned k_rd = lds0 + lane * 16, v_rd = lds0 + 2 * K_STAGE + tr_off;
 
+    // variant 32: s_memtime at the phase boundaries of every tile, summed per wave (the value is consumed at once, so no scalar
+    // load is outstanding when the counted LDS waits run)
+    long long ph[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    auto mark = [&](int i) {
+        if constexpr (V & 32) {
+            __builtin_amdgcn_sched_barrier(0);
+            const long long now = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ph[i] += now - tprev;
+            tprev = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     issue(0);
+    if constexpr (V & 32) tprev = __builtin_readcyclecounter();
     for (int kt = 0; kt < nkt; ++kt) {
         wait_vm<0>();                       // this wave's pieces of tile kt have landed ...
+        mark(4);
         __builtin_amdgcn_s_barrier();       // ... and everybody's; everybody is also done reading the other stage (tile kt-1)
+        mark(0);
         if (kt + 1 < nkt && (!(V & 1) || kt < 1)) issue(kt + 1);
         const unsigned kb_ = k_rd + (kt & 1) * K_STAGE, vb_ = v_rd + (kt & 1) * V_STAGE;
         // ---- S^T = K . Q^T: fragments double-buffered in registers, counted LDS waits ----
@@ -199,6 +225,7 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void attn_fwd_tp3_kernel(FwdP p) {
         read_k<2 * BLK>(ka, kb_); wait_k<3>(kb); sc = mma6(kb, qf[1], sc);
         read_k<3 * BLK>(kb, kb_); wait_k<3>(ka); sc = mma6(ka, qf[2], sc);
         wait_k<0>(kb); sc = mma6(kb, qf[3], sc);
+        mark(1);
         // the first V^T fragments are requested now: they land underneath the softmax arithmetic
         u32x2 va[6], vb[6];
         read_v<0>(va, vb_); read_v<0>(vb, vb_ + 512);
@@ -235,10 +262,18 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void attn_fwd_tp3_kernel(FwdP p) {
         // ---- O^T += V^T . P^T ----
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc_o[0][r] *= alpha; acc_o[1][r] *= alpha; }
+        mark(2);
         wait_v<6>(va); acc_o[0] = mma6_v(va, pf0, acc_o[0]);
         read_v<2 * VCH>(va, vb_); wait_v<6>(vb); acc_o[0] = mma6_v(vb, pf1, acc_o[0]);
         read_v<2 * VCH>(vb, vb_ + 512); wait_v<6>(va); acc_o[1] = mma6_v(va, pf0, acc_o[1]);
         wait_v<0>(vb); acc_o[1] = mma6_v(vb, pf1, acc_o[1]);
+        mark(3);
+    }
+    if constexpr (V & 32) {
+        if (threadIdx.x == 0 && p.stamps) {
+            long long* o = p.stamps + 5L * blockIdx.x;
+            for (int i = 0; i < 5; ++i) o[i] = ph[i];
+        }
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -552,7 +587,10 @@ static int attn_tp3_fwd_launch(const void* qkv_tp3, void* o_tp3, float* lse, int
     switch (variant) {
         case 0: hipLaunchKernelGGL(attn_fwd_tp3_kernel<0>, grid, dim3(FWD_THREADS), FWD_LDS, s, p); break;
         case 1: hipLaunchKernelGGL(attn_fwd_tp3_kernel<1>, grid, dim3(FWD_THREADS), FWD_LDS, s, p); break;
+        case 2: hipLaunchKernelGGL(attn_fwd_tp3_kernel<2>, grid, dim3(FWD_THREADS), FWD_LDS, s, p); break;
         case 16: hipLaunchKernelGGL(attn_fwd_tp3_kernel<16>, grid, dim3(FWD_THREADS), FWD_LDS, s, p); break;
+        case 32: hipLaunchKernelGGL(attn_fwd_tp3_kernel<32>, grid, dim3(FWD_THREADS), FWD_LDS, s, p); break;
+        case 34: hipLaunchKernelGGL(attn_fwd_tp3_kernel<34>, grid, dim3(FWD_THREADS), FWD_LDS, s, p); break;
         default: TVL_REQUIRE(false, "tvl_attn_tp3_fwd: unknown variant %d", variant);
     }
     TVL_LAUNCH_CHECK("tvl_attn_tp3_fwd");

@@ -187,8 +187,7 @@ __device__ __forceinline__ void sstore(const StageRegs<ROWS, BK>& sr, __bf16* __
 }
 
 // One float4 of the epilogue (4 consecutive columns of one row), all operands 16-byte aligned and inside the matrix.
-template <bool POST>
-__device__ __forceinline__ void emit4(const GemmParams& p, long crow, int col, float4 a) {
+__device__ __forceinline__ void emit4(const GemmParams& p, bool post, long crow, int col, float4 a) {
     float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
     if (p.bias) {
         const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col);
@@ -199,16 +198,12 @@ __device__ __forceinline__ void emit4(const GemmParams& p, long crow, int col, f
         v[0] *= dact_f(z4.x, p.dact); v[1] *= dact_f(z4.y, p.dact); v[2] *= dact_f(z4.z, p.dact); v[3] *= dact_f(z4.w, p.dact);
     }
     if (p.pre_out) *reinterpret_cast<float4*>(p.pre_out + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-    if (POST && p.residual) {
-        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + crow * p.ldr + col);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-    }
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.residual) r4 = *reinterpret_cast<const float4*>(p.residual + crow * p.ldr + col);
+    if (post) { v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act & 0xff);
-    if (!POST && p.residual) {
-        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + crow * p.ldr + col);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-    }
+    if (!post) { v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
     *reinterpret_cast<float4*>(p.C + crow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
@@ -217,26 +212,29 @@ __device__ __forceinline__ void emit4(const GemmParams& p, long crow, int col, f
 // at fixed M, N has an intercept proportional to M*N).  Each 32x32 block therefore takes a round trip through a per-wave LDS
 // scratch (free after the k-loop's last barrier) and leaves as 8 rows x 128 contiguous bytes per instruction; the epilogue's own
 // loads (residual, activation-derivative operand) get the same mapping.
-template <int TM, int TN, bool POST>
-__device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], int row_base, int col_base, int lane, float* scratch) {
+// The loop over row groups is ROLLED and the option handling is run-time: the fully unrolled version (TM x TN x 4 copies of emit4,
+// twice for the two residual orders) is executed once per workgroup and arrived cold from the instruction cache -- on the tp3 kernel
+// the same structure cost 20 us per tile against 4 for this one (profiles/r2_gemm_experiments.md).
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_lds(const GemmParams& p, bool post, f32x16 (&acc)[TM][TN], int row_base, int col_base, int lane, float* scratch) {
     constexpr int LDS_ROW = 36;  // floats: 32 + 4 pad, ds_write_b128 of 8 consecutive rows hits 32 distinct banks
     const int l31 = lane & 31, h = lane >> 5;
     const int rr = lane >> 3, cc = (lane & 7) * 4;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(&scratch[l31 * LDS_ROW + 8 * g + 4 * h]) =
+                *reinterpret_cast<float4*>(&scratch[(i * 32 + l31) * LDS_ROW + 8 * g + 4 * h]) =
                     make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-            const int col = col_base + j * 32 + cc;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rl = 8 * q + rr;
+        const int col = col_base + j * 32 + cc;
+        if (col + 3 < p.N) {
+#pragma unroll 1
+            for (int rl = rr; rl < TM * 32; rl += 8) {
                 const float4 v = *reinterpret_cast<const float4*>(&scratch[rl * LDS_ROW + cc]);
-                const int row = row_base + i * 32 + rl;
-                if (row < p.M && col + 3 < p.N) emit4<POST>(p, map_row(row, p.c_map), col, v);
+                const int row = row_base + rl;
+                if (row < p.M) emit4(p, post, map_row(row, p.c_map), col, v);
             }
         }
     }
@@ -447,9 +445,8 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmParams& p) {
                          (!p.dact || (p.ld_aux % 4 == 0 && tvl_dev_aligned16(p.dact_aux))) && (!p.bias || tvl_dev_aligned16(p.bias));
     const bool post = (p.act & TVL_ACT_POST_RESIDUAL) != 0;
     if (aligned && n0 + BN <= p.N) {  // workgroup-uniform: LDS scratch is only touched on this path
-        float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
-        if (post) epilogue_lds<TM, TN, true>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, scratch);
-        else epilogue_lds<TM, TN, false>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, scratch);
+        float* scratch = reinterpret_cast<float*>(smem) + wave * (TM * 32 * 36);
+        epilogue_lds<TM, TN>(p, post, acc, m0 + wm * WM, n0 + wn * WN, lane, scratch);
     } else if (post) {
         epilogue_t<TM, TN, VEC, true>(p, acc, m0 + wm * WM, n0 + wn * WN, l31, h);
     } else {
@@ -576,7 +573,7 @@ int launch_v(const GemmParams& p0, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     constexpr size_t stage_bytes = (size_t)STAGES * S * (BM + BN) * (BK + 8) * sizeof(__bf16);
-    constexpr size_t epi_bytes = (size_t)NWAVES * 32 * 36 * sizeof(float);  // per-wave scratch of the coalesced epilogue
+    constexpr size_t epi_bytes = (size_t)NWAVES * (BM / WGM) * 36 * sizeof(float);  // per-wave scratch of the coalesced epilogue: its WM rows
     constexpr size_t smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static int attr_dev_mask = 0;  // the > 64 KiB dynamic-LDS opt-in is a per-device function attribute
     auto kern = gemm_bf16s_kernel<BM, BN, WGM, S, VEC, BK, STAGES, CONV>;
