@@ -100,7 +100,7 @@ def build_maple_module(device, seed: int = 0):
     return module, module.configure_optimizers()["optimizer"]
 
 
-def build_module(device, num_context: int = 10, prompt_depth: int = 1, seed: int = 0):
+def build_module(device, num_context: int = 10, prompt_depth: int = 1, seed: int = 0, cond_cache: bool = False):
     from tunevlseg_amd import nets
     from tunevlseg_amd.nets.context_learner import VPTContextLearner
     from tunevlseg_amd.task import DiceCELoss, FusedAdamW, ImageTextMaskModule
@@ -109,7 +109,8 @@ def build_module(device, num_context: int = 10, prompt_depth: int = 1, seed: int
     net = nets.VPTCLIPSeg(
         context_learner=partial(VPTContextLearner, prompt_depth=prompt_depth, num_context=num_context, vector_std=0.02),
         model_cfg={"pretrained_model_name_or_path": f"random:rd64:seed={seed}", "freeze_encoder": False, "freeze_decoder": False},
-        freeze_all=True, no_freeze_last_layer=False, use_new_last_layer=False)  # authors' setting (scripts/schedule_vpt.sh:14,21)
+        freeze_all=True, no_freeze_last_layer=False, use_new_last_layer=False,  # authors' setting (scripts/schedule_vpt.sh:14,21)
+        cache_text_features=cond_cache)
     module = ImageTextMaskModule(net=net, loss_fn=DiceCELoss(sigmoid=True, lambda_dice=1, lambda_ce=0.2),
                                  optimizer=partial(FusedAdamW, lr=2e-4), scheduler=None, compile=False, task="binary",
                                  threshold=0.5, weight_decay=0.0).to(device)
@@ -186,6 +187,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cond-cache", action="store_true",
+                    help="vpt only: keep the frozen text tower's conditional embeddings per distinct token row (skips work: NOT the headline number; "
+                         "the line is marked cond_cache=true)")
     ap.add_argument("--cpu-steps32", type=int, default=2, help="timed CPU-oracle steps at the headline shape (bs 32)")
     ap.add_argument("--cpu-steps4", type=int, default=3, help="timed CPU-oracle steps of config C1 (CoOp-4, bs 4)")
     ap.add_argument("--workload", choices=("vpt", "cris", "maple"), default="vpt",
@@ -206,7 +210,7 @@ def main():
     hip.load()
 
     cris, maple = args.workload == "cris", args.workload == "maple"
-    module, opt = build_cris_module(device) if cris else (build_maple_module(device) if maple else build_module(device))
+    module, opt = build_cris_module(device) if cris else (build_maple_module(device) if maple else build_module(device, cond_cache=args.cond_cache))
     batch = make_batch(args.batch, 416 if cris else 352, 100 + rank, device, pad_id=0 if cris else 1)
     gflop_per_image = 212.8 if cris else (167.8 if maple else GFLOP_PER_IMAGE_TRAIN)  # SURVEY.md §8d (FlopCounterMode on the reference)
 
@@ -296,6 +300,9 @@ def main():
             "loss": round(float(loss.item()), 6), "train_dice": round(metrics["train_dice"], 6), "train_iou": round(metrics["train_iou"], 6),
             "roofline": roofline,
         }
+        if args.cond_cache and not cris and not maple:
+            out["cond_cache"] = True
+            out["config"]["workload"] += " -- WITH the conditional-embedding cache (text tower skipped after the first step: not the headline)"
         if not args.no_cpu_baseline and world == 1 and not cris and not maple:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps32, args.cpu_steps4)
         print(json.dumps(out), flush=True)

@@ -198,3 +198,40 @@ def test_hip_net_matches_reference_headline_batch():
     prof = run_compact_case("rd64_vpt_n10_d1_b32")
     big = [k for k in prof if k.startswith("gemm_tp3_kernel<192") or "gemm_bf16s_kernel<192" in k]
     assert big, sorted(prof)
+
+
+def test_vpt_conditional_embedding_cache_skips_the_text_tower_and_keeps_the_logits(monkeypatch):
+    """Opt-in extension (VPTCLIPSeg(cache_text_features=True)): rows seen before do not run the text tower again; logits equal the
+    uncached net's (the frozen text tower is a pure function of the token row; trailing padding is not part of the key)."""
+    from functools import partial
+
+    from tunevlseg_amd import nets
+    from tunevlseg_amd.nets import towers
+    from tunevlseg_amd.nets.context_learner import VPTContextLearner
+
+    def make(cache):
+        torch.manual_seed(0)
+        return nets.VPTCLIPSeg(context_learner=partial(VPTContextLearner, prompt_depth=2, num_context=4), cache_text_features=cache,
+                               model_cfg={"pretrained_model_name_or_path": "random:tiny:seed=5"}).cuda()
+
+    plain, cached = make(False), make(True)
+    g = torch.Generator().manual_seed(1)
+    pix = torch.randn(3, 3, 64, 64, generator=g).cuda()
+    ids = torch.tensor([[62, 5, 9, 63, 1, 1], [62, 7, 11, 13, 63, 1], [62, 5, 9, 63, 1, 1]]).cuda()
+    am = (ids != 1).long()
+    calls = []
+    real = towers.text_tower
+    monkeypatch.setattr(towers, "text_tower", lambda model, i, a, *r, **k: (calls.append(i.shape[0]), real(model, i, a, *r, **k))[1])
+    ref = plain(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix)
+    calls.clear()
+    a = cached(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix)
+    assert calls == [2], calls   # rows 0 and 2 are the same phrase: one text-tower call on the two distinct rows
+    # the same phrases, padded to a longer row: no text-tower call at all
+    ids2 = torch.cat([ids, torch.ones(3, 2, dtype=ids.dtype, device=ids.device)], dim=1)
+    b = cached(text_input={"input_ids": ids2, "attention_mask": (ids2 != 1).long()}, image_input=pix)
+    assert calls == [2], calls
+    for out in (a, b):
+        assert (out - ref).abs().max().item() <= 1e-5
+    cached.clear_text_cache()
+    cached(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix)
+    assert calls == [2, 2]
