@@ -132,8 +132,10 @@ constexpr int FWD_LDS = 2 * K_STAGE + 2 * V_STAGE;
 // step -- all in the matrix stretch, then all in the softmax -- so the two ADD: 2,300 cycles per wave-tile measured, however the
 // vector work was trimmed (mask only on edge tiles, scale folded into the exp2 argument), with conflict-free transposed reads, with
 // the next tile's S^T issued ahead of this tile's softmax, or with two 4-wave halves held in anti-phase by barriers (5,650 cycles
-// per tile pair: every phase start exposes an LDS round trip).  The way on is a hand-placed stream with <= 5 vector instructions in
-// every MFMA gap (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'); hipcc's scheduler does not produce one around inline asm.
+// per tile pair: every phase start exposes an LDS round trip), or with a hand-placed stream (every MFMA followed by the <= 5 vector
+// instructions that fit in its shadow, the softmax of tile k under the S MFMAs of tile k+1: same time).  The kernel is POWER-limited:
+// the identical instruction stream on all-zero operands runs 18 % faster (backward: 34 %), so what pays is fewer MFMAs and fewer bytes
+// moved per result (profiles/r2_attention_experiments.md), not a denser schedule.
 // V = 0 is the product; 1 (no DMA after the prologue), 2 (no static priority) and 16 (workgroup clock stamps) are diagnostics for
 // tools/bench_attn.py.
 constexpr int FWD_THREADS = 256, FWD_Q = 128;
@@ -300,6 +302,12 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void attn_fwd_tp3_kernel(FwdP p) {
     }
 }
 
+// virtual workgroup id: blocks of one (sample, head) consecutive inside one XCD's share of the grid (as in the forward)
+__device__ __forceinline__ int xcd_vid() {
+    const int total = (int)gridDim.x, L = (int)blockIdx.x, per = total / 8;
+    return L < per * 8 ? (L % 8) * per + L / 8 : L;
+}
+
 // ---- backward -------------------------------------------------------------------------------------------------------------
 // Same arithmetic as attn_bwd_dq / dkdv_bf16s_kernel (attention_bf16s.hip): P is recomputed from Q, K and the forward's log-sum-exp,
 // dS = P o (dP - delta), every product is the 6-MFMA piece sum.  Operands arrive as tp3 images: packed QKV [B*T, 3*H*64] (the QKV
@@ -361,12 +369,6 @@ __device__ __forceinline__ void mma_cols(unsigned t_rd, const bf16x8 (&x0)[3], c
 
 constexpr int BWD_STAGE = 24 * PIECE + 256;   // two 12-piece tiles + 64 floats (log-sum-exp | delta of a query tile; dK/dV kernel only)
 constexpr int BWD_LDS = 2 * BWD_STAGE;
-
-// virtual workgroup id: blocks of one (sample, head) consecutive inside one XCD's share of the grid (as in the forward)
-__device__ __forceinline__ int xcd_vid() {
-    const int total = (int)gridDim.x, L = (int)blockIdx.x, per = total / 8;
-    return L < per * 8 ? (L % 8) * per + L / 8 : L;
-}
 
 // dQ: query-stationary.  Per key tile: S^T = K.Q^T, dP^T = V.dO^T (K, V fragments straight out of the DMA image), dS^T on the
 // accumulators, dQ^T += K^T . dS^T (K^T by transposed reads of the same K pieces).  Also writes delta for the dK/dV kernel.
