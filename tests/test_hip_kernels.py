@@ -521,7 +521,7 @@ def test_input_side_normalize_and_mask(hip):
     assert torch.equal(out.long().cpu(), (m == 255).long()[:, None])
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 495, 12), (3, 100, 2), (1, 33, 1), (4, 64, 3), (2, 485, 12)])
+@pytest.mark.parametrize("B,T,H", [(2, 495, 12), (3, 100, 2), (1, 33, 1), (4, 64, 3), (2, 485, 12), (4, 8, 2), (5, 31, 1)])
 def test_attention_on_tp3_qkv(hip, B, T, H):
     """Attention reading Q / K / V from the tp3 image of the packed QKV matrix (LDS-DMA key tiles aligned to the image's row
     blocks, neighbouring samples' keys masked) against the fp32-input kernel: same piece arithmetic, different key tiling."""
@@ -533,7 +533,7 @@ def test_attention_on_tp3_qkv(hip, B, T, H):
     close(lse, lse_ref, 1e-6, "attn tp3 fwd lse")
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 495, 12), (3, 100, 2), (1, 33, 1), (4, 64, 3), (2, 485, 12)])
+@pytest.mark.parametrize("B,T,H", [(2, 495, 12), (3, 100, 2), (1, 33, 1), (4, 64, 3), (2, 485, 12), (4, 8, 2), (5, 31, 1)])
 def test_attention_backward_on_tp3_operands(hip, B, T, H):
     """dQ | dK | dV from tp3 images of QKV, O and dO (query / key tiles aligned to the images' row blocks, neighbouring samples'
     rows masked, delta formed from the pieces) against the fp32-input backward kernels: same piece arithmetic, different tiling."""

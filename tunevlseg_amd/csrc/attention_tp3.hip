@@ -91,6 +91,14 @@ __device__ __forceinline__ void row_frags(const unsigned char* __restrict__ img,
     for (int p = 0; p < 3; ++p) out[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(src + p * PIECE));
 }
 
+// Address of the 16-byte unit (row m, k-half hh) of piece 0 of a column block of a tp3 image (colblk = image + column block * BLK,
+// blk_stride = bytes between row blocks).  Key / query tiles start at the SAMPLE's first row, not at a 32-row block of the image: a
+// tile's 32 rows straddle two row blocks, which costs the LDS-DMA nothing (its global addresses are per lane) and saves the 17th tile
+// and the first-tile mask that block-aligned tiles needed at T = 495.
+__device__ __forceinline__ const unsigned char* unit_at(const unsigned char* colblk, long blk_stride, long m, int hh) {
+    return colblk + (m >> 5) * blk_stride + (hh * 32 + (int)(m & 31)) * 16;
+}
+
 // Two workgroups share a CU and their waves a SIMD.  With equal priority the co-resident waves fall into step (both in the MFMA
 // stretch, then both in the vector stretch) and the two stretches add.  Every second workgroup the dispatcher places on a CU -- it
 // deals one workgroup to each of an XCD's 32 CUs before the second -- therefore runs at a higher static priority: it takes the
@@ -171,23 +179,26 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void attn_fwd_tp3_kernel(FwdP p) {
     float m_run = NEG_BIG, l_run = 0.f;
     const float sc2 = p.scale * LOG2E;
 
-    // key tiles = the image's row blocks that overlap this sample's rows [b*T, (b+1)*T)
-    const long row_lo = (long)b * T, row_hi = row_lo + T;
-    const int rb_lo = (int)(row_lo >> 5);
-    const int nkt = (int)((row_hi - 1) >> 5) - rb_lo + 1;
-    const int lo_in_blk = (int)(row_lo & 31);
-    // DMA: a tile is 12 K pieces + 12 V pieces (each group contiguous in HBM); wave w moves pieces w, w + 4, w + 8 of both
-    const unsigned char* k_src = p.qkv + ((long)rb_lo * p.kb + (D + head * DH) / 16) * BLK + lane * 16;
-    // V pieces land key-interleaved: LDS unit L (16 B) of a piece = (key L >> 1, d-half L & 1), i.e. a key's 16 d are 32 contiguous bytes
-    const unsigned char* v_src = p.qkv + ((long)rb_lo * p.kb + (2 * D + head * DH) / 16) * BLK + ((lane & 1) * 32 + (lane >> 1)) * 16;
+    // key tile kt = keys [32 kt, 32 kt + 32) of this sample (image rows b*T + ...; rows past the image's last row are clamped, their
+    // keys masked).  DMA: a tile is 12 K pieces + 12 V pieces; wave w moves pieces w, w + 4, w + 8 of both.
+    const long row_lo = (long)b * T;
+    const int nkt = (T + 31) / 32;
     const long tile_stride = (long)p.kb * BLK;
+    const unsigned char* k_col = p.qkv + (long)((D + head * DH) / 16) * BLK;
+    const unsigned char* v_col = p.qkv + (long)((2 * D + head * DH) / 16) * BLK;
+    const unsigned k_lane = (unsigned)(unit_at(k_col, tile_stride, row_lo + (l31 < T ? l31 : T - 1), h) - k_col);   // tile 0 (a row of the sample); tile kt is kt row blocks further
+    // V pieces land key-interleaved: LDS unit L (16 B) of a piece = (key L >> 1, d-half L & 1), i.e. a key's 16 d are 32 contiguous bytes
+    const unsigned v_lane = (unsigned)(unit_at(v_col, tile_stride, row_lo + ((lane >> 1) < T ? (lane >> 1) : T - 1), lane & 1) - v_col);
     auto issue = [&](int kt) {
         const unsigned kd = lds0 + (kt & 1) * K_STAGE, vd = lds0 + 2 * K_STAGE + (kt & 1) * V_STAGE;
+        // rows past the sample's end (last tile only) are masked anyway: those lanes re-read their tile-0 row, so no address leaves the image
+        const unsigned char* ks = k_col + (k_lane + (32 * kt + l31 < T ? (unsigned)kt * (unsigned)tile_stride : 0u));
+        const unsigned char* vs = v_col + (v_lane + (32 * kt + (lane >> 1) < T ? (unsigned)kt * (unsigned)tile_stride : 0u));
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int pc = wave + 4 * i;   // 0..11
-            glds16(k_src + kt * tile_stride + pc * PIECE, kd + pc * PIECE);
-            glds16(v_src + kt * tile_stride + pc * PIECE, vd + (pc / 3) * VCH + (pc % 3) * PIECE);
+            const int pc = wave + 4 * i;   // 0..11: (d-chunk pc / 3, piece pc % 3), consecutive in the image
+            glds16(ks + pc * PIECE, kd + pc * PIECE);
+            glds16(vs + pc * PIECE, vd + (pc / 3) * VCH + (pc % 3) * PIECE);
         }
     };
     // transposed-read addressing of a V piece (32 keys x 16 d, element (key, d) at key * 32 + d * 2): a 16-lane group reads
@@ -233,13 +244,10 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void attn_fwd_tp3_kernel(FwdP p) {
         read_v<0>(va, vb_); read_v<0>(vb, vb_ + 512);
         // ---- online softmax (query on the lane; register r <-> key (r & 3) + 8 (r >> 2) + 4 h of the tile) ----
         // The running maximum is kept in RAW score units (scale > 0 commutes with max); the scale rides on the exp2 argument's fma.
-        if (kt == 0 || kt == nkt - 1) {   // only the first / last tile of a sample can hold a neighbour's keys
-            const int key0 = 32 * kt + 4 * h - lo_in_blk;   // key index, relative to the sample, of register 0
+        if (kt == nkt - 1) {   // only the last tile reaches past the sample
+            const int key0 = 32 * kt + 4 * h;   // key index of register 0
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + (r & 3) + 8 * (r >> 2);
-                sc[r] = (key >= 0 && key < T) ? sc[r] : NEG_BIG;
-            }
+            for (int r = 0; r < 16; ++r) sc[r] = (key0 + (r & 3) + 8 * (r >> 2) < T) ? sc[r] : NEG_BIG;
         }
         float mx = fmaxf(sc[0], sc[1]);
 #pragma unroll
@@ -347,7 +355,8 @@ __device__ __forceinline__ void pieces_of(float (&x)[16], bf16x8 (&f0)[3], bf16x
     f1[0] = frag_of(p0[4], p0[5], p0[6], p0[7]); f1[1] = frag_of(p1[4], p1[5], p1[6], p1[7]); f1[2] = frag_of(p2[4], p2[5], p2[6], p2[7]);
 }
 // A . B accumulated over the four 16-k steps of d_h = 64: A fragments double-buffered out of LDS (piece blocks BLK apart), B in registers
-__device__ __forceinline__ f32x16 mma_rows(unsigned a_rd, const bf16x8 (&bq)[4][3], const f32x16& zero) {
+__device__ __forceinline__ f32x16 mma_rows(unsigned a_rd, const bf16x8 (&bq)[4][3]) {
+    const f32x16 zero = {};   // an inline constant as the first MFMA's accumulator input, not 16 registers
     bf16x8 ka[3], kb[3];
     read_k<0>(ka, a_rd); read_k<BLK>(kb, a_rd);
     wait_k<3>(ka); f32x16 acc = mma6(ka, bq[0], zero);
@@ -407,24 +416,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tp3_kernel(BwdP p) {
     const float sc2 = p.scale * LOG2E;
     const float nlse2 = -p.lse[stat] * LOG2E;
 
-    f32x16 acc_dq[2], zero;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc_dq[0][r] = 0.f; acc_dq[1][r] = 0.f; zero[r] = 0.f; }
+    f32x16 acc_dq[2] = {};
 
-    const long row_lo = (long)b * T, row_hi = row_lo + T;
-    const int rb_lo = (int)(row_lo >> 5);
-    const int nkt = (int)((row_hi - 1) >> 5) - rb_lo + 1;
-    const int lo_in_blk = (int)(row_lo & 31);
-    const unsigned char* k_src = p.qkv + ((long)rb_lo * p.kb + (D + head * DH) / 16) * BLK + lane * 16;
-    const unsigned char* v_src = p.qkv + ((long)rb_lo * p.kb + (2 * D + head * DH) / 16) * BLK + lane * 16;
+    const long row_lo = (long)b * T;
+    const int nkt = (T + 31) / 32;
     const long tile_stride = (long)p.kb * BLK;
-    auto issue = [&](int kt) {
+    const unsigned char* k_col = p.qkv + (long)((D + head * DH) / 16) * BLK;
+    const unsigned char* v_col = p.qkv + (long)((2 * D + head * DH) / 16) * BLK;
+    const unsigned k_lane = (unsigned)(unit_at(k_col, tile_stride, row_lo + (l31 < T ? l31 : T - 1), h) - k_col);   // tile 0 (a row of the sample); tile kt is kt row blocks further
+    const long v_minus_k = v_col - k_col;
+    auto issue = [&](int kt) {   // key tile kt = keys [32 kt, 32 kt + 32) of the sample (unit_at)
         const unsigned dst = lds0 + (kt & 1) * BWD_STAGE;
+        // rows past the sample's end (last tile only) are masked anyway: those lanes re-read their tile-0 row, so no address leaves the image
+        const unsigned char* ks = k_col + (k_lane + (32 * kt + l31 < T ? (unsigned)kt * (unsigned)tile_stride : 0u));
+        const unsigned char* vs = ks + v_minus_k;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int pc = wave + 4 * i;
-            glds16(k_src + kt * tile_stride + pc * PIECE, dst + pc * PIECE);
-            glds16(v_src + kt * tile_stride + pc * PIECE, dst + (12 + pc) * PIECE);
+            glds16(ks + pc * PIECE, dst + pc * PIECE);
+            glds16(vs + pc * PIECE, dst + (12 + pc) * PIECE);
         }
     };
     const int li = lane & 15, g1 = (lane >> 4) & 1;
@@ -436,18 +446,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tp3_kernel(BwdP p) {
         __builtin_amdgcn_s_barrier();
         if (kt + 1 < nkt) issue(kt + 1);
         const unsigned st = lds0 + (kt & 1) * BWD_STAGE;
-        f32x16 sc = mma_rows(st + lane * 16, qf, zero);                  // S^T  [key (register), query (lane)]
-        f32x16 dp = mma_rows(st + 12 * PIECE + lane * 16, dof, zero);    // dP^T
+        f32x16 sc = mma_rows(st + lane * 16, qf);                  // S^T  [key (register), query (lane)]
+        f32x16 dp = mma_rows(st + 12 * PIECE + lane * 16, dof);    // dP^T
         float ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], sc2, nlse2)) * (dp[r] - dl);
-        if (kt == 0 || kt == nkt - 1) {   // a neighbour sample's keys share the first / last row block
-            const int key0 = 32 * kt + 4 * h - lo_in_blk;
+        if (kt == nkt - 1) {   // only the last tile reaches past the sample
+            const int key0 = 32 * kt + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + (r & 3) + 8 * (r >> 2);
-                ds[r] = (key >= 0 && key < T) ? ds[r] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) ds[r] = (key0 + (r & 3) + 8 * (r >> 2) < T) ? ds[r] : 0.f;
         }
         bf16x8 x0[3], x1[3];
         pieces_of(ds, x0, x1);
@@ -489,31 +496,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_tp3_kernel(BwdP p) {
         row_frags(p.qkv, p.kb, m_k, (D + head * DH) / 16 + s, h, kf[s]);
         row_frags(p.qkv, p.kb, m_k, (2 * D + head * DH) / 16 + s, h, vf[s]);
     }
-    f32x16 acc_dk[2], acc_dv[2], zero;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc_dk[0][r] = 0.f; acc_dk[1][r] = 0.f; acc_dv[0][r] = 0.f; acc_dv[1][r] = 0.f; zero[r] = 0.f; }
+    f32x16 acc_dk[2] = {}, acc_dv[2] = {};
     const float sc2 = p.scale * LOG2E;
 
-    const long row_lo = (long)b * T, row_hi = row_lo + T;
-    const int rb_lo = (int)(row_lo >> 5);
-    const int nqt = (int)((row_hi - 1) >> 5) - rb_lo + 1;
-    const int lo_in_blk = (int)(row_lo & 31);
-    const unsigned char* q_src = p.qkv + ((long)rb_lo * p.kb + (head * DH) / 16) * BLK + lane * 16;
-    const unsigned char* d_src = p.do_img + ((long)rb_lo * p.o_kb + (head * DH) / 16) * BLK + lane * 16;
+    const long row_lo = (long)b * T;
+    const int nqt = (T + 31) / 32;
     const long q_stride = (long)p.kb * BLK, d_stride = (long)p.o_kb * BLK;
+    const unsigned char* q_col = p.qkv + (long)((head * DH) / 16) * BLK;
+    const unsigned char* d_col = p.do_img + (long)((head * DH) / 16) * BLK;
     const float* stat_base = (lane < 32 ? p.lse : p.delta) + ((long)b * p.H + head) * T;
-    auto issue = [&](int qt) {
+    const unsigned q_lane = (unsigned)(unit_at(q_col, q_stride, row_lo + (l31 < T ? l31 : T - 1), h) - q_col);   // tile 0 (a row of the sample); tile qt is qt row blocks further
+    const unsigned d_lane = (unsigned)(unit_at(d_col, d_stride, row_lo + (l31 < T ? l31 : T - 1), h) - d_col);
+    auto issue = [&](int qt) {   // query tile qt = queries [32 qt, 32 qt + 32) of the sample (unit_at)
         const unsigned dst = lds0 + (qt & 1) * BWD_STAGE;
+        // uniform base + 32-bit lane offset (images are < 4 GB).  Rows past the sample's end (last tile only) are masked anyway: those
+        // lanes re-read their tile-0 row instead, so that no address leaves the image
+        const bool in_sample = 32 * qt + l31 < T;
+        const unsigned char* qs = q_col + (q_lane + (in_sample ? (unsigned)qt * (unsigned)q_stride : 0u));
+        const unsigned char* ds_ = d_col + (d_lane + (in_sample ? (unsigned)qt * (unsigned)d_stride : 0u));
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int pc = wave + 4 * i;
-            glds16(q_src + qt * q_stride + pc * PIECE, dst + pc * PIECE);
-            glds16(d_src + qt * d_stride + pc * PIECE, dst + (12 + pc) * PIECE);
+            glds16(qs + pc * PIECE, dst + pc * PIECE);
+            glds16(ds_ + pc * PIECE, dst + (12 + pc) * PIECE);
         }
         if (wave == 0) {   // lanes 0-31: log-sum-exp of the tile's 32 queries, lanes 32-63: their delta (clamped inside the sample)
-            int q = 32 * qt + l31 - lo_in_blk;
-            q = q < 0 ? 0 : (q < T ? q : T - 1);
-            glds4(stat_base + q, dst + 24 * PIECE);
+            const int q = 32 * qt + l31;
+            glds4(stat_base + (q < T ? q : T - 1), dst + 24 * PIECE);
         }
     };
     const int li = lane & 15, g1 = (lane >> 4) & 1;
@@ -525,8 +534,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_tp3_kernel(BwdP p) {
         __builtin_amdgcn_s_barrier();
         if (qt + 1 < nqt) issue(qt + 1);
         const unsigned st = lds0 + (qt & 1) * BWD_STAGE;
-        f32x16 sc = mma_rows(st + lane * 16, kf, zero);                  // S   [query (register), key (lane)]
-        f32x16 dp = mma_rows(st + 12 * PIECE + lane * 16, vf, zero);     // dP
+        f32x16 sc = mma_rows(st + lane * 16, kf);                  // S   [query (register), key (lane)]
+        f32x16 dp = mma_rows(st + 12 * PIECE + lane * 16, vf);     // dP
         // rows of S / dP are the tile's queries (r & 3) + 8 (r >> 2) + 4 h: their statistics come as four float4 each
         f32x4 l4[4], d4[4];
 #pragma unroll
@@ -540,12 +549,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_tp3_kernel(BwdP p) {
             pv[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], sc2, -LOG2E * l4[r >> 2][r & 3]));
             dsv[r] = pv[r] * (dp[r] - d4[r >> 2][r & 3]);
         }
-        if (qt == 0 || qt == nqt - 1 || !key_ok) {   // a neighbour sample's queries share the first / last row block
-            const int q0 = 32 * qt + 4 * h - lo_in_blk;
+        if (qt == nqt - 1 || !key_ok) {   // only the last tile reaches past the sample
+            const int q0 = 32 * qt + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int q = q0 + (r & 3) + 8 * (r >> 2);
-                const bool ok = key_ok && q >= 0 && q < T;
+                const bool ok = key_ok && q0 + (r & 3) + 8 * (r >> 2) < T;
                 pv[r] = ok ? pv[r] : 0.f;
                 dsv[r] = ok ? dsv[r] : 0.f;
             }
