@@ -77,3 +77,74 @@ def test_pad_to_longest_collator():
     assert PadToLongestCollator(pad_token_id=0, pad_to_multiple_of=8)(feats)["input_ids"].shape == (2, 8)
     with pytest.raises(ValueError):
         PadToLongestCollator(())
+
+
+def _write_toy_dataset(root: Path):
+    from PIL import Image
+    import numpy as np
+
+    (root / "images").mkdir()
+    (root / "masks").mkdir()
+    rng = np.random.default_rng(0)
+    tasks = []
+    for i, (h, w) in enumerate([(20, 30), (17, 17), (40, 24)]):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(root / "images" / f"im{i}.png")
+        m = (rng.random((h, w)) > 0.6).astype(np.uint8) * 255
+        Image.fromarray(m).save(root / "masks" / f"m{i}.png")
+        tasks.append({"img_name": f"im{i}.png", "mask_name": f"m{i}.png",
+                      "prompts": {"p0": "", "p1": f"polyp number {i}", "p2": [f"a round polyp {i}", f"a pink polyp {i}"]}})
+    (root / "anns.json").write_text(json.dumps(tasks))
+    return tasks
+
+
+def test_dataset_items_follow_the_reference_wire_format(tmp_path, toy_tokenizer):
+    """image_dir / mask_dir / task file with prompts p0..pN -> item keys, original mask_shape, prompt selection rules
+    (reference image_text_mask_dataset.py:46-128), uint8 payloads, pad-to-longest collation across ragged prompts."""
+    import random
+
+    import numpy as np
+
+    from tunevlseg_amd.data import ImageTextMaskDataset, ResizeTransform
+
+    _write_toy_dataset(tmp_path)
+    kw = dict(image_dir=tmp_path / "images", mask_dir=tmp_path / "masks", task_path=tmp_path / "anns.json", tokenizer=toy_tokenizer,
+              transforms=ResizeTransform(16))
+    ds = ImageTextMaskDataset(prompt_index=1, **kw)
+    assert len(ds) == 3
+    it = ds[2]
+    assert set(it) == {"image", "mask", "mask_shape", "mask_name", "prompt", "input_ids", "attention_mask"}
+    assert it["image"].shape == (16, 16, 3) and it["image"].dtype == torch.uint8
+    assert it["mask"].shape == (16, 16) and it["mask"].dtype == torch.uint8 and set(it["mask"].unique().tolist()) <= {0, 255}
+    assert it["mask_shape"].tolist() == [40, 24] and it["mask_name"] == "m2.png" and it["prompt"] == "polyp number 2"
+    assert it["input_ids"][0] == toy_tokenizer.bos_token_id and it["input_ids"][-1] == toy_tokenizer.eos_token_id
+    # list-valued prompt -> one of its elements; negative index -> any key but p0; override; trailing stop
+    random.seed(0)
+    assert ImageTextMaskDataset(prompt_index=2, **kw)[0]["prompt"] in {"a round polyp 0", "a pink polyp 0"}
+    for _ in range(8):
+        assert ImageTextMaskDataset(prompt_index=-1, **kw)[1]["prompt"] != ""
+    assert ImageTextMaskDataset(prompt_index=1, override_prompt="tumour", insert_stop_at_last=True, **kw)[0]["prompt"] == "tumour."
+    # without a transform the sample keeps its own geometry
+    raw = ImageTextMaskDataset(prompt_index=1, **{**kw, "transforms": None})[0]
+    assert raw["image"].shape == (20, 30, 3) and np.array_equal(raw["mask_shape"], [20, 30])
+    with pytest.raises(ValueError, match="Image not found"):
+        ImageTextMaskDataset(prompt_index=1, **{**kw, "image_dir": tmp_path / "nowhere"})[0]
+    batch = PadToLongestCollator(pad_token_id=toy_tokenizer.eos_token_id)([ds[i] for i in range(3)])
+    assert batch["image"].shape == (3, 16, 16, 3) and batch["mask"].shape == (3, 16, 16)
+    assert batch["input_ids"].shape == batch["attention_mask"].shape and batch["mask_name"] == ["m0.png", "m1.png", "m2.png"]
+
+
+@pytest.mark.gpu
+def test_device_batch_prep_equals_the_host_transform(tmp_path, toy_tokenizer):
+    """uint8 batch -> normalised fp32 image / mask on the device == A.Normalize + ToTensorV2 + mask / 255 done on the host."""
+    from tunevlseg_amd.data import DeviceBatchPrep, ImageTextMaskDataset, ResizeTransform
+
+    _write_toy_dataset(tmp_path)
+    ds = ImageTextMaskDataset(image_dir=tmp_path / "images", mask_dir=tmp_path / "masks", task_path=tmp_path / "anns.json",
+                              prompt_index=1, tokenizer=toy_tokenizer, transforms=ResizeTransform(32))
+    batch = PadToLongestCollator(pad_token_id=toy_tokenizer.eos_token_id)([ds[i] for i in range(3)])
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    out = DeviceBatchPrep(mean, std)(batch)
+    ref_img = ((batch["image"].float() / 255 - torch.tensor(mean)) / torch.tensor(std)).permute(0, 3, 1, 2)
+    assert out["image"].shape == (3, 3, 32, 32) and (out["image"].cpu() - ref_img).abs().max().item() <= 1e-6
+    assert torch.equal(out["mask"].cpu(), (batch["mask"].float() / 255)[:, None])
+    assert out["input_ids"].is_cuda and out["mask_name"] == batch["mask_name"]
