@@ -545,3 +545,25 @@ def test_attention_backward_on_tp3_operands(hip, B, T, H):
     got = hip.attn_tp3_bwd(hip.tp3_pack(qkv), o_t, hip.tp3_pack(d_o), lse, B, T, H, dh**-0.5).float()
     for name, c0 in (("dQ", 0), ("dK", D), ("dV", 2 * D)):
         close(got[:, c0:c0 + D], ref[:, c0:c0 + D], 5e-6, f"attn tp3 bwd {name}")
+
+
+def test_dropout_statistics_and_reproducibility(hip):
+    """tvl_dropout (the SharedAttn learner's TransformerEncoderLayer, configs/model/shared_attn_clipseg.yaml:21 uses p = 0.25):
+    the dropped fraction is binomial around p, survivors are scaled by 1 / (1 - p), the same (seed) reproduces the mask -- which is how
+    the backward re-creates it -- and another seed gives an independent one."""
+    n, p = 1 << 20, 0.25
+    x = dev(torch.ones(n))
+    a, b, c = hip.dropout(x, p, 1234), hip.dropout(x, p, 1234), hip.dropout(x, p, 1235)
+    assert torch.equal(a, b)
+    dropped = (a == 0).double().mean().item()
+    sigma = (p * (1 - p) / n) ** 0.5
+    assert abs(dropped - p) < 5 * sigma, (dropped, p, sigma)
+    kept = a[a != 0]
+    assert torch.allclose(kept, torch.full_like(kept, 1 / (1 - p)), rtol=1e-6, atol=0)
+    # independence of two seeds: P(both dropped) = p^2 within 5 sigma
+    both = ((a == 0) & (c == 0)).double().mean().item()
+    assert abs(both - p * p) < 5 * (p * p * (1 - p * p) / n) ** 0.5, both
+    # no visible structure along the index (runs test on 64-element blocks: block means spread like a binomial)
+    blk = (a == 0).double().view(-1, 64).mean(1)
+    assert abs(blk.var().item() - p * (1 - p) / 64) < 0.1 * p * (1 - p) / 64
+    assert torch.equal(hip.dropout(x, 0.0, 7), x)

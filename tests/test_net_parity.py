@@ -235,3 +235,31 @@ def test_vpt_conditional_embedding_cache_skips_the_text_tower_and_keeps_the_logi
     cached.clear_text_cache()
     cached(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix)
     assert calls == [2, 2]
+
+
+def test_shared_attn_learner_dropout_is_on_in_fit_and_off_in_eval():
+    """SharedAttn with the reference's dropout 0.25 (configs/model/shared_attn_clipseg.yaml:21; the fixtures use 0): in train mode
+    two forward passes differ and both differ from eval; in eval mode (what validation / test / predict run under,
+    trainer.evaluation_mode) the net is deterministic and equals the dropout-free fixture; averaging train-mode passes moves towards
+    the eval logits (inverted dropout keeps the expectation of the dropped activations; the LayerNorms behind them keep it from
+    converging all the way)."""
+    from tunevlseg_amd.trainer import evaluation_mode
+
+    fx = load_golden("tiny_sharedattn_d2")
+    fx["meta"]["learner_kw"] = dict(fx["meta"]["learner_kw"])
+    fx["meta"]["learner_kw"]["_tlayer"] = dict(fx["meta"]["learner_kw"]["_tlayer"], dropout=0.25)
+    net = build_net(fx)
+    pix, ids, am, _ = (t.cuda() for t in inputs_of(fx))
+    call = lambda: net(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix).detach()  # noqa: E731
+    net.context_learner.train()
+    a, b = call(), call()
+    assert not torch.equal(a, b)
+    with evaluation_mode(net):
+        e1, e2 = call(), call()
+    assert torch.equal(e1, e2) and not torch.equal(e1, a)
+    assert net.context_learner.training  # the flag came back
+    ref = torch.from_numpy(fx["out.logits"]).cuda()
+    assert (e1 - ref).abs().max().item() <= LOGIT_TOL   # eval == the dropout-free fixture
+    mean = torch.stack([call() for _ in range(64)]).mean(0)
+    spread = (a - e1).abs().mean().item()
+    assert (mean - e1).abs().mean().item() < 0.8 * spread, ((mean - e1).abs().mean().item(), spread)
