@@ -190,6 +190,21 @@ def load():
     return lib
 
 
+_CONST_I32: dict = {}
+
+
+def const_i32(values, device) -> torch.Tensor:
+    """Device int32 tensor of a small host-side index list (token maps, row maps), built once per (values, device): the per-step
+    ``torch.tensor(list, device=...)`` it replaces is a pageable host-to-device copy, which also forbids HIP-graph capture."""
+    key = (tuple(int(v) for v in values), str(device))
+    t = _CONST_I32.get(key)
+    if t is None:
+        if len(_CONST_I32) > 4096:
+            _CONST_I32.clear()
+        t = _CONST_I32[key] = torch.tensor(key[0], dtype=torch.int32, device=device)
+    return t
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 

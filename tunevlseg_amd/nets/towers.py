@@ -92,7 +92,7 @@ def text_tower(model: CLIPSegBackbone, input_ids: torch.Tensor, attention_mask: 
     T = len(tmap_list)
     if T > t.max_position_embeddings:
         raise ValueError(f"Sequence length must be less than max_position_embeddings (got {T} > {t.max_position_embeddings})")
-    tmap = torch.tensor(tmap_list, dtype=torch.int32, device=dev)
+    tmap = hip.const_i32(tmap_list, dev)
     x = ops.TextAssembleFn.apply(input_ids.contiguous(), tmap, tm.embeddings.token_embedding.weight.detach(), ctx0,
                                  tm.embeddings.position_embedding.weight.detach(), n)
     key_mask = None

@@ -563,7 +563,7 @@ class SpliceRowsFn(Fn):
         B, L, D = x.shape
         n = cvec.shape[-2]
         per_sample = cvec.dim() == 3
-        tmap = torch.tensor(tmap_list, dtype=torch.int32, device=x.device)
+        tmap = hip.const_i32(tmap_list, x.device)
         ctx.meta = (B, L, D, n, per_sample, tuple(tmap_list))
         return hip.splice_rows(x, tmap, cvec, n * D if per_sample else 0)
 
@@ -578,7 +578,7 @@ class SpliceRowsFn(Fn):
                 if m >= 0:
                     inv[m] = t
             zero = torch.zeros((1, D), device=dout.device, dtype=torch.float32)
-            dx = hip.splice_rows(dout, torch.tensor(inv, dtype=torch.int32, device=dout.device), zero, 0)
+            dx = hip.splice_rows(dout, hip.const_i32(inv, dout.device), zero, 0)
         if ctx.needs_input_grad[1]:
             rows = [t for t, m in enumerate(tmap_list) if m < 0]
             if rows != list(range(rows[0], rows[0] + n)) or [tmap_list[t] for t in rows] != [-(j + 1) for j in range(n)]:
