@@ -290,6 +290,17 @@ typedef struct {
     int32_t tile_m, variant;
 } tvlGemmTp3Args;
 int tvl_gemm_tp3(const tvlGemmTp3Args* args, tvlStream_t stream);
+
+/* "h2": two fp16 pieces per element (x * s = h0 + h1, s an exact power of two per row or per tensor), same block order as tp3 with
+ * 2 KiB per 32 x 16 block.  Three MFMAs per product instead of six at the same (fp32-equivalent) accuracy: csrc/gemm_h2.hip.
+ * tvl_h2_pack: fp32 [rows, K] -> image + inverse scales (per_row != 0: inv_scale[rows], the A operand of an activation; else
+ * inv_scale[1], a frozen weight; work = 4 bytes of device scratch for the per-tensor maximum).
+ * tvl_gemm_h2: tvl_gemm_tp3's argument block with h2 images as A / B; the result is multiplied by alpha (= B's inverse scale) and by
+ * a_row_scale[m] (A's inverse row scales, may be null); C_tp3 stays a tp3 image.  Replaces the same nn.Linear calls as tvl_gemm_tp3. */
+int64_t tvl_h2_bytes(int64_t rows, int32_t K);
+int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, float* inv_scale, int32_t per_row, void* work, tvlStream_t stream);
+int tvl_gemm_h2(const tvlGemmTp3Args* args, const float* a_row_scale, tvlStream_t stream);
+
 /* nn.AvgPool2d(k) / F.avg_pool2d(x, k, k) on [B,H,W,C] (H, W divisible by k) and its gradient (H, W = input sizes) */
 int tvl_avgpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);
 int tvl_avgpool_bwd(const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);

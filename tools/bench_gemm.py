@@ -18,14 +18,22 @@ if len(sys.argv) > 1 and sys.argv[1] != "f32":  # split-bf16 runs data gradients
 
 
 TP3 = len(sys.argv) > 1 and sys.argv[1].startswith("tp3")
+H2 = len(sys.argv) > 1 and sys.argv[1].startswith("h2")   # h2 | h2:<tile>: two fp16 pieces, 3 MFMAs per product (csrc/gemm_h2.hip)
+if H2:
+    SHAPES += [("qkv* NT", hip.NT, M, 2304, 768), ("fc1* NT", hip.NT, M, 3072, 768)]
 if TP3:  # the two GEMMs whose epilogue moves the most bytes, with their real epilogues (ops.EncoderLayerTp3Fn)
     SHAPES += [("fc1* NT", hip.NT, M, 3072, 768), ("dz*  NT", hip.NT, M, 3072, 768), ("out* NT", hip.NT, M, 768, 768)]
+
+
+H2_TILE = int(sys.argv[1].split(":")[1]) if H2 and ":" in sys.argv[1] else 0
 
 
 def main():
     hip.load()
     if len(sys.argv) > 1:
-        if sys.argv[1].startswith("tp3"):  # tp3 | tp3:<tile>:<variant>
+        if H2:
+            pass
+        elif sys.argv[1].startswith("tp3"):  # tp3 | tp3:<tile>:<variant>
             parts = sys.argv[1].split(":")
             hip.GEMM_TP3_TILE = int(parts[1]) if len(parts) > 1 else 0
             hip.GEMM_TP3_VARIANT = int(parts[2]) if len(parts) > 2 else hip.GEMM_TP3_VARIANT
@@ -41,16 +49,21 @@ def main():
             A.zero_(), B.zero_()
         hip.mark_frozen(B)
         C = torch.empty(m, n, device="cuda")
+        if H2:
+            A, B = hip.h2_pack(A, True), hip.h2_pack(B, False)
+            B._alpha = None
         if TP3:  # operands handed over pre-tiled (activations by their producer, weights once)
             A, B = hip.tp3_pack(A), hip.tp3_pack(B)
         extra = {}
-        if name.startswith("fc1*"):
+        if H2 and name.startswith("qkv*"):
+            extra = dict(want_f32=False, out_tp3=hip.Tp3(m, n, "cuda"), bias=torch.randn(n, device="cuda"))
+        elif name.startswith("fc1*"):
             extra = dict(want_f32=False, out_tp3=hip.Tp3(m, n, "cuda"), bias=torch.randn(n, device="cuda"), act=hip.ACT_QUICK_GELU, pre_out=C)
         elif name.startswith("dz*"):
             extra = dict(want_f32=False, out_tp3=hip.Tp3(m, n, "cuda"), dact=hip.ACT_QUICK_GELU, dact_aux=torch.randn(m, n, device="cuda"))
         elif name.startswith("out*"):
             extra = dict(out=C, bias=torch.randn(n, device="cuda"), residual=torch.randn(m, n, device="cuda"))
-        elif TP3:
+        elif TP3 or H2:
             extra = dict(out=C)
         bufs[name] = (A, B, C, extra)
     rounds = 5
@@ -61,7 +74,9 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                if TP3:
+                if H2:
+                    hip.gemm_h2(A, B, tile_m=H2_TILE, **extra)
+                elif TP3:
                     hip.gemm_tp3(A, B, **extra)
                 else:
                     hip.gemm(layout, m, n, k, A, A.shape[1], B, B.shape[1], C, n)
@@ -76,7 +91,7 @@ def main():
         if not name.startswith("sq"):
             tot_f += fl
             tot_t += t
-        key = f"gemm_tp3<{hip.tp3_tile(m, n)},256,{hip.GEMM_TP3_VARIANT}>" if TP3 else hip.gemm_kernel_key(layout, m, n, True, hip._NSPLIT.get(hip.GEMM_MODE, 0), k)
+        key = f"gemm_h2<tile {H2_TILE or 'auto'}>" if H2 else f"gemm_tp3<{hip.tp3_tile(m, n)},256,{hip.GEMM_TP3_VARIANT}>" if TP3 else hip.gemm_kernel_key(layout, m, n, True, hip._NSPLIT.get(hip.GEMM_MODE, 0), k)
         print(f"{name} M={m} N={n} K={k}: {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TF/s  {key}")
     print(f"layer GEMMs total: {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TF/s")
 

@@ -28,6 +28,11 @@ for K in (768, 3072):
         hip.set_gemm_mode("bf16x6")
         C, _ = hip.gemm_tp3(hip.tp3_pack(Ad), hip.tp3_pack(Bd))
         outs["tp3"] = C.cpu().double()
+        C, _ = hip.gemm_h2(hip.h2_pack(Ad, True), hip.h2_pack(Bd, False))
+        outs["h2 (fp16 x 3)"] = C.cpu().double()
+        Bs = Bd * 0.02   # weight-like magnitudes: the tensor scale has to lift them
+        C, _ = hip.gemm_h2(hip.h2_pack(Ad * 37.0, True), hip.h2_pack(Bs, False))
+        outs["h2 scaled in"] = C.cpu().double() / (37.0 * 0.02)
         outs["torch_cpu_f32"] = (A @ B.T).double()
         for k, v in outs.items():
             e = (v - ref) / scale

@@ -1,0 +1,173 @@
+// "h2": the two-piece fp16 operand format and its GEMM entry point (the kernel is gemm_tp3_kernel.h with NP = 2).
+//
+// x * s = h0 + h1 with h0 = fp16(x s), h1 = fp16(x s - h0): 11 + 11 significand bits; the three products h0 h0 + h0 h1 + h1 h0 on
+// v_mfma_f32_32x32x16_f16 (fp16 products are exact in fp32) leave a relative error of ~2^-22 per product, below the fp32 rounding of
+// the accumulation (tools/piece_schemes.py: 2.5e-9 of sum|a||b| at K = 3072; bf16 x 6: 1.8e-9; torch fp32: 1.0e-8) -- at HALF the
+// MFMAs and two thirds of the bytes of the three-piece bf16 format.  fp16's exponent range is the price: the second piece of a
+// scaled value below 0.125 is subnormal, so every row (or tensor) is multiplied by an exact power of two s that puts its largest
+// magnitude in [2^13, 2^14) -- far from 65504, and anything down to 2^-17 of the maximum keeps both pieces normal.  The GEMM's
+// epilogue undoes the scales: per-row factors of A (a_scale[m] = 1 / s_m) and alpha (= 1 / s of the B tensor), both exact.
+//
+// Image layout = tp3's with two pieces: block (rb, kb) at ((rb * K/16 + kb) * 2 + piece) * 1024, same lane order inside a piece.
+#include "gemm_tp3_kernel.h"
+
+namespace {
+
+constexpr int BLK2 = 2 * PIECE;
+
+__device__ __forceinline__ float pow2_scale_inv(float amax) {   // 1 / s, s = power of two with amax * s in [2^13, 2^14)
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+    int e;
+    frexpf(amax, &e);               // amax = m * 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, e - 14);    // s = 2^(14 - e)
+}
+
+// per-row maxima -> inverse scales [rows]; one wave per row
+__global__ __launch_bounds__(256) void h2_rowscale_kernel(const float* __restrict__ x, long ldx, long rows, int K, float* __restrict__ inv_scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float m = 0.f;
+    for (int c = lane * 4; c < K; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) inv_scale[row] = pow2_scale_inv(m);
+}
+
+// whole-tensor maximum -> one inverse scale (two stages: block maxima by atomicMax on the bit pattern of a non-negative float)
+__global__ __launch_bounds__(256) void h2_absmax_kernel(const float* __restrict__ x, long ldx, long rows, int K, unsigned* __restrict__ bits) {
+    float m = 0.f;
+    const long total = rows * (K >> 2);
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long r = t / (K >> 2);
+        const int c = (int)(t - r * (K >> 2)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(bits, __builtin_bit_cast(unsigned, m));
+}
+__global__ void h2_tensorscale_kernel(const unsigned* __restrict__ bits, float* __restrict__ inv_scale) {
+    inv_scale[0] = pow2_scale_inv(__builtin_bit_cast(float, bits[0]));
+}
+
+// one thread = 8 consecutive k of one row -> one 16-byte store per piece (same mapping as tp3_pack_kernel)
+__global__ void h2_pack_kernel(const float* __restrict__ x, long ldx, long rows, int K, const float* __restrict__ inv_scale, int per_row,
+                               unsigned char* __restrict__ out, long rows_padded) {
+    const int KB = K >> 4;
+    const long total = rows_padded * (K >> 3);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(t & 63);
+        const long blk = t >> 6;
+        const long rb = blk / KB;
+        const int kb = (int)(blk - rb * KB);
+        const int r = lane & 31, h = lane >> 5;
+        const long row = rb * 32 + r;
+        _Float16 h0[8], h1[8];
+        if (row < rows) {
+            const float s = 1.0f / inv_scale[per_row ? row : 0];   // a power of two: exact
+            const float* xr = x + row * ldx + kb * 16 + h * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = xr[e] * s;
+                h0[e] = (_Float16)v;
+                h1[e] = (_Float16)(v - (float)h0[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { h0[e] = (_Float16)0.f; h1[e] = (_Float16)0.f; }
+        }
+        unsigned char* o = out + blk * BLK2 + lane * 16;
+        *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(h0);
+        *reinterpret_cast<uint4*>(o + PIECE) = *reinterpret_cast<const uint4*>(h1);
+    }
+}
+
+int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
+    // the epilogues the vision tower's forward needs (QKV -> tp3, fc1 -> QuickGELU -> tp3 + z) + the plain ones; others: generic
+    if (bm == 256) {
+        switch (epi) {
+            case E_BIAS | E_QGELU | E_PRE | E_TP3 | E_RSCALE: return launch<256, 256, 2, E_BIAS | E_QGELU | E_PRE | E_TP3 | E_RSCALE, 2>(p, s);
+            case E_BIAS | E_QGELU | E_TP3 | E_RSCALE: return launch<256, 256, 2, E_BIAS | E_QGELU | E_TP3 | E_RSCALE, 2>(p, s);
+            default: return launch<256, 256, 2, -1, 2>(p, s);
+        }
+    }
+    switch (epi) {
+        case E_BIAS | E_TP3 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_TP3 | E_RSCALE, 2>(p, s);
+        case E_BIAS | E_F32 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_F32 | E_RSCALE, 2>(p, s);
+        case E_F32 | E_RSCALE: return launch<192, 256, 3, E_F32 | E_RSCALE, 2>(p, s);
+        default: return launch<192, 256, 3, -1, 2>(p, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t tvl_h2_bytes(int64_t rows, int32_t K) {
+    if (rows <= 0 || K <= 0 || K % 16 != 0) return -1;
+    return ((rows + 31) / 32) * (int64_t)(K / 16) * BLK2;
+}
+
+// fp32 [rows, K] -> h2 image + inverse scale(s): per_row != 0 -> inv_scale[rows] (activations: A operand), else inv_scale[1]
+// (a frozen weight: B operand, its factor goes into alpha).  `work` = 4 bytes of device scratch (per-tensor mode only).
+extern "C" int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, float* inv_scale, int32_t per_row, void* work,
+                           tvlStream_t stream) {
+    TVL_REQUIRE(x && out && inv_scale && (per_row || work), "tvl_h2_pack: null pointer");
+    TVL_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ldx >= K && ldx % 4 == 0, "tvl_h2_pack: need K %% 16 == 0, ldx >= K, ldx %% 4 == 0");
+    TVL_REQUIRE(tvl_aligned16(out) && tvl_aligned16(x), "tvl_h2_pack: operands must be 16-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (per_row) {
+        hipLaunchKernelGGL(h2_rowscale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, (long)ldx, (long)rows, K, inv_scale);
+    } else {
+        hipError_t e = hipMemsetAsync(work, 0, 4, s);
+        TVL_REQUIRE(e == hipSuccess, "tvl_h2_pack: memset failed: %s", hipGetErrorString(e));
+        long nb = (rows * (K / 4) + 255) / 256;
+        nb = nb > 2048 ? 2048 : nb;
+        hipLaunchKernelGGL(h2_absmax_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, reinterpret_cast<unsigned*>(work));
+        hipLaunchKernelGGL(h2_tensorscale_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<const unsigned*>(work), inv_scale);
+    }
+    const long rp = (rows + 31) / 32 * 32;
+    long nb = (rp * (K / 8) + 255) / 256;
+    nb = nb > 1048576 ? 1048576 : nb;
+    hipLaunchKernelGGL(h2_pack_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, (const float*)inv_scale, per_row,
+                       reinterpret_cast<unsigned char*>(out), rp);
+    TVL_LAUNCH_CHECK("tvl_h2_pack");
+    return 0;
+}
+
+// epilogue(alpha * a_row_scale[m] * A . B^T) over h2 operands; same argument block as tvl_gemm_tp3 (A / B are h2 images; C_tp3, if given,
+// is still a tp3 image: the consumers of this round read three bf16 pieces).  a_row_scale: [M] inverse scales of A's rows (or null);
+// alpha carries the inverse scale of B.
+extern "C" int tvl_gemm_h2(const tvlGemmTp3Args* a, const float* a_row_scale, tvlStream_t stream) {
+    TVL_REQUIRE(a != nullptr, "tvl_gemm_h2: null args");
+    TVL_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "tvl_gemm_h2: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+    TVL_REQUIRE(a->K % 32 == 0 && a->K >= 64 && a->N % 16 == 0, "tvl_gemm_h2: need K %% 32 == 0, K >= 64, N %% 16 == 0 (K=%d N=%d)", a->K, a->N);
+    TVL_REQUIRE(a->A && a->B && (a->C || a->C_tp3), "tvl_gemm_h2: null operand");
+    TVL_REQUIRE(tvl_aligned16(a->A) && tvl_aligned16(a->B), "tvl_gemm_h2: operands must be 16-byte aligned");
+    TVL_REQUIRE(a->a_rows >= a->M && a->b_rows >= a->N, "tvl_gemm_h2: operand images hold fewer rows than M / N");
+    TVL_REQUIRE(!a->C || (a->ldc >= a->N && a->ldc % 4 == 0 && tvl_aligned16(a->C)), "tvl_gemm_h2: C needs ldc >= N, ldc %% 4 == 0, 16-byte alignment");
+    TVL_REQUIRE(!a->pre_out || (a->ldc >= a->N && a->ldc % 4 == 0 && tvl_aligned16(a->pre_out)), "tvl_gemm_h2: pre_out shares ldc and needs 16-byte alignment");
+    TVL_REQUIRE(!a->C_tp3 || tvl_aligned16(a->C_tp3), "tvl_gemm_h2: C_tp3 must be 16-byte aligned");
+    TVL_REQUIRE(!a->residual || (a->ldr >= a->N && a->ldr % 4 == 0 && tvl_aligned16(a->residual)), "tvl_gemm_h2: residual needs ldr >= N, %% 4, alignment");
+    TVL_REQUIRE(!a->dact || (a->dact_aux && a->ld_aux >= a->N && a->ld_aux % 4 == 0 && tvl_aligned16(a->dact_aux)), "tvl_gemm_h2: dact needs an aligned dact_aux");
+    TVL_REQUIRE(!a->bias || tvl_aligned16(a->bias), "tvl_gemm_h2: bias must be 16-byte aligned");
+    Tp3Params p = {};
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.A = reinterpret_cast<const unsigned char*>(a->A); p.a_rb = (int)((a->a_rows + 31) / 32);
+    p.B = reinterpret_cast<const unsigned char*>(a->B); p.b_rb = (int)((a->b_rows + 31) / 32);
+    p.C = a->C; p.ldc = a->ldc; p.Cp = reinterpret_cast<unsigned char*>(a->C_tp3);
+    p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.act = a->act; p.pre_out = a->pre_out;
+    p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha; p.a_scale = a_row_scale;
+    int bm = a->tile_m;
+    if (bm != 256 && bm != 192) {
+        const long t256 = ((long)(a->M + 255) / 256) * ((a->N + 255) / 256), t192 = ((long)(a->M + 191) / 192) * ((a->N + 255) / 256);
+        bm = ((t256 + 255) / 256) * 256 < ((t192 + 255) / 256) * 192 ? 256 : 192;
+    }
+    const int rc = launch_h2(p, bm, epi_code(p), reinterpret_cast<hipStream_t>(stream));
+    TVL_REQUIRE(rc == 0, "tvl_gemm_h2: launch failed (dynamic LDS opt-in?)");
+    TVL_LAUNCH_CHECK("tvl_gemm_h2");
+    return 0;
+}

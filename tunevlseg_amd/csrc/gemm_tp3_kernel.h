@@ -34,6 +34,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -54,6 +55,7 @@ struct Tp3Params {
     float* pre_out;
     const float* dact_aux; int ld_aux; int dact;
     float alpha;
+    const float* a_scale;   // optional per-row factor of the result (two-piece fp16 operands carry power-of-two row scales), or null
     int tiles_m, tiles_n;
 };
 
@@ -90,15 +92,16 @@ __device__ __forceinline__ long tp3_off(long row, int col, int kblocks) { return
 // bit set of the options below, resolved at compile time -- the epilogue is cold, straight-line code executed once per tile, and
 // with all options live it was ~5 KB per 4-column group, 24 groups per wave: the write-out of a tile then ran at the
 // instruction-fetch rate (20 us per 192x256 tile; stamps in profiles/r2_gemm_experiments.md), not at the store rate.
-enum { E_BIAS = 1, E_RES = 2, E_QGELU = 4, E_DQGELU = 8, E_PRE = 16, E_F32 = 32, E_TP3 = 64 };
+enum { E_BIAS = 1, E_RES = 2, E_QGELU = 4, E_DQGELU = 8, E_PRE = 16, E_F32 = 32, E_TP3 = 64, E_RSCALE = 128 };
 
 template <int EPI, bool NOSTORE = false>
 __device__ __forceinline__ void emit4(const Tp3Params& p, long row, int col, float4 a) {
     constexpr bool G = EPI < 0;
     float v[4] = {a.x, a.y, a.z, a.w};
-    if (G) {
+    if (G || (EPI & E_RSCALE)) {   // alpha, and the operand row scale of the two-piece fp16 format
+        const float f = (G ? (p.a_scale != nullptr) : true) ? p.alpha * p.a_scale[row] : p.alpha;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+        for (int e = 0; e < 4; ++e) v[e] *= f;
     }
     if (G ? p.bias != nullptr : (EPI & E_BIAS) != 0) {
         const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col);
@@ -170,24 +173,26 @@ __device__ __forceinline__ void epilogue(const Tp3Params& p, f32x16 (&acc)[TM][T
 template <int INFLIGHT, bool ISSUE, bool LAST>
 struct StepMode {};
 
-template <int TM, int TN>
+template <int TM, int TN, int NP>
 struct Frags {
-    bf16x8 a[TM][3], b[TN][3];
+    bf16x8 a[TM][NP], b[TN][NP];
 };
 
 // piece q of the slab's (memory-op, MFMA) interleave: DMA pieces first, then the fragment reads of the NEXT slab
-template <int TM, int TN, int IDX>
-__device__ __forceinline__ void read_one(Frags<TM, TN>& f, unsigned a_addr, unsigned b_addr) {
-    if constexpr (IDX < 3 * TM) f.a[IDX / 3][IDX % 3] = lds_frag<IDX * PIECE>(a_addr);
-    else if constexpr (IDX < 3 * (TM + TN)) f.b[(IDX - 3 * TM) / 3][(IDX - 3 * TM) % 3] = lds_frag<(IDX - 3 * TM) * PIECE>(b_addr);
+template <int TM, int TN, int NP, int IDX>
+__device__ __forceinline__ void read_one(Frags<TM, TN, NP>& f, unsigned a_addr, unsigned b_addr) {
+    if constexpr (IDX < NP * TM) f.a[IDX / NP][IDX % NP] = lds_frag<IDX * PIECE>(a_addr);
+    else if constexpr (IDX < NP * (TM + TN)) f.b[(IDX - NP * TM) / NP][(IDX - NP * TM) % NP] = lds_frag<(IDX - NP * TM) * PIECE>(b_addr);
 }
 
-template <int TM, int TN, int... I>
-__device__ __forceinline__ void read_all(Frags<TM, TN>& f, unsigned a_addr, unsigned b_addr, std::integer_sequence<int, I...>) {
-    (read_one<TM, TN, I>(f, a_addr, b_addr), ...);
+template <int TM, int TN, int NP, int... I>
+__device__ __forceinline__ void read_all(Frags<TM, TN, NP>& f, unsigned a_addr, unsigned b_addr, std::integer_sequence<int, I...>) {
+    (read_one<TM, TN, NP, I>(f, a_addr, b_addr), ...);
 }
 
-template <int BM, int BN, int VARIANT, int EPI>
+// NP = pieces per operand element: 3 (bf16 pieces, 6 products per k-step: the tp3 format) or 2 (fp16 pieces, 3 products: the "h2" format,
+// gemm_h2.hip -- same block order, 2 KiB per 32 x 16 block, operands pre-scaled by exact powers of two)
+template <int BM, int BN, int VARIANT, int EPI, int NP = 3>
 __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     Tp3Params p = p_in;
     float* const stamp_buf = p_in.pre_out;
@@ -195,11 +200,13 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     constexpr int WGM = 2, WGN = 4;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int PA = 3 * BM / 32, PB = 3 * BN / 32, PT = PA + PB;   // 1-KiB pieces per slab
+    constexpr int BLKP = NP * PIECE;                                      // one 32 x 16 block of an operand image
+    constexpr int PA = NP * BM / 32, PB = NP * BN / 32, PT = PA + PB;   // 1-KiB pieces per slab
     constexpr int PW = (PT + NWAVE - 1) / NWAVE;                       // pieces per wave (the first PT % 8 waves carry one more)
     constexpr int STAGE = PT * PIECE;
-    constexpr int NREAD = 3 * (TM + TN);
-    constexpr int NMFMA = 6 * TM * TN;
+    constexpr int NREAD = NP * (TM + TN);
+    constexpr int NPROD = NP == 3 ? 6 : 3;   // piece products kept per k-step
+    constexpr int NMFMA = NPROD * TM * TN;
     constexpr bool PIN = (VARIANT & 1) != 0, DMA_SPREAD = (VARIANT & 2) != 0;
     // timing-only ablations (wrong results): bit 2 = no DMA inside the loop, bit 3 = every DMA re-reads slab 0 (L2-resident)
     constexpr bool ABL_NODMA = (VARIANT & 4) != 0, ABL_SLAB0 = (VARIANT & 8) != 0, ABL_NOSTORE = (VARIANT & 16) != 0;
@@ -244,14 +251,14 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     for (int i = 0; i < PW; ++i) {
         const int pc = wave + NWAVE * i;
         if (pc < PA) {
-            int rb = tile_m * (BM / 32) + pc / 3;
+            int rb = tile_m * (BM / 32) + pc / NP;
             rb = rb < p.a_rb ? rb : p.a_rb - 1;
-            src[i] = p.A + ((long)rb * KB) * BLK + (pc % 3) * PIECE;
+            src[i] = p.A + ((long)rb * KB) * BLKP + (pc % NP) * PIECE;
         } else {
             const int q = pc < PT ? pc - PA : 0;
-            int rb = tile_n * (BN / 32) + q / 3;
+            int rb = tile_n * (BN / 32) + q / NP;
             rb = rb < p.b_rb ? rb : p.b_rb - 1;
-            src[i] = p.B + ((long)rb * KB) * BLK + (q % 3) * PIECE;
+            src[i] = p.B + ((long)rb * KB) * BLKP + (q % NP) * PIECE;
         }
     }
     const unsigned lane16 = lane * 16;
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     auto issue_piece = [&](auto idx, int slab, int stage) {
         constexpr int i = decltype(idx)::value;
         const int pc = wave + NWAVE * i;
-        if ((i + 1) * NWAVE <= PT || pc < PT) glds16((src[i] + (long)(ABL_SLAB0 ? (slab & 1) : slab) * BLK) + lane16, lds0 + stage * STAGE + pc * PIECE);
+        if ((i + 1) * NWAVE <= PT || pc < PT) glds16((src[i] + (long)(ABL_SLAB0 ? (slab & 1) : slab) * BLKP) + lane16, lds0 + stage * STAGE + pc * PIECE);
     };
     auto issue = [&](int slab, int stage) {
         [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(std::integral_constant<int, I>{}, slab, stage), ...); }(std::make_integer_sequence<int, PW>{});
@@ -273,8 +280,8 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const unsigned a_frag = lds0 + lane * 16 + wm * (TM * BLK);
-    const unsigned b_frag = lds0 + lane * 16 + PA * PIECE + wn * (TN * BLK);
+    const unsigned a_frag = lds0 + lane * 16 + wm * (TM * BLKP);
+    const unsigned b_frag = lds0 + lane * 16 + PA * PIECE + wn * (TN * BLKP);
 
     // prologue: three slabs in flight, wait for the first
     issue(0, 0);
@@ -283,16 +290,17 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     wait_groups<PT>((nk < 3 ? nk : 3) - 1, extra);
     __builtin_amdgcn_s_barrier();
     stamp(1);
-    Frags<TM, TN> f0, f1;
-    read_all<TM, TN>(f0, a_frag, b_frag, std::make_integer_sequence<int, NREAD>{});
+    Frags<TM, TN, NP> f0, f1;
+    read_all<TM, TN, NP>(f0, a_frag, b_frag, std::make_integer_sequence<int, NREAD>{});
 
-    constexpr int PA_[6] = {0, 1, 2, 0, 1, 0}, PB_[6] = {2, 1, 0, 1, 0, 0};  // smallest piece products first, a1*b1 last
+    // smallest piece products first, a0*b0 last
+    constexpr int PA_[6] = {NP == 3 ? 0 : 0, 1, NP == 3 ? 2 : 0, 0, 1, 0}, PB_[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0};
 
     // One slab.  `cur` holds slab kt's fragments (requested one slab ago); unless LAST, `nxt` receives slab kt+1's.
     //   INFLIGHT: DMA groups that may stay in flight while slab kt+1 is awaited (1 in steady state, 0 near the end);
     //   ISSUE:    slab kt+3 exists and is requested into the stage slab kt has just left.
-    auto step = [&]<int INFLIGHT, bool ISSUE, bool LAST>(StepMode<INFLIGHT, ISSUE, LAST>, int kt, int st_cur, Frags<TM, TN>& cur,
-                                                         Frags<TM, TN>& nxt) {
+    auto step = [&]<int INFLIGHT, bool ISSUE, bool LAST>(StepMode<INFLIGHT, ISSUE, LAST>, int kt, int st_cur, Frags<TM, TN, NP>& cur,
+                                                         Frags<TM, TN, NP>& nxt) {
         if constexpr (!LAST && !ABL_NODMA) wait_groups<PT>(INFLIGHT, extra);   // this wave's pieces of slab kt+1 have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // `cur` is complete and this wave no longer reads stage st_cur
         if constexpr (!LAST) __builtin_amdgcn_s_barrier();        // ... nor does any other wave, and their pieces landed too
@@ -306,11 +314,16 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
         constexpr int DMA_EVERY = NMFMA / PW;
         auto body = [&](auto idx) {
             constexpr int q = decltype(idx)::value;
-            if constexpr (!LAST && q < NREAD) read_one<TM, TN, q>(nxt, a_addr, b_addr);
+            if constexpr (!LAST && q < NREAD) read_one<TM, TN, NP, q>(nxt, a_addr, b_addr);
             if constexpr (ISSUE && !ABL_NODMA && DMA_SPREAD && q % DMA_EVERY == 1 && q / DMA_EVERY < PW)
                 issue_piece(std::integral_constant<int, q / DMA_EVERY>{}, kt + 3, st_cur);
-            constexpr int pair = q % 6, ij = q / 6, i = ij / TN, j = ij % TN;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.b[j][PB_[pair]], cur.a[i][PA_[pair]], acc[i][j], 0, 0, 0);
+            constexpr int pair = q % NPROD, ij = q / NPROD, i = ij / TN, j = ij % TN;
+            if constexpr (NP == 3) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.b[j][PB_[pair]], cur.a[i][PA_[pair]], acc[i][j], 0, 0, 0);
+            } else {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.b[j][PB_[pair]]),
+                                                                   __builtin_bit_cast(f16x8, cur.a[i][PA_[pair]]), acc[i][j], 0, 0, 0);
+            }
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
         };
         if constexpr (ISSUE && !ABL_NODMA && !DMA_SPREAD) issue(kt + 3, st_cur);
@@ -354,16 +367,16 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     }
 }
 
-template <int BM, int BN, int VARIANT, int EPI>
+template <int BM, int BN, int VARIANT, int EPI, int NP = 3>
 int launch(const Tp3Params& p0, hipStream_t s) {
     Tp3Params p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    constexpr size_t stage_bytes = (size_t)3 * (3 * (BM + BN) / 32) * PIECE;
+    constexpr size_t stage_bytes = (size_t)3 * (NP * (BM + BN) / 32) * PIECE;
     constexpr size_t epi_bytes = (size_t)NWAVE * (BM / 2) * 36 * sizeof(float);
     constexpr size_t smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = gemm_tp3_kernel<BM, BN, VARIANT, EPI>;
+    auto kern = gemm_tp3_kernel<BM, BN, VARIANT, EPI, NP>;
     static int attr_dev_mask = 0;  // per device: the opt-in for > 64 KiB of dynamic LDS is a per-device function attribute
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1;
@@ -393,11 +406,11 @@ int launch_epi(const Tp3Params& p, int epi, hipStream_t s) {
 
 // compile-time epilogue code of a call, or -1 (generic) when it uses anything the specialised set does not cover
 inline int epi_code(const Tp3Params& p) {
-    if (p.alpha != 1.0f || (p.act & TVL_ACT_POST_RESIDUAL)) return -1;
+    if ((p.alpha != 1.0f && !p.a_scale) || (p.act & TVL_ACT_POST_RESIDUAL)) return -1;
     const int act = p.act & 0xff;
     if ((act != TVL_ACT_NONE && act != TVL_ACT_QUICK_GELU) || (p.dact != TVL_ACT_NONE && p.dact != TVL_ACT_QUICK_GELU)) return -1;
     return (p.bias ? E_BIAS : 0) | (p.residual ? E_RES : 0) | (act ? E_QGELU : 0) | (p.dact ? E_DQGELU : 0) | (p.pre_out ? E_PRE : 0) |
-           (p.C ? E_F32 : 0) | (p.Cp ? E_TP3 : 0);
+           (p.C ? E_F32 : 0) | (p.Cp ? E_TP3 : 0) | (p.a_scale ? E_RSCALE : 0);
 }
 
 }  // namespace

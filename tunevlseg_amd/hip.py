@@ -147,6 +147,8 @@ _SIGS = {
     "tvl_tp3_pack": [_P, _L, _L, _I, _P],
     "tvl_tp3_unpack": [_P, _L, _I, _P, _L],
     "tvl_gemm_tp3": [C.POINTER(GemmTp3Args)],
+    "tvl_h2_pack": [_P, _L, _L, _I, _P, _P, _I, _P],
+    "tvl_gemm_h2": [C.POINTER(GemmTp3Args), _P],
     "tvl_im2col3x3": [_P, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
@@ -158,7 +160,7 @@ _SIGS = {
     "tvl_dynconv_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
     "tvl_dynconv_bwd": [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
 }
-EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_dicece_work_doubles", *_SIGS]
+EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_h2_bytes", "tvl_dicece_work_doubles", *_SIGS]
 
 _lib = None
 
@@ -414,6 +416,67 @@ def tp3_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, alph
     if alpha != 1.0 or (act & ~0xFF) or epi not in _TP3_EPI_BUILT:
         epi = -1
     return f"gemm_tp3_kernel<{tile}, 256, {variant}, {epi}>"
+
+
+class H2:
+    """An fp32 matrix [rows, cols] as two fp16 pieces per element of the row- (activations) or tensor- (weights) scaled values, in
+    MFMA-fragment order (include/tvl_hip.h, "h2"): the operand format of ``tvl_gemm_h2`` -- 3 MFMAs per product instead of tp3's 6.
+    ``inv_scale``: fp32 [rows] (per row) or [1] (per tensor) exact powers of two that the GEMM's epilogue multiplies back in."""
+
+    __slots__ = ("buf", "rows", "cols", "inv_scale", "per_row", "_alpha")
+
+    def __init__(self, rows: int, cols: int, device, per_row: bool):
+        if cols % 16:
+            raise RuntimeError(f"h2 needs cols % 16 == 0, got {cols}")
+        self.rows, self.cols, self.per_row = rows, cols, per_row
+        n = (rows + 31) // 32 * (cols // 16) * 2048
+        self.buf = (torch.zeros if rows % 32 else torch.empty)(n, device=device, dtype=torch.uint8)
+        self.inv_scale = torch.empty(rows if per_row else 1, device=device, dtype=torch.float32)
+        self._alpha = None   # host copy of a per-tensor inverse scale, read once (frozen weights)
+
+    @property
+    def shape(self):
+        return (self.rows, self.cols)
+
+    def alpha(self) -> float:
+        """Per-tensor inverse scale as a host float (one device read per weight image, then cached)."""
+        if self._alpha is None:
+            self._alpha = float(self.inv_scale[0].item())
+        return self._alpha
+
+
+def h2_pack(x2d: torch.Tensor, per_row: bool) -> H2:
+    """fp32 [rows, cols] -> H2 (per_row: activations, the A operand; per tensor: frozen weights, the B operand)."""
+    rows, cols = x2d.shape
+    out = H2(rows, cols, x2d.device, per_row)
+    work = None if per_row else torch.zeros(1, device=x2d.device, dtype=torch.int32)
+    _call("tvl_h2_pack", _ps(x2d), x2d.stride(0), rows, cols, out.buf.data_ptr(), _p(out.inv_scale), 1 if per_row else 0,
+          None if work is None else work.data_ptr())
+    return out
+
+
+def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = None, out_tp3: Tp3 | None = None, want_f32=True,
+            want_tp3=False, bias=None, residual=None, act=ACT_NONE, pre_out=None, tile_m: int = 0):
+    """epilogue(A . B^T) over h2 operands (A row-scaled, B tensor-scaled); returns (C fp32 or None, C as Tp3 or None)."""
+    M = A.rows if M is None else M
+    N, K = B.rows, A.cols
+    if B.cols != K or not A.per_row or B.per_row:
+        raise RuntimeError(f"gemm_h2: need A {A.shape} per-row scaled and B {B.shape} per-tensor scaled with equal K")
+    dev = A.buf.device
+    Cf = out if out is not None else (torch.empty((M, N), device=dev, dtype=torch.float32) if want_f32 else None)
+    Ct = out_tp3 if out_tp3 is not None else (Tp3(M, N, dev) if want_tp3 else None)
+    ldc = Cf.stride(0) if Cf is not None else (pre_out.stride(0) if pre_out is not None else N)
+    args = GemmTp3Args(M, N, K, A.buf.data_ptr(), A.rows, B.buf.data_ptr(), B.rows, _ps(Cf), ldc, None if Ct is None else Ct.buf.data_ptr(),
+                       _p(bias), _ps(residual), 0 if residual is None else residual.stride(0), act, _ps(pre_out), None, 0, ACT_NONE,
+                       B.alpha(), tile_m, 0)
+    if _gemm_prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _call("tvl_gemm_h2", C.byref(args), _p(A.inv_scale))
+    if _gemm_prof is not None:
+        e1.record()
+        _gemm_prof.append((f"gemm_h2<{tile_m or 'auto'}>", 2.0 * M * N * K, e0, e1))
+    return Cf, Ct
 
 
 def tp3_tile(M: int, N: int) -> int:
