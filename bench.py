@@ -253,7 +253,8 @@ def main():
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         gemm_ms = sum(v["ms"] for v in prof.values()) / 2
         split = "bf16s" in name or "tp3" in name
-        peak = MODE_PEAK[hip.GEMM_MODE] if split else PEAK_F32_MFMA_TFLOPS
+        two_piece = name.endswith(", 2>")   # the h2 format: two fp16 pieces, 3 MFMAs per fp32 product
+        peak = (PEAK_BF16_MFMA_TFLOPS / 3 if two_piece else MODE_PEAK[hip.GEMM_MODE]) if split else PEAK_F32_MFMA_TFLOPS
         # HBM bytes per launch of that kernel: recorded by two separate rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE; FETCH_SIZE
         # doubled per the gfx950 note of MI355X_MICROARCH.md §HBM) and committed under profiles/.  It is a RECORDED number: reported
         # only when the record names the same kernel instantiation, and always with the file and commit it came from.
@@ -267,7 +268,8 @@ def main():
                 traffic_source = {"file": str(tf.relative_to(ROOT)), "recorded_at_commit": rec_all.get("commit"), "kind": "recorded (rocprofv3 --pmc), not measured by this run"}
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "kernel": name,
-                    "peak_note": "algorithmic fp32 FLOP/s ceiling = dense bf16 MFMA peak (2.5 PFLOP/s) / 6 MFMAs per fp32 product" if split
+                    "peak_note": ("algorithmic fp32 FLOP/s ceiling = dense fp16 MFMA peak (2.5 PFLOP/s) / 3 MFMAs per fp32 product" if two_piece else
+                                  "algorithmic fp32 FLOP/s ceiling = dense bf16 MFMA peak (2.5 PFLOP/s) / 6 MFMAs per fp32 product") if split
                     else "dense f32-input MFMA peak",
                     "launches_per_step": d["launches"] // 2, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1),
                     "flops_per_launch": round(d["flops"] / d["launches"]), "all_gemm_ms_per_step": round(gemm_ms, 2),

@@ -300,6 +300,11 @@ int tvl_gemm_tp3(const tvlGemmTp3Args* args, tvlStream_t stream);
 int64_t tvl_h2_bytes(int64_t rows, int32_t K);
 int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, float* inv_scale, int32_t per_row, void* work, tvlStream_t stream);
 int tvl_gemm_h2(const tvlGemmTp3Args* args, const float* a_row_scale, tvlStream_t stream);
+/* LayerNorm forward / backward writing their result as an h2 operand (+ inv_scale[rows]); otherwise as tvl_layernorm_fwd_tp3 / _bwd_tp3 */
+int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const float* beta, void* y_h2, float* inv_scale, float* mean, float* rstd,
+                         int64_t rows, int32_t cols, float eps, tvlStream_t stream);
+int tvl_layernorm_bwd_h2(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres,
+                         float* dx, void* dx_h2, float* inv_scale, int64_t rows, int32_t cols, tvlStream_t stream);
 
 /* nn.AvgPool2d(k) / F.avg_pool2d(x, k, k) on [B,H,W,C] (H, W divisible by k) and its gradient (H, W = input sizes) */
 int tvl_avgpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);

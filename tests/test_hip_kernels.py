@@ -567,3 +567,55 @@ def test_dropout_statistics_and_reproducibility(hip):
     blk = (a == 0).double().view(-1, 64).mean(1)
     assert abs(blk.var().item() - p * (1 - p) / 64) < 0.1 * p * (1 - p) / 64
     assert torch.equal(hip.dropout(x, 0.0, 7), x)
+
+
+@pytest.mark.parametrize("rows,cols", [(100, 64), (32, 768), (495, 768)])
+def test_h2_pack_round_trip_and_scales(hip, rows, cols):
+    """Two fp16 pieces of the power-of-two scaled value: 22 significand bits per element relative to its ROW maximum (per-row mode)
+    or TENSOR maximum, exact power-of-two scales that put the largest magnitude in [2^13, 2^14)."""
+    x = rnd(rows, cols, seed=4) * torch.logspace(-6, 2, rows)[:, None]   # rows spanning eight decades, as gradients do
+    for per_row in (True, False):
+        t = hip.h2_pack(dev(x), per_row)
+        inv = t.inv_scale.cpu()
+        assert torch.equal(inv, torch.exp2(torch.round(torch.log2(inv))))   # exact powers of two
+        top = (x.abs().amax(1) if per_row else x.abs().max().reshape(1)) / inv
+        assert (top >= 2.0**13).all() and (top < 2.0**14).all()
+        err = (t.float().cpu() - x).abs()
+        bound = (x.abs().amax(1, keepdim=True) if per_row else x.abs().max()) * 2.0**-21
+        assert (err <= bound).all(), (err / bound).max()
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (495, 512, 3072), (33, 256, 64)])
+def test_gemm_h2_matches_fp64(hip, M, N, K):
+    """tvl_gemm_h2: three fp16-piece products per k-step, row scales of A and the tensor scale of B undone in the epilogue."""
+    a = rnd(M, K, seed=5) * torch.logspace(-5, 1, M)[:, None]
+    b = rnd(N, K, seed=6) * 0.03
+    bias = rnd(N, seed=7)
+    ref = a.double() @ b.double().T + bias.double()
+    den = a.abs().double() @ b.abs().double().T + bias.abs().double()
+    A, B = hip.h2_pack(dev(a), True), hip.h2_pack(dev(b), False)
+    c, _ = hip.gemm_h2(A, B, bias=dev(bias))
+    assert ((c.cpu().double() - ref).abs() / den).max().item() < 2e-6
+    c3, _ = hip.gemm_tp3(hip.tp3_pack(dev(a)), hip.tp3_pack(dev(b)), bias=dev(bias))
+    e2, e3 = ((c.cpu().double() - ref) / den).pow(2).mean().sqrt().item(), ((c3.cpu().double() - ref) / den).pow(2).mean().sqrt().item()
+    assert e2 < 3 * e3 + 1e-9, (e2, e3)   # as accurate as the six-product bf16 scheme
+    # tp3 output of the same call (what the attention / fc2 consume)
+    _, ct = hip.gemm_h2(A, B, bias=dev(bias), want_f32=False, want_tp3=True)
+    assert torch.equal(ct.float(), c)
+
+
+def test_layernorm_h2_forward_and_backward(hip):
+    rows, cols = 495, 768
+    x, dy, dres = rnd(rows, cols, seed=8) * 3 + 0.5, rnd(rows, cols, seed=9) * torch.logspace(-7, -3, rows)[:, None], rnd(rows, cols, seed=10) * 1e-6
+    g, b = 1 + 0.1 * rnd(cols, seed=11), 0.1 * rnd(cols, seed=12)
+    y_ref = torch.nn.functional.layer_norm(x.double(), (cols,), g.double(), b.double(), 1e-5)
+    y, mean, rstd = hip.layernorm_fwd_h2(dev(x), dev(g), dev(b), 1e-5)
+    err = (y.float().cpu().double() - y_ref).abs()
+    assert (err <= y_ref.abs().amax(1, keepdim=True) * 2.0**-20).all()
+    y3, mean3, rstd3 = hip.layernorm_fwd_tp3(dev(x), dev(g), dev(b), 1e-5)
+    assert torch.equal(mean, mean3) and torch.equal(rstd, rstd3)
+    dx, dxt = hip.layernorm_bwd_h2(dev(dy), dev(x), dev(g), mean, rstd, dres=dev(dres))
+    dx3, _ = hip.layernorm_bwd_tp3(dev(dy), dev(x), dev(g), mean, rstd, dres=dev(dres))
+    assert torch.equal(dx, dx3)   # the fp32 result is the same kernel code
+    e = (dxt.float() - dx).abs()
+    assert (e <= dx.abs().amax(1, keepdim=True) * 2.0**-20).all()

@@ -15,12 +15,7 @@ namespace {
 
 constexpr int BLK2 = 2 * PIECE;
 
-__device__ __forceinline__ float pow2_scale_inv(float amax) {   // 1 / s, s = power of two with amax * s in [2^13, 2^14)
-    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
-    int e;
-    frexpf(amax, &e);               // amax = m * 2^e, m in [0.5, 1)
-    return ldexpf(1.0f, e - 14);    // s = 2^(14 - e)
-}
+__device__ __forceinline__ float pow2_scale_inv(float amax) { return h2::inv_scale_of(amax); }
 
 // per-row maxima -> inverse scales [rows]; one wave per row
 __global__ __launch_bounds__(256) void h2_rowscale_kernel(const float* __restrict__ x, long ldx, long rows, int K, float* __restrict__ inv_scale) {
@@ -93,11 +88,13 @@ int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
         switch (epi) {
             case E_BIAS | E_QGELU | E_PRE | E_TP3 | E_RSCALE: return launch<256, 256, 2, E_BIAS | E_QGELU | E_PRE | E_TP3 | E_RSCALE, 2>(p, s);
             case E_BIAS | E_QGELU | E_TP3 | E_RSCALE: return launch<256, 256, 2, E_BIAS | E_QGELU | E_TP3 | E_RSCALE, 2>(p, s);
+            case E_DQGELU | E_TP3 | E_RSCALE: return launch<256, 256, 2, E_DQGELU | E_TP3 | E_RSCALE, 2>(p, s);   // dz of the backward
             default: return launch<256, 256, 2, -1, 2>(p, s);
         }
     }
     switch (epi) {
         case E_BIAS | E_TP3 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_TP3 | E_RSCALE, 2>(p, s);
+        case E_TP3 | E_RSCALE: return launch<192, 256, 3, E_TP3 | E_RSCALE, 2>(p, s);                                 // dO of the backward
         case E_BIAS | E_F32 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_F32 | E_RSCALE, 2>(p, s);
         case E_F32 | E_RSCALE: return launch<192, 256, 3, E_F32 | E_RSCALE, 2>(p, s);
         default: return launch<192, 256, 3, -1, 2>(p, s);
@@ -164,7 +161,7 @@ extern "C" int tvl_gemm_h2(const tvlGemmTp3Args* a, const float* a_row_scale, tv
     int bm = a->tile_m;
     if (bm != 256 && bm != 192) {
         const long t256 = ((long)(a->M + 255) / 256) * ((a->N + 255) / 256), t192 = ((long)(a->M + 191) / 192) * ((a->N + 255) / 256);
-        bm = ((t256 + 255) / 256) * 256 < ((t192 + 255) / 256) * 192 ? 256 : 192;
+        bm = ((t256 + 255) / 256) * 256 <= ((t192 + 255) / 256) * 192 ? 256 : 192;   // rounds x rows per tile; ties go to the larger tile
     }
     const int rc = launch_h2(p, bm, epi_code(p), reinterpret_cast<hipStream_t>(stream));
     TVL_REQUIRE(rc == 0, "tvl_gemm_h2: launch failed (dynamic LDS opt-in?)");

@@ -163,12 +163,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // piece per store instruction (fully coalesced).  The fp32 result is never materialised: its only consumer is the GEMM.
 // NW waves per workgroup: 16 (two rows per wave in phase 1) keeps ~31 waves per CU in flight at 495 row blocks; with 4 the
 // kernel ran at 8 waves per CU and a third of the HBM rate.
-template <int LN_MAXV, int NW>
+// NP = 3: tp3 output (three bf16 pieces).  NP = 2: h2 output (two fp16 pieces of the row scaled by a power of two, tp3.h): phase 1 also
+// finds the row's largest |y| and writes the inverse scale to inv_scale[row] for the consuming GEMM's epilogue.
+template <int LN_MAXV, int NW, int NP = 3>
 __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, unsigned char* __restrict__ out,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows, int cols,
-                                                         float eps) {
-    __shared__ float s_mean[32], s_rstd[32];
+                                                         float eps, float* __restrict__ inv_scale) {
+    __shared__ float s_mean[32], s_rstd[32], s_scale[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rb = blockIdx.x;
     const float inv_n = 1.0f / (float)cols;
@@ -204,7 +206,23 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
                 if (mean_out) mean_out[row] = mean;
                 if (rstd_out) rstd_out[row] = rstd;
             }
-        }
+            if constexpr (NP == 2) {
+                float amax = 0.f;
+#pragma unroll
+                for (int i = 0; i < LN_MAXV; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < nv) {
+                        const float4 g4 = reinterpret_cast<const float4*>(gamma)[c];
+                        const float4 b4 = beta ? reinterpret_cast<const float4*>(beta)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        amax = fmaxf(fmaxf(amax, fmaxf(fabsf((v[i].x - mean) * rstd * g4.x + b4.x), fabsf((v[i].y - mean) * rstd * g4.y + b4.y))),
+                                     fmaxf(fabsf((v[i].z - mean) * rstd * g4.z + b4.z), fabsf((v[i].w - mean) * rstd * g4.w + b4.w)));
+                    }
+                }
+                amax = wave_max(amax);
+                const float inv = h2::inv_scale_of(amax);
+                if (lane == 0) { inv_scale[row] = inv; s_scale[rl] = 1.0f / inv; }
+            }
+        } else if (NP == 2 && lane == 0) s_scale[rl] = 1.0f;
         if (lane == 0) { s_mean[rl] = mean; s_rstd[rl] = rstd; }
     }
     __syncthreads();
@@ -229,29 +247,45 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = 0.f;
         }
-        uint4 pl[3];
-        tp3::split8(v, pl);
-        unsigned char* o = out + (rb * KB + kb) * (long)tp3::BLK + lane * 16;
+        if constexpr (NP == 3) {
+            uint4 pl[3];
+            tp3::split8(v, pl);
+            unsigned char* o = out + (rb * KB + kb) * (long)tp3::BLK + lane * 16;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(o + s * tp3::PIECE) = pl[s];
+            for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(o + s * tp3::PIECE) = pl[s];
+        } else {
+            const float sc = s_scale[r];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= sc;
+            uint4 pl[2];
+            h2::split8(v, pl);
+            unsigned char* o = out + (rb * KB + kb) * (long)h2::BLK + lane * 16;
+            *reinterpret_cast<uint4*>(o) = pl[0];
+            *reinterpret_cast<uint4*>(o + h2::PIECE) = pl[1];
+        }
     }
 }
 
 // LayerNorm backward (+ residual gradient) writing dx twice: fp32 (the residual stream's gradient, read by the next
 // LayerNorm backward) and tp3 (the A operand of the next data-gradient GEMM).  Phase 1 = ln_bwd_kernel's row pass; phase 2
 // re-reads the block's fresh dx rows (this CU's own stores, drained and fenced) in fragment order.
-template <int LN_MAXV, int NW>
+template <int LN_MAXV, int NW, int NP = 3>
 __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const float* __restrict__ dres, float* __restrict__ dx, unsigned char* __restrict__ out,
-                                                         long rows, int cols) {
+                                                         long rows, int cols, float* __restrict__ inv_scale) {
+    __shared__ float s_scale[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rb = blockIdx.x;
     const float inv_n = 1.0f / (float)cols;
     const int nv = cols >> 2;
     for (int rr = 0; rr < 32 / NW; ++rr) {
         const long row = rb * 32 + wave * (32 / NW) + rr;
-        if (row >= rows) break;
+        if (row >= rows) {
+            if (NP == 2 && lane == 0) s_scale[wave * (32 / NW) + rr] = 1.0f;
+            continue;
+        }
+        float amax = 0.f;
         const float* xr = x + row * cols;
         const float* dyr = dy + row * cols;
         float* dxr = dx + row * cols;
@@ -287,7 +321,13 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
                     o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
                 }
                 reinterpret_cast<float4*>(dxr)[c] = o;
+                if constexpr (NP == 2) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             }
+        }
+        if constexpr (NP == 2) {
+            amax = wave_max(amax);
+            const float inv = h2::inv_scale_of(amax);
+            if (lane == 0) { inv_scale[row] = inv; s_scale[wave * (32 / NW) + rr] = 1.0f / inv; }
         }
     }
     // the block's dx rows are re-read by other waves of this workgroup: drain the stores, then make them visible (the lines
@@ -310,11 +350,22 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = 0.f;
         }
-        uint4 pl[3];
-        tp3::split8(v, pl);
-        unsigned char* o = out + (rb * KB + kb) * (long)tp3::BLK + lane * 16;
+        if constexpr (NP == 3) {
+            uint4 pl[3];
+            tp3::split8(v, pl);
+            unsigned char* o = out + (rb * KB + kb) * (long)tp3::BLK + lane * 16;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(o + s * tp3::PIECE) = pl[s];
+            for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(o + s * tp3::PIECE) = pl[s];
+        } else {
+            const float sc = s_scale[r];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= sc;
+            uint4 pl[2];
+            h2::split8(v, pl);
+            unsigned char* o = out + (rb * KB + kb) * (long)h2::BLK + lane * 16;
+            *reinterpret_cast<uint4*>(o) = pl[0];
+            *reinterpret_cast<uint4*>(o + h2::PIECE) = pl[1];
+        }
     }
 }
 
@@ -359,8 +410,8 @@ extern "C" int tvl_layernorm_fwd_tp3(const float* x, const float* gamma, const f
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(y_tp3);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps);
-    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr);
+    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr);
     TVL_LAUNCH_CHECK("tvl_layernorm_fwd_tp3");
     return 0;
 }
@@ -374,8 +425,39 @@ extern "C" int tvl_layernorm_bwd_tp3(const float* dy, const float* x, const floa
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(dx_tp3);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols);
-    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr);
+    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr);
     TVL_LAUNCH_CHECK("tvl_layernorm_bwd_tp3");
     return 0;
 }
+
+// The same two kernels writing the h2 operand format (two fp16 pieces of the row scaled by a power of two) + the rows' inverse scales.
+extern "C" int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const float* beta, void* y_h2, float* inv_scale, float* mean, float* rstd,
+                                    int64_t rows, int32_t cols, float eps, tvlStream_t stream) {
+    TVL_REQUIRE(x && gamma && y_h2 && inv_scale, "tvl_layernorm_fwd_h2: null pointer");
+    TVL_REQUIRE(rows > 0 && cols > 0 && cols % 16 == 0 && cols <= 2048, "tvl_layernorm_fwd_h2: need cols %% 16 == 0 and cols <= 2048 (rows=%ld cols=%d)", (long)rows, cols);
+    TVL_REQUIRE(tvl_aligned16(x) && tvl_aligned16(y_h2) && tvl_aligned16(gamma) && (!beta || tvl_aligned16(beta)), "tvl_layernorm_fwd_h2: operands must be 16-byte aligned");
+    const unsigned grid = (unsigned)((rows + 31) / 32);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned char* out = reinterpret_cast<unsigned char*>(y_h2);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale);
+    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale);
+    TVL_LAUNCH_CHECK("tvl_layernorm_fwd_h2");
+    return 0;
+}
+
+extern "C" int tvl_layernorm_bwd_h2(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                    const float* dres, float* dx, void* dx_h2, float* inv_scale, int64_t rows, int32_t cols, tvlStream_t stream) {
+    TVL_REQUIRE(dy && x && gamma && mean && rstd && dx && dx_h2 && inv_scale, "tvl_layernorm_bwd_h2: null pointer");
+    TVL_REQUIRE(rows > 0 && cols > 0 && cols % 16 == 0 && cols <= 2048, "tvl_layernorm_bwd_h2: need cols %% 16 == 0 and cols <= 2048 (rows=%ld cols=%d)", (long)rows, cols);
+    TVL_REQUIRE(tvl_aligned16(x) && tvl_aligned16(dy) && tvl_aligned16(dx) && tvl_aligned16(dx_h2) && tvl_aligned16(gamma) && (!dres || tvl_aligned16(dres)),
+                "tvl_layernorm_bwd_h2: operands must be 16-byte aligned");
+    const unsigned grid = (unsigned)((rows + 31) / 32);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned char* out = reinterpret_cast<unsigned char*>(dx_h2);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale);
+    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale);
+    TVL_LAUNCH_CHECK("tvl_layernorm_bwd_h2");
+    return 0;
+}
+

@@ -73,3 +73,31 @@ __device__ __forceinline__ void store4(unsigned char* __restrict__ img, int kblo
 }
 
 }  // namespace tp3
+
+// "h2": two fp16 pieces of the value scaled by an exact power of two (csrc/gemm_h2.hip); same block order as tp3, 2 KiB per block.
+namespace h2 {
+
+constexpr int PIECE = 1024;
+constexpr int BLK = 2 * PIECE;
+
+// 1 / s for the power of two s that puts amax * s in [2^13, 2^14) (1 for a zero / non-finite maximum)
+__device__ __forceinline__ float inv_scale_of(float amax) {
+    if (!(amax > 1.0e-30f) || !(amax < 3.0e38f)) return 1.0f;   // (a row that small is left unscaled: its pieces are subnormal noise either way)
+    int e;
+    frexpf(amax, &e);               // amax = m * 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, e - 14);    // s = 2^(14 - e)
+}
+// 8 consecutive k-elements (already scaled) -> 2 pieces of 16 bytes: h0 = fp16(x), h1 = fp16(x - h0)
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[2]) {
+    _Float16 h0[8], h1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h0[e] = (_Float16)v[e];
+        h1[e] = (_Float16)(v[e] - (float)h0[e]);
+    }
+    out[0] = *reinterpret_cast<const uint4*>(h0);
+    out[1] = *reinterpret_cast<const uint4*>(h1);
+}
+
+}  // namespace h2
+

@@ -149,6 +149,8 @@ _SIGS = {
     "tvl_gemm_tp3": [C.POINTER(GemmTp3Args)],
     "tvl_h2_pack": [_P, _L, _L, _I, _P, _P, _I, _P],
     "tvl_gemm_h2": [C.POINTER(GemmTp3Args), _P],
+    "tvl_layernorm_fwd_h2": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F],
+    "tvl_layernorm_bwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
     "tvl_im2col3x3": [_P, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
@@ -415,7 +417,7 @@ def tp3_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, alph
           (32 if c_f32 else 0) | (64 if c_tp3 else 0)
     if alpha != 1.0 or (act & ~0xFF) or epi not in _TP3_EPI_BUILT:
         epi = -1
-    return f"gemm_tp3_kernel<{tile}, 256, {variant}, {epi}>"
+    return f"gemm_tp3_kernel<{tile}, 256, {variant}, {epi}, 3>"
 
 
 class H2:
@@ -438,6 +440,13 @@ class H2:
     def shape(self):
         return (self.rows, self.cols)
 
+    def float(self) -> torch.Tensor:
+        """Back to fp32: (h0 + h1) * inverse scale.  Tests and debugging (plain tensor ops on the byte image)."""
+        RB, KB = (self.rows + 31) // 32, self.cols // 16
+        h = self.buf.view(torch.float16).view(RB, KB, 2, 2, 32, 8).float().sum(2)   # [rb, kb, k-half, row, 8]
+        x = h.permute(0, 3, 1, 2, 4).reshape(RB * 32, self.cols)[: self.rows]
+        return x * (self.inv_scale[:, None] if self.per_row else self.inv_scale)
+
     def alpha(self) -> float:
         """Per-tensor inverse scale as a host float (one device read per weight image, then cached)."""
         if self._alpha is None:
@@ -456,7 +465,7 @@ def h2_pack(x2d: torch.Tensor, per_row: bool) -> H2:
 
 
 def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = None, out_tp3: Tp3 | None = None, want_f32=True,
-            want_tp3=False, bias=None, residual=None, act=ACT_NONE, pre_out=None, tile_m: int = 0):
+            want_tp3=False, bias=None, residual=None, act=ACT_NONE, pre_out=None, dact_aux=None, dact=ACT_NONE, tile_m: int = 0):
     """epilogue(A . B^T) over h2 operands (A row-scaled, B tensor-scaled); returns (C fp32 or None, C as Tp3 or None)."""
     M = A.rows if M is None else M
     N, K = B.rows, A.cols
@@ -467,16 +476,33 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
     Ct = out_tp3 if out_tp3 is not None else (Tp3(M, N, dev) if want_tp3 else None)
     ldc = Cf.stride(0) if Cf is not None else (pre_out.stride(0) if pre_out is not None else N)
     args = GemmTp3Args(M, N, K, A.buf.data_ptr(), A.rows, B.buf.data_ptr(), B.rows, _ps(Cf), ldc, None if Ct is None else Ct.buf.data_ptr(),
-                       _p(bias), _ps(residual), 0 if residual is None else residual.stride(0), act, _ps(pre_out), None, 0, ACT_NONE,
-                       B.alpha(), tile_m, 0)
+                       _p(bias), _ps(residual), 0 if residual is None else residual.stride(0), act, _ps(pre_out), _ps(dact_aux),
+                       0 if dact_aux is None else dact_aux.stride(0), dact, B.alpha(), tile_m, 0)
     if _gemm_prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _call("tvl_gemm_h2", C.byref(args), _p(A.inv_scale))
     if _gemm_prof is not None:
         e1.record()
-        _gemm_prof.append((f"gemm_h2<{tile_m or 'auto'}>", 2.0 * M * N * K, e0, e1))
+        _gemm_prof.append((h2_kernel_name(M, N, bias is not None, residual is not None, act, dact, pre_out is not None, Cf is not None,
+                                          Ct is not None, tile_m), 2.0 * M * N * K, e0, e1))
     return Cf, Ct
+
+
+_H2_EPI_BUILT = {192: {193, 161, 160, 192}, 256: {213, 197, 200}}   # launch_h2's compile-time epilogues per row tile (csrc/gemm_h2.hip)
+
+
+def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_m=0) -> str:
+    """Instantiation tvl_gemm_h2 launches, spelled as rocprofv3 prints it (NP = 2 as the last template argument)."""
+    tile = tile_m
+    if tile not in (192, 256):
+        t256, t192 = -(-M // 256) * -(-N // 256), -(-M // 192) * -(-N // 256)
+        tile = 256 if -(-t256 // 256) * 256 <= -(-t192 // 256) * 192 else 192
+    epi = (1 if bias else 0) | (2 if residual else 0) | (4 if (act & 0xFF) else 0) | (8 if dact else 0) | (16 if pre_out else 0) | \
+          (32 if c_f32 else 0) | (64 if c_tp3 else 0) | 128
+    if (act & ~0xFF) or epi not in _H2_EPI_BUILT[tile]:
+        epi = -1
+    return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2>"
 
 
 def tp3_tile(M: int, N: int) -> int:
@@ -591,6 +617,25 @@ def layernorm_fwd_tp3(x2d, gamma, beta, eps: float, want_stats=True):
     return y, mean, rstd
 
 
+def layernorm_fwd_h2(x2d, gamma, beta, eps: float, want_stats=True):
+    """LayerNorm whose only consumer is an h2 GEMM: returns (H2 image of y with per-row scales, mean, rstd)."""
+    rows, cols = x2d.shape
+    y = H2(rows, cols, x2d.device, per_row=True)
+    mean = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
+    rstd = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
+    _call("tvl_layernorm_fwd_h2", _p(x2d), _p(gamma), _p(beta), y.buf.data_ptr(), _p(y.inv_scale), _p(mean), _p(rstd), rows, cols, float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd_h2(dy2d, x2d, gamma, mean, rstd, dres=None):
+    """dx = [dres +] LN'(dy) as fp32 (the residual stream's gradient) AND as the H2 operand of the next data-gradient GEMM."""
+    rows, cols = x2d.shape
+    dx = torch.empty_like(x2d)
+    dxt = H2(rows, cols, x2d.device, per_row=True)
+    _call("tvl_layernorm_bwd_h2", _p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), dxt.buf.data_ptr(), _p(dxt.inv_scale), rows, cols)
+    return dx, dxt
+
+
 def layernorm_bwd_tp3(dy2d, x2d, gamma, mean, rstd, dres=None):
     """dx = [dres +] LN'(dy) as fp32 (the residual stream's gradient) AND as the Tp3 operand of the next data-gradient GEMM."""
     rows, cols = x2d.shape
@@ -600,6 +645,7 @@ def layernorm_bwd_tp3(dy2d, x2d, gamma, mean, rstd, dres=None):
     return dx, dxt
 
 
+GEMM_H2 = os.environ.get("TVL_GEMM_H2", "1") != "0"   # the four LayerNorm-fed GEMMs of a tp3 layer on two fp16 pieces (3 MFMAs per product)
 ATTN_TP3 = os.environ.get("TVL_ATTN_TP3", "1") != "0"   # 0: attention of the tp3 layers on the fp32-operand kernels (A/B switch)
 TP3_MIN_ROWS = int(os.environ.get("TVL_TP3_MIN_ROWS", "1024"))  # below this the layer is launch-latency bound either way
 

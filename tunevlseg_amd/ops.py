@@ -37,6 +37,7 @@ class LayerWeights:
     w1_t: torch.Tensor | None = None
     w2_t: torch.Tensor | None = None
     _tp3: dict | None = None
+    _h2: dict | None = None
 
     def tp3(self) -> dict:
         """The eight weight operands of the layer's tp3 GEMMs (forward: W as stored [N, K]; data gradients: W^T), packed once."""
@@ -47,6 +48,16 @@ class LayerWeights:
                 ("wqkv_t", self.wqkv_t if self.wqkv_t is not None else t(self.wqkv)), ("wo_t", self.wo_t if self.wo_t is not None else t(self.wo)),
                 ("w1_t", self.w1_t if self.w1_t is not None else t(self.w1)), ("w2_t", self.w2_t if self.w2_t is not None else t(self.w2)))}
         return self._tp3
+
+    def h2(self) -> dict:
+        """Two-piece fp16 images (per-tensor power-of-two scale) of the four weights whose GEMMs take a LayerNorm-produced A operand:
+        QKV and fc1 forward, the out-projection and fc2 data gradients (W^T)."""
+        if self._h2 is None:
+            t = lambda w: w.detach().t().contiguous()  # noqa: E731
+            self._h2 = {k: hip.h2_pack(w.detach().contiguous(), per_row=False) for k, w in (
+                ("wqkv", self.wqkv), ("w1", self.w1),
+                ("wo_t", self.wo_t if self.wo_t is not None else t(self.wo)), ("w2_t", self.w2_t if self.w2_t is not None else t(self.w2)))}
+        return self._h2
 
 
 @dataclass
@@ -89,9 +100,15 @@ class EncoderLayerTp3Fn(Fn):
         need = ctx.needs_input_grad[0]
         W = lw.tp3()
         h2d = h.view(M, D)
-        x1, mean1, rstd1 = hip.layernorm_fwd_tp3(h2d, lw.ln1_w, lw.ln1_b, spec.eps, want_stats=need)
+        # the GEMMs whose A operand a LayerNorm kernel writes run on two fp16 pieces (3 MFMAs per product instead of 6): that producer has
+        # the whole row, hence its exact power-of-two scale (hip.GEMM_H2, csrc/gemm_h2.hip)
+        use_h2 = hip.GEMM_H2 and hip.ATTN_TP3
+        ln_fwd = hip.layernorm_fwd_h2 if use_h2 else hip.layernorm_fwd_tp3
+        gemm_ln = hip.gemm_h2 if use_h2 else hip.gemm_tp3
+        WL = lw.h2() if use_h2 else W
+        x1, mean1, rstd1 = ln_fwd(h2d, lw.ln1_w, lw.ln1_b, spec.eps, want_stats=need)
         if hip.ATTN_TP3:   # Q | K | V never exist in fp32: the attention kernels read the GEMM epilogue's tp3 image by LDS-DMA
-            _, qkv_t = hip.gemm_tp3(x1, W["wqkv"], want_f32=False, want_tp3=True, bias=lw.bqkv)
+            _, qkv_t = gemm_ln(x1, WL["wqkv"], want_f32=False, want_tp3=True, bias=lw.bqkv)
             o, lse = hip.attn_tp3_fwd(qkv_t, B, T, H, dh**-0.5, want_lse=need)
             qkv = qkv_t.buf
         else:
@@ -99,9 +116,9 @@ class EncoderLayerTp3Fn(Fn):
             o, lse = hip.attn_fwd_packed_tp3(qkv, B, T, H, dh, dh**-0.5, want_lse=need)
         del x1
         h2, _ = hip.gemm_tp3(o, W["wo"], bias=lw.bo, residual=h2d)
-        x2, mean2, rstd2 = hip.layernorm_fwd_tp3(h2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
+        x2, mean2, rstd2 = ln_fwd(h2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
         z = torch.empty((M, lw.w1.shape[0]), device=h.device, dtype=torch.float32) if need else None
-        _, a = hip.gemm_tp3(x2, W["w1"], want_f32=False, want_tp3=True, bias=lw.b1, act=spec.act, pre_out=z)
+        _, a = gemm_ln(x2, WL["w1"], want_f32=False, want_tp3=True, bias=lw.b1, act=spec.act, pre_out=z)
         del x2
         out = torch.empty((B, T, D), device=h.device, dtype=torch.float32)  # a base tensor: deep prompts overwrite rows in place
         hip.gemm_tp3(a, W["w2"], out=out.view(M, D), bias=lw.b2, residual=h2)
@@ -120,15 +137,21 @@ class EncoderLayerTp3Fn(Fn):
         dh = D // H
         W = lw.tp3()
         dout2d = _c(dout).view(M, D)
-        dout_t = _tp3_of(dout) or hip.tp3_pack(dout2d)   # attached by the layer above's LayerNorm backward, unless autograd summed into it
-        _, dz = hip.gemm_tp3(dout_t, W["w2_t"], want_f32=False, want_tp3=True, dact=spec.act, dact_aux=z)
+        use_h2 = hip.GEMM_H2 and hip.ATTN_TP3
+        gemm_ln = hip.gemm_h2 if use_h2 else hip.gemm_tp3
+        ln_bwd = hip.layernorm_bwd_h2 if use_h2 else hip.layernorm_bwd_tp3
+        WL = lw.h2() if use_h2 else W
+        dout_t = _tp3_of(dout)   # attached by the layer above's LayerNorm backward, unless autograd summed into it
+        if dout_t is None or isinstance(dout_t, hip.H2) != use_h2:
+            dout_t = hip.h2_pack(dout2d, per_row=True) if use_h2 else hip.tp3_pack(dout2d)
+        _, dz = gemm_ln(dout_t, WL["w2_t"], want_f32=False, want_tp3=True, dact=spec.act, dact_aux=z)
         dx2, _ = hip.gemm_tp3(dz, W["w1_t"])
         del dz
-        dh2, dh2_t = hip.layernorm_bwd_tp3(dx2, h2, lw.ln2_w, mean2, rstd2, dres=dout2d)
+        dh2, dh2_t = ln_bwd(dx2, h2, lw.ln2_w, mean2, rstd2, dres=dout2d)
         del dx2
         o_t = hip.Tp3(M, D, o_buf.device, o_buf)
         if hip.ATTN_TP3:
-            _, do = hip.gemm_tp3(dh2_t, W["wo_t"], want_f32=False, want_tp3=True)
+            _, do = gemm_ln(dh2_t, WL["wo_t"], want_f32=False, want_tp3=True)
             dqkv = hip.attn_tp3_bwd(hip.Tp3(M, 3 * D, qkv.device, qkv), o_t, do, lse, B, T, H, dh**-0.5)
         else:
             do, _ = hip.gemm_tp3(dh2_t, W["wo_t"])
@@ -136,7 +159,7 @@ class EncoderLayerTp3Fn(Fn):
         del dh2_t, do
         dx1, _ = hip.gemm_tp3(dqkv, W["wqkv_t"])
         del dqkv
-        dh_in, dh_in_t = hip.layernorm_bwd_tp3(dx1, h2d, lw.ln1_w, mean1, rstd1, dres=dh2)
+        dh_in, dh_in_t = ln_bwd(dx1, h2d, lw.ln1_w, mean1, rstd1, dres=dh2)
         g = dh_in.view(B, T, D)
         g._tvl_tp3 = ((g.data_ptr(), g._version, g.numel()), dh_in_t)  # the layer below starts its backward with a tp3 GEMM on this
         return g, None, None
