@@ -298,13 +298,19 @@ int tvl_gemm_tp3(const tvlGemmTp3Args* args, tvlStream_t stream);
  * tvl_gemm_h2: tvl_gemm_tp3's argument block with h2 images as A / B; the result is multiplied by alpha (= B's inverse scale) and by
  * a_row_scale[m] (A's inverse row scales, may be null); C_tp3 stays a tp3 image.  Replaces the same nn.Linear calls as tvl_gemm_tp3. */
 int64_t tvl_h2_bytes(int64_t rows, int32_t K);
-int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, float* inv_scale, int32_t per_row, void* work, tvlStream_t stream);
+int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, float* inv_scale, float* row_norm /* [rows] or null */,
+                int32_t per_row, void* work, tvlStream_t stream);
 int tvl_gemm_h2(const tvlGemmTp3Args* args, const float* a_row_scale, tvlStream_t stream);
+/* ... with the result written as an h2 image (the next GEMM's A operand).  Its row scales come from the bound
+ * |out[m, n]| <= out_row_norm[m] * out_mul + out_add (L2 norms of A's rows from A's producer; out_mul = max_n ||B row n||_2 times the
+ * activation's Lipschitz bound; out_add = max |bias|); the inverse scales are written to out_inv_scale[M]. */
+int tvl_gemm_h2_out(const tvlGemmTp3Args* args, const float* a_row_scale, void* c_h2, const float* out_row_norm, float out_mul, float out_add,
+                    float* out_inv_scale, tvlStream_t stream);
 /* LayerNorm forward / backward writing their result as an h2 operand (+ inv_scale[rows]); otherwise as tvl_layernorm_fwd_tp3 / _bwd_tp3 */
-int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const float* beta, void* y_h2, float* inv_scale, float* mean, float* rstd,
+int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const float* beta, void* y_h2, float* inv_scale, float* row_norm /* or null */, float* mean, float* rstd,
                          int64_t rows, int32_t cols, float eps, tvlStream_t stream);
 int tvl_layernorm_bwd_h2(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres,
-                         float* dx, void* dx_h2, float* inv_scale, int64_t rows, int32_t cols, tvlStream_t stream);
+                         float* dx, void* dx_h2, float* inv_scale, float* row_norm /* or null */, int64_t rows, int32_t cols, tvlStream_t stream);
 
 /* nn.AvgPool2d(k) / F.avg_pool2d(x, k, k) on [B,H,W,C] (H, W divisible by k) and its gradient (H, W = input sizes) */
 int tvl_avgpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);

@@ -619,3 +619,27 @@ def test_layernorm_h2_forward_and_backward(hip):
     assert torch.equal(dx, dx3)   # the fp32 result is the same kernel code
     e = (dxt.float() - dx).abs()
     assert (e <= dx.abs().amax(1, keepdim=True) * 2.0**-20).all()
+
+
+def test_gemm_h2_with_h2_output_feeds_the_next_gemm(hip):
+    """fc1 -> QuickGELU -> fc2 on two-piece operands end to end: the first GEMM's epilogue writes its result as an h2 image whose row
+    scales come from the Cauchy-Schwarz bound ||A row|| max ||B row|| + max |bias| (no value may overflow fp16, every row keeps ~20 bits)."""
+    M, D, F = 700, 768, 3072
+    x = rnd(M, D, seed=13) * torch.logspace(-3, 1, M)[:, None]
+    w1, b1, w2 = rnd(F, D, seed=14) * 0.04, rnd(F, seed=15) * 0.1, rnd(D, F, seed=16) * 0.02
+    X = hip.h2_pack(dev(x), True, want_norm=True)
+    W1, W2 = hip.weight_h2(dev(w1)), hip.weight_h2(dev(w2))
+    z = torch.empty(M, F, device="cuda")
+    _, a = hip.gemm_h2(X, W1, want_f32=False, want_h2=True, out_add=float(b1.abs().max()), bias=dev(b1), act=hip.ACT_QUICK_GELU, pre_out=z)
+    z_ref = x.double() @ w1.double().T + b1.double()
+    a_ref = z_ref * torch.sigmoid(1.702 * z_ref)
+    assert torch.isfinite(a.float()).all()
+    top = a_ref.abs().amax(1) / a.inv_scale.cpu().double()
+    assert (top < 2.0**14).all()                       # the bound held: nothing near fp16's 65504
+    assert (a.float().cpu().double() - a_ref).abs().max().item() <= 1e-5 * a_ref.abs().max().item()
+    err_rows = (a.float().cpu().double() - a_ref).abs().amax(1) / a_ref.abs().amax(1)
+    assert err_rows.max().item() < 2e-5, err_rows.max()   # every row, however small, keeps its own precision
+    y, _ = hip.gemm_h2(a, W2)
+    y_ref = a_ref @ w2.double().T
+    den = a_ref.abs() @ w2.abs().double().T
+    assert ((y.cpu().double() - y_ref).abs() / den).max().item() < 5e-6

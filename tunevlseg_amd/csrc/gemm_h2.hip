@@ -18,18 +18,23 @@ constexpr int BLK2 = 2 * PIECE;
 __device__ __forceinline__ float pow2_scale_inv(float amax) { return h2::inv_scale_of(amax); }
 
 // per-row maxima -> inverse scales [rows]; one wave per row
-__global__ __launch_bounds__(256) void h2_rowscale_kernel(const float* __restrict__ x, long ldx, long rows, int K, float* __restrict__ inv_scale) {
+__global__ __launch_bounds__(256) void h2_rowscale_kernel(const float* __restrict__ x, long ldx, long rows, int K, float* __restrict__ inv_scale,
+                                                          float* __restrict__ row_norm) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    float m = 0.f;
+    float m = 0.f, ss = 0.f;
     for (int c = lane * 4; c < K; c += 256) {
         const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if (lane == 0) inv_scale[row] = pow2_scale_inv(m);
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); ss += __shfl_xor(ss, o, 64); }
+    if (lane == 0) {
+        inv_scale[row] = pow2_scale_inv(m);
+        if (row_norm) row_norm[row] = sqrtf(ss) * 1.0001f;
+    }
 }
 
 // whole-tensor maximum -> one inverse scale (two stages: block maxima by atomicMax on the bit pattern of a non-negative float)
@@ -89,6 +94,9 @@ int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
             case E_BIAS | E_QGELU | E_PRE | E_TP3 | E_RSCALE: return launch<256, 256, 2, E_BIAS | E_QGELU | E_PRE | E_TP3 | E_RSCALE, 2>(p, s);
             case E_BIAS | E_QGELU | E_TP3 | E_RSCALE: return launch<256, 256, 2, E_BIAS | E_QGELU | E_TP3 | E_RSCALE, 2>(p, s);
             case E_DQGELU | E_TP3 | E_RSCALE: return launch<256, 256, 2, E_DQGELU | E_TP3 | E_RSCALE, 2>(p, s);   // dz of the backward
+            case E_BIAS | E_QGELU | E_PRE | E_RSCALE | E_H2OUT: return launch<256, 256, 2, E_BIAS | E_QGELU | E_PRE | E_RSCALE | E_H2OUT, 2>(p, s);   // fc1 -> h2
+            case E_BIAS | E_QGELU | E_RSCALE | E_H2OUT: return launch<256, 256, 2, E_BIAS | E_QGELU | E_RSCALE | E_H2OUT, 2>(p, s);
+            case E_DQGELU | E_RSCALE | E_H2OUT: return launch<256, 256, 2, E_DQGELU | E_RSCALE | E_H2OUT, 2>(p, s);                 // dz -> h2
             default: return launch<256, 256, 2, -1, 2>(p, s);
         }
     }
@@ -97,6 +105,7 @@ int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
         case E_TP3 | E_RSCALE: return launch<192, 256, 3, E_TP3 | E_RSCALE, 2>(p, s);                                 // dO of the backward
         case E_BIAS | E_F32 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_F32 | E_RSCALE, 2>(p, s);
         case E_F32 | E_RSCALE: return launch<192, 256, 3, E_F32 | E_RSCALE, 2>(p, s);
+        case E_BIAS | E_RES | E_F32 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_RES | E_F32 | E_RSCALE, 2>(p, s);   // out_proj, fc2
         default: return launch<192, 256, 3, -1, 2>(p, s);
     }
 }
@@ -110,14 +119,14 @@ extern "C" int64_t tvl_h2_bytes(int64_t rows, int32_t K) {
 
 // fp32 [rows, K] -> h2 image + inverse scale(s): per_row != 0 -> inv_scale[rows] (activations: A operand), else inv_scale[1]
 // (a frozen weight: B operand, its factor goes into alpha).  `work` = 4 bytes of device scratch (per-tensor mode only).
-extern "C" int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, float* inv_scale, int32_t per_row, void* work,
-                           tvlStream_t stream) {
+extern "C" int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, float* inv_scale, float* row_norm, int32_t per_row,
+                           void* work, tvlStream_t stream) {
     TVL_REQUIRE(x && out && inv_scale && (per_row || work), "tvl_h2_pack: null pointer");
     TVL_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ldx >= K && ldx % 4 == 0, "tvl_h2_pack: need K %% 16 == 0, ldx >= K, ldx %% 4 == 0");
     TVL_REQUIRE(tvl_aligned16(out) && tvl_aligned16(x), "tvl_h2_pack: operands must be 16-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (per_row) {
-        hipLaunchKernelGGL(h2_rowscale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, (long)ldx, (long)rows, K, inv_scale);
+        hipLaunchKernelGGL(h2_rowscale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, (long)ldx, (long)rows, K, inv_scale, row_norm);
     } else {
         hipError_t e = hipMemsetAsync(work, 0, 4, s);
         TVL_REQUIRE(e == hipSuccess, "tvl_h2_pack: memset failed: %s", hipGetErrorString(e));
@@ -138,11 +147,13 @@ extern "C" int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K,
 // epilogue(alpha * a_row_scale[m] * A . B^T) over h2 operands; same argument block as tvl_gemm_tp3 (A / B are h2 images; C_tp3, if given,
 // is still a tp3 image: the consumers of this round read three bf16 pieces).  a_row_scale: [M] inverse scales of A's rows (or null);
 // alpha carries the inverse scale of B.
-extern "C" int tvl_gemm_h2(const tvlGemmTp3Args* a, const float* a_row_scale, tvlStream_t stream) {
+static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void* c_h2, const float* out_row_norm, float out_mul, float out_add,
+                        float* out_inv_scale, tvlStream_t stream) {
     TVL_REQUIRE(a != nullptr, "tvl_gemm_h2: null args");
     TVL_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "tvl_gemm_h2: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     TVL_REQUIRE(a->K % 32 == 0 && a->K >= 64 && a->N % 16 == 0, "tvl_gemm_h2: need K %% 32 == 0, K >= 64, N %% 16 == 0 (K=%d N=%d)", a->K, a->N);
-    TVL_REQUIRE(a->A && a->B && (a->C || a->C_tp3), "tvl_gemm_h2: null operand");
+    TVL_REQUIRE(a->A && a->B && (a->C || a->C_tp3 || c_h2), "tvl_gemm_h2: null operand");
+    TVL_REQUIRE(!c_h2 || (out_row_norm && out_inv_scale && tvl_aligned16(c_h2)), "tvl_gemm_h2: an h2 output needs row norms, a place for its inverse scales and 16-byte alignment");
     TVL_REQUIRE(tvl_aligned16(a->A) && tvl_aligned16(a->B), "tvl_gemm_h2: operands must be 16-byte aligned");
     TVL_REQUIRE(a->a_rows >= a->M && a->b_rows >= a->N, "tvl_gemm_h2: operand images hold fewer rows than M / N");
     TVL_REQUIRE(!a->C || (a->ldc >= a->N && a->ldc % 4 == 0 && tvl_aligned16(a->C)), "tvl_gemm_h2: C needs ldc >= N, ldc %% 4 == 0, 16-byte alignment");
@@ -158,6 +169,7 @@ extern "C" int tvl_gemm_h2(const tvlGemmTp3Args* a, const float* a_row_scale, tv
     p.C = a->C; p.ldc = a->ldc; p.Cp = reinterpret_cast<unsigned char*>(a->C_tp3);
     p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.act = a->act; p.pre_out = a->pre_out;
     p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha; p.a_scale = a_row_scale;
+    p.Ch2 = reinterpret_cast<unsigned char*>(c_h2); p.out_norm = out_row_norm; p.out_mul = out_mul; p.out_add = out_add; p.out_inv = out_inv_scale;
     int bm = a->tile_m;
     if (bm != 256 && bm != 192) {
         const long t256 = ((long)(a->M + 255) / 256) * ((a->N + 255) / 256), t192 = ((long)(a->M + 191) / 192) * ((a->N + 255) / 256);
@@ -168,3 +180,19 @@ extern "C" int tvl_gemm_h2(const tvlGemmTp3Args* a, const float* a_row_scale, tv
     TVL_LAUNCH_CHECK("tvl_gemm_h2");
     return 0;
 }
+
+extern "C" int tvl_gemm_h2(const tvlGemmTp3Args* a, const float* a_row_scale, tvlStream_t stream) {
+    return gemm_h2_impl(a, a_row_scale, nullptr, nullptr, 0.f, 0.f, nullptr, stream);
+}
+
+// The same GEMM with its result ALSO (or only) written as an h2 image, i.e. as the A operand of the next h2 GEMM.  The producer of a
+// row-scaled operand needs the row's magnitude before it writes the row; a GEMM workgroup sees 256 of its columns, so the scale comes
+// from a bound instead: |out[m, n]| <= out_row_norm[m] * out_mul + out_add with out_row_norm = the L2 norms of A's rows (written by A's
+// own producer), out_mul = max_n ||B row n||_2 (times the Lipschitz constant of the epilogue's activation), out_add = max |bias|.
+// out_inv_scale[M] receives the inverse scales the consumer passes as its a_row_scale.
+extern "C" int tvl_gemm_h2_out(const tvlGemmTp3Args* a, const float* a_row_scale, void* c_h2, const float* out_row_norm, float out_mul, float out_add,
+                               float* out_inv_scale, tvlStream_t stream) {
+    TVL_REQUIRE(c_h2 != nullptr, "tvl_gemm_h2_out: null h2 output");
+    return gemm_h2_impl(a, a_row_scale, c_h2, out_row_norm, out_mul, out_add, out_inv_scale, stream);
+}
+

@@ -56,6 +56,10 @@ struct Tp3Params {
     const float* dact_aux; int ld_aux; int dact;
     float alpha;
     const float* a_scale;   // optional per-row factor of the result (two-piece fp16 operands carry power-of-two row scales), or null
+    // h2 OUTPUT (the next GEMM's A operand as two fp16 pieces): its row scale comes from a Cauchy-Schwarz bound on the row,
+    // |out[m, n]| <= out_norm[m] * out_mul + out_add (out_norm = ||A row m||_2 from A's producer, out_mul = max_n ||B row n||_2 times
+    // the activation's Lipschitz bound, out_add = max |bias|); the epilogue writes the inverse scale to out_inv[m]
+    unsigned char* Ch2; const float* out_norm; float out_mul, out_add; float* out_inv;
     int tiles_m, tiles_n;
 };
 
@@ -92,7 +96,7 @@ __device__ __forceinline__ long tp3_off(long row, int col, int kblocks) { return
 // bit set of the options below, resolved at compile time -- the epilogue is cold, straight-line code executed once per tile, and
 // with all options live it was ~5 KB per 4-column group, 24 groups per wave: the write-out of a tile then ran at the
 // instruction-fetch rate (20 us per 192x256 tile; stamps in profiles/r2_gemm_experiments.md), not at the store rate.
-enum { E_BIAS = 1, E_RES = 2, E_QGELU = 4, E_DQGELU = 8, E_PRE = 16, E_F32 = 32, E_TP3 = 64, E_RSCALE = 128 };
+enum { E_BIAS = 1, E_RES = 2, E_QGELU = 4, E_DQGELU = 8, E_PRE = 16, E_F32 = 32, E_TP3 = 64, E_RSCALE = 128, E_H2OUT = 256 };
 
 template <int EPI, bool NOSTORE = false>
 __device__ __forceinline__ void emit4(const Tp3Params& p, long row, int col, float4 a) {
@@ -139,6 +143,13 @@ __device__ __forceinline__ void emit4(const Tp3Params& p, long row, int col, flo
         unsigned char* o = p.Cp + tp3_off(row, col, p.N >> 4);
 #pragma unroll
         for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(o + s * PIECE) = pl[s];
+    }
+    if (G ? p.Ch2 != nullptr : (EPI & E_H2OUT) != 0) {
+        const float inv = h2::inv_scale_of(p.out_norm[row] * p.out_mul + p.out_add);
+        if (col == 0) p.out_inv[row] = inv;   // once per row: the lane that owns the row's first four columns
+        const float sc = 1.0f / inv;          // a power of two: exact
+        const float w[4] = {v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
+        h2::store4(p.Ch2, p.N >> 4, row, col, w);
     }
 }
 
@@ -410,7 +421,7 @@ inline int epi_code(const Tp3Params& p) {
     const int act = p.act & 0xff;
     if ((act != TVL_ACT_NONE && act != TVL_ACT_QUICK_GELU) || (p.dact != TVL_ACT_NONE && p.dact != TVL_ACT_QUICK_GELU)) return -1;
     return (p.bias ? E_BIAS : 0) | (p.residual ? E_RES : 0) | (act ? E_QGELU : 0) | (p.dact ? E_DQGELU : 0) | (p.pre_out ? E_PRE : 0) |
-           (p.C ? E_F32 : 0) | (p.Cp ? E_TP3 : 0) | (p.a_scale ? E_RSCALE : 0);
+           (p.C ? E_F32 : 0) | (p.Cp ? E_TP3 : 0) | (p.a_scale ? E_RSCALE : 0) | (p.Ch2 ? E_H2OUT : 0);
 }
 
 }  // namespace

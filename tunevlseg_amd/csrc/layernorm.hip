@@ -169,7 +169,7 @@ template <int LN_MAXV, int NW, int NP = 3>
 __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, unsigned char* __restrict__ out,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows, int cols,
-                                                         float eps, float* __restrict__ inv_scale) {
+                                                         float eps, float* __restrict__ inv_scale, float* __restrict__ row_norm) {
     __shared__ float s_mean[32], s_rstd[32], s_scale[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rb = blockIdx.x;
@@ -207,20 +207,26 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
                 if (rstd_out) rstd_out[row] = rstd;
             }
             if constexpr (NP == 2) {
-                float amax = 0.f;
+                float amax = 0.f, ss = 0.f;
 #pragma unroll
                 for (int i = 0; i < LN_MAXV; ++i) {
                     const int c = lane + 64 * i;
                     if (c < nv) {
                         const float4 g4 = reinterpret_cast<const float4*>(gamma)[c];
                         const float4 b4 = beta ? reinterpret_cast<const float4*>(beta)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        amax = fmaxf(fmaxf(amax, fmaxf(fabsf((v[i].x - mean) * rstd * g4.x + b4.x), fabsf((v[i].y - mean) * rstd * g4.y + b4.y))),
-                                     fmaxf(fabsf((v[i].z - mean) * rstd * g4.z + b4.z), fabsf((v[i].w - mean) * rstd * g4.w + b4.w)));
+                        const float y0 = (v[i].x - mean) * rstd * g4.x + b4.x, y1 = (v[i].y - mean) * rstd * g4.y + b4.y;
+                        const float y2 = (v[i].z - mean) * rstd * g4.z + b4.z, y3 = (v[i].w - mean) * rstd * g4.w + b4.w;
+                        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1))), fmaxf(fabsf(y2), fabsf(y3)));
+                        ss += (y0 * y0 + y1 * y1) + (y2 * y2 + y3 * y3);
                     }
                 }
                 amax = wave_max(amax);
+                ss = wave_sum(ss);
                 const float inv = h2::inv_scale_of(amax);
-                if (lane == 0) { inv_scale[row] = inv; s_scale[rl] = 1.0f / inv; }
+                if (lane == 0) {
+                    inv_scale[row] = inv; s_scale[rl] = 1.0f / inv;
+                    if (row_norm) row_norm[row] = sqrtf(ss) * 1.0001f;   // ||y row||_2, rounded up: it feeds a bound (tvl_gemm_h2_out)
+                }
             }
         } else if (NP == 2 && lane == 0) s_scale[rl] = 1.0f;
         if (lane == 0) { s_mean[rl] = mean; s_rstd[rl] = rstd; }
@@ -273,7 +279,7 @@ template <int LN_MAXV, int NW, int NP = 3>
 __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const float* __restrict__ dres, float* __restrict__ dx, unsigned char* __restrict__ out,
-                                                         long rows, int cols, float* __restrict__ inv_scale) {
+                                                         long rows, int cols, float* __restrict__ inv_scale, float* __restrict__ row_norm) {
     __shared__ float s_scale[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rb = blockIdx.x;
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
             if (NP == 2 && lane == 0) s_scale[wave * (32 / NW) + rr] = 1.0f;
             continue;
         }
-        float amax = 0.f;
+        float amax = 0.f, ss = 0.f;
         const float* xr = x + row * cols;
         const float* dyr = dy + row * cols;
         float* dxr = dx + row * cols;
@@ -321,13 +327,20 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
                     o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
                 }
                 reinterpret_cast<float4*>(dxr)[c] = o;
-                if constexpr (NP == 2) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                if constexpr (NP == 2) {
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                    ss += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                }
             }
         }
         if constexpr (NP == 2) {
             amax = wave_max(amax);
+            ss = wave_sum(ss);
             const float inv = h2::inv_scale_of(amax);
-            if (lane == 0) { inv_scale[row] = inv; s_scale[wave * (32 / NW) + rr] = 1.0f / inv; }
+            if (lane == 0) {
+                inv_scale[row] = inv; s_scale[wave * (32 / NW) + rr] = 1.0f / inv;
+                if (row_norm) row_norm[row] = sqrtf(ss) * 1.0001f;
+            }
         }
     }
     // the block's dx rows are re-read by other waves of this workgroup: drain the stores, then make them visible (the lines
@@ -410,8 +423,8 @@ extern "C" int tvl_layernorm_fwd_tp3(const float* x, const float* gamma, const f
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(y_tp3);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr);
-    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr, (float*)nullptr);
+    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr, (float*)nullptr);
     TVL_LAUNCH_CHECK("tvl_layernorm_fwd_tp3");
     return 0;
 }
@@ -425,14 +438,14 @@ extern "C" int tvl_layernorm_bwd_tp3(const float* dy, const float* x, const floa
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(dx_tp3);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr);
-    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr, (float*)nullptr);
+    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr, (float*)nullptr);
     TVL_LAUNCH_CHECK("tvl_layernorm_bwd_tp3");
     return 0;
 }
 
 // The same two kernels writing the h2 operand format (two fp16 pieces of the row scaled by a power of two) + the rows' inverse scales.
-extern "C" int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const float* beta, void* y_h2, float* inv_scale, float* mean, float* rstd,
+extern "C" int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const float* beta, void* y_h2, float* inv_scale, float* row_norm, float* mean, float* rstd,
                                     int64_t rows, int32_t cols, float eps, tvlStream_t stream) {
     TVL_REQUIRE(x && gamma && y_h2 && inv_scale, "tvl_layernorm_fwd_h2: null pointer");
     TVL_REQUIRE(rows > 0 && cols > 0 && cols % 16 == 0 && cols <= 2048, "tvl_layernorm_fwd_h2: need cols %% 16 == 0 and cols <= 2048 (rows=%ld cols=%d)", (long)rows, cols);
@@ -440,14 +453,14 @@ extern "C" int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const fl
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(y_h2);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale);
-    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm);
+    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm);
     TVL_LAUNCH_CHECK("tvl_layernorm_fwd_h2");
     return 0;
 }
 
 extern "C" int tvl_layernorm_bwd_h2(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                    const float* dres, float* dx, void* dx_h2, float* inv_scale, int64_t rows, int32_t cols, tvlStream_t stream) {
+                                    const float* dres, float* dx, void* dx_h2, float* inv_scale, float* row_norm, int64_t rows, int32_t cols, tvlStream_t stream) {
     TVL_REQUIRE(dy && x && gamma && mean && rstd && dx && dx_h2 && inv_scale, "tvl_layernorm_bwd_h2: null pointer");
     TVL_REQUIRE(rows > 0 && cols > 0 && cols % 16 == 0 && cols <= 2048, "tvl_layernorm_bwd_h2: need cols %% 16 == 0 and cols <= 2048 (rows=%ld cols=%d)", (long)rows, cols);
     TVL_REQUIRE(tvl_aligned16(x) && tvl_aligned16(dy) && tvl_aligned16(dx) && tvl_aligned16(dx_h2) && tvl_aligned16(gamma) && (!dres || tvl_aligned16(dres)),
@@ -455,8 +468,8 @@ extern "C" int tvl_layernorm_bwd_h2(const float* dy, const float* x, const float
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(dx_h2);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale);
-    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm);
+    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm);
     TVL_LAUNCH_CHECK("tvl_layernorm_bwd_h2");
     return 0;
 }

@@ -99,5 +99,22 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[2]) {
     out[1] = *reinterpret_cast<const uint4*>(h1);
 }
 
+// byte offset of 4 consecutive elements (row, col .. col+3), col % 4 == 0, of piece 0 inside an h2 image with kblocks = cols / 16
+__device__ __forceinline__ long off4(long row, int col, int kblocks) {
+    return ((row >> 5) * kblocks + (col >> 4)) * (long)BLK + ((((col >> 3) & 1) * 32 + (int)(row & 31)) * 16 + (col & 4) * 2);
+}
+// split 4 consecutive (already scaled) elements and store them (8 bytes per piece)
+__device__ __forceinline__ void store4(unsigned char* __restrict__ img, int kblocks, long row, int col, const float (&v)[4]) {
+    _Float16 h0[4], h1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h0[e] = (_Float16)v[e];
+        h1[e] = (_Float16)(v[e] - (float)h0[e]);
+    }
+    unsigned char* o = img + off4(row, col, kblocks);
+    *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(h0);
+    *reinterpret_cast<uint2*>(o + PIECE) = *reinterpret_cast<const uint2*>(h1);
+}
+
 }  // namespace h2
 

@@ -147,10 +147,11 @@ _SIGS = {
     "tvl_tp3_pack": [_P, _L, _L, _I, _P],
     "tvl_tp3_unpack": [_P, _L, _I, _P, _L],
     "tvl_gemm_tp3": [C.POINTER(GemmTp3Args)],
-    "tvl_h2_pack": [_P, _L, _L, _I, _P, _P, _I, _P],
+    "tvl_h2_pack": [_P, _L, _L, _I, _P, _P, _P, _I, _P],
+    "tvl_gemm_h2_out": [C.POINTER(GemmTp3Args), _P, _P, _P, _F, _F, _P],
     "tvl_gemm_h2": [C.POINTER(GemmTp3Args), _P],
-    "tvl_layernorm_fwd_h2": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F],
-    "tvl_layernorm_bwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
+    "tvl_layernorm_fwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F],
+    "tvl_layernorm_bwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
     "tvl_im2col3x3": [_P, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
@@ -425,7 +426,7 @@ class H2:
     MFMA-fragment order (include/tvl_hip.h, "h2"): the operand format of ``tvl_gemm_h2`` -- 3 MFMAs per product instead of tp3's 6.
     ``inv_scale``: fp32 [rows] (per row) or [1] (per tensor) exact powers of two that the GEMM's epilogue multiplies back in."""
 
-    __slots__ = ("buf", "rows", "cols", "inv_scale", "per_row", "_alpha")
+    __slots__ = ("buf", "rows", "cols", "inv_scale", "per_row", "_alpha", "row_norm", "_bound")
 
     def __init__(self, rows: int, cols: int, device, per_row: bool):
         if cols % 16:
@@ -435,6 +436,8 @@ class H2:
         self.buf = (torch.zeros if rows % 32 else torch.empty)(n, device=device, dtype=torch.uint8)
         self.inv_scale = torch.empty(rows if per_row else 1, device=device, dtype=torch.float32)
         self._alpha = None   # host copy of a per-tensor inverse scale, read once (frozen weights)
+        self.row_norm = None   # [rows] L2 norms of the rows (per-row operands whose consumer GEMM writes an h2 output)
+        self._bound = None
 
     @property
     def shape(self):
@@ -454,19 +457,32 @@ class H2:
         return self._alpha
 
 
-def h2_pack(x2d: torch.Tensor, per_row: bool) -> H2:
+def h2_pack(x2d: torch.Tensor, per_row: bool, want_norm: bool = False) -> H2:
     """fp32 [rows, cols] -> H2 (per_row: activations, the A operand; per tensor: frozen weights, the B operand)."""
     rows, cols = x2d.shape
     out = H2(rows, cols, x2d.device, per_row)
     work = None if per_row else torch.zeros(1, device=x2d.device, dtype=torch.int32)
-    _call("tvl_h2_pack", _ps(x2d), x2d.stride(0), rows, cols, out.buf.data_ptr(), _p(out.inv_scale), 1 if per_row else 0,
+    if per_row and want_norm:
+        out.row_norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    _call("tvl_h2_pack", _ps(x2d), x2d.stride(0), rows, cols, out.buf.data_ptr(), _p(out.inv_scale), _p(out.row_norm), 1 if per_row else 0,
           None if work is None else work.data_ptr())
     return out
 
 
+def weight_h2(W: torch.Tensor) -> H2:
+    """H2 image of a frozen weight [N, K] + the largest L2 norm of its rows (the factor of the output bound, tvl_gemm_h2_out)."""
+    img = h2_pack(W.detach().contiguous(), per_row=False)
+    img._bound = float(W.detach().float().norm(dim=1).max().item()) * 1.0001
+    img.alpha()
+    return img
+
+
 def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = None, out_tp3: Tp3 | None = None, want_f32=True,
-            want_tp3=False, bias=None, residual=None, act=ACT_NONE, pre_out=None, dact_aux=None, dact=ACT_NONE, tile_m: int = 0):
-    """epilogue(A . B^T) over h2 operands (A row-scaled, B tensor-scaled); returns (C fp32 or None, C as Tp3 or None)."""
+            want_tp3=False, bias=None, residual=None, act=ACT_NONE, pre_out=None, dact_aux=None, dact=ACT_NONE, tile_m: int = 0,
+            want_h2=False, out_mul: float | None = None, out_add: float = 0.0):
+    """epilogue(A . B^T) over h2 operands (A row-scaled, B tensor-scaled); returns (C fp32 or None, C as Tp3 / H2 or None).
+    ``want_h2``: the result as an H2 image (next GEMM's A operand); its row scales come from the bound
+    ``A.row_norm[m] * out_mul + out_add`` (out_mul defaults to B's largest row norm)."""
     M = A.rows if M is None else M
     N, K = B.rows, A.cols
     if B.cols != K or not A.per_row or B.per_row:
@@ -474,6 +490,11 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
     dev = A.buf.device
     Cf = out if out is not None else (torch.empty((M, N), device=dev, dtype=torch.float32) if want_f32 else None)
     Ct = out_tp3 if out_tp3 is not None else (Tp3(M, N, dev) if want_tp3 else None)
+    Ch = None
+    if want_h2:
+        if A.row_norm is None or (out_mul is None and B._bound is None):
+            raise RuntimeError("gemm_h2(want_h2=True) needs A.row_norm (from A's producer) and a bound factor (weight_h2 / out_mul)")
+        Ch = H2(M, N, dev, per_row=True)
     ldc = Cf.stride(0) if Cf is not None else (pre_out.stride(0) if pre_out is not None else N)
     args = GemmTp3Args(M, N, K, A.buf.data_ptr(), A.rows, B.buf.data_ptr(), B.rows, _ps(Cf), ldc, None if Ct is None else Ct.buf.data_ptr(),
                        _p(bias), _ps(residual), 0 if residual is None else residual.stride(0), act, _ps(pre_out), _ps(dact_aux),
@@ -481,25 +502,29 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
     if _gemm_prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _call("tvl_gemm_h2", C.byref(args), _p(A.inv_scale))
+    if Ch is not None:
+        _call("tvl_gemm_h2_out", C.byref(args), _p(A.inv_scale), Ch.buf.data_ptr(), _p(A.row_norm), float(B._bound if out_mul is None else out_mul),
+              float(out_add), _p(Ch.inv_scale))
+    else:
+        _call("tvl_gemm_h2", C.byref(args), _p(A.inv_scale))
     if _gemm_prof is not None:
         e1.record()
         _gemm_prof.append((h2_kernel_name(M, N, bias is not None, residual is not None, act, dact, pre_out is not None, Cf is not None,
-                                          Ct is not None, tile_m), 2.0 * M * N * K, e0, e1))
-    return Cf, Ct
+                                          Ct is not None, tile_m, Ch is not None), 2.0 * M * N * K, e0, e1))
+    return Cf, (Ch if Ch is not None else Ct)
 
 
-_H2_EPI_BUILT = {192: {193, 161, 160, 192}, 256: {213, 197, 200}}   # launch_h2's compile-time epilogues per row tile (csrc/gemm_h2.hip)
+_H2_EPI_BUILT = {192: {193, 161, 160, 192, 163}, 256: {213, 197, 200, 405, 389, 392}}   # launch_h2's compile-time epilogues per row tile (csrc/gemm_h2.hip)
 
 
-def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_m=0) -> str:
+def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_m=0, c_h2=False) -> str:
     """Instantiation tvl_gemm_h2 launches, spelled as rocprofv3 prints it (NP = 2 as the last template argument)."""
     tile = tile_m
     if tile not in (192, 256):
         t256, t192 = -(-M // 256) * -(-N // 256), -(-M // 192) * -(-N // 256)
         tile = 256 if -(-t256 // 256) * 256 <= -(-t192 // 256) * 192 else 192
     epi = (1 if bias else 0) | (2 if residual else 0) | (4 if (act & 0xFF) else 0) | (8 if dact else 0) | (16 if pre_out else 0) | \
-          (32 if c_f32 else 0) | (64 if c_tp3 else 0) | 128
+          (32 if c_f32 else 0) | (64 if c_tp3 else 0) | 128 | (256 if c_h2 else 0)
     if (act & ~0xFF) or epi not in _H2_EPI_BUILT[tile]:
         epi = -1
     return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2>"
@@ -621,9 +646,10 @@ def layernorm_fwd_h2(x2d, gamma, beta, eps: float, want_stats=True):
     """LayerNorm whose only consumer is an h2 GEMM: returns (H2 image of y with per-row scales, mean, rstd)."""
     rows, cols = x2d.shape
     y = H2(rows, cols, x2d.device, per_row=True)
+    y.row_norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
     mean = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
-    _call("tvl_layernorm_fwd_h2", _p(x2d), _p(gamma), _p(beta), y.buf.data_ptr(), _p(y.inv_scale), _p(mean), _p(rstd), rows, cols, float(eps))
+    _call("tvl_layernorm_fwd_h2", _p(x2d), _p(gamma), _p(beta), y.buf.data_ptr(), _p(y.inv_scale), _p(y.row_norm), _p(mean), _p(rstd), rows, cols, float(eps))
     return y, mean, rstd
 
 
@@ -632,7 +658,9 @@ def layernorm_bwd_h2(dy2d, x2d, gamma, mean, rstd, dres=None):
     rows, cols = x2d.shape
     dx = torch.empty_like(x2d)
     dxt = H2(rows, cols, x2d.device, per_row=True)
-    _call("tvl_layernorm_bwd_h2", _p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), dxt.buf.data_ptr(), _p(dxt.inv_scale), rows, cols)
+    dxt.row_norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    _call("tvl_layernorm_bwd_h2", _p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), dxt.buf.data_ptr(), _p(dxt.inv_scale),
+          _p(dxt.row_norm), rows, cols)
     return dx, dxt
 
 

@@ -54,9 +54,11 @@ class LayerWeights:
         QKV and fc1 forward, the out-projection and fc2 data gradients (W^T)."""
         if self._h2 is None:
             t = lambda w: w.detach().t().contiguous()  # noqa: E731
-            self._h2 = {k: hip.h2_pack(w.detach().contiguous(), per_row=False) for k, w in (
-                ("wqkv", self.wqkv), ("w1", self.w1),
-                ("wo_t", self.wo_t if self.wo_t is not None else t(self.wo)), ("w2_t", self.w2_t if self.w2_t is not None else t(self.w2)))}
+            self._h2 = {k: hip.weight_h2(w) for k, w in (
+                ("wqkv", self.wqkv), ("w1", self.w1), ("w2", self.w2),
+                ("wo_t", self.wo_t if self.wo_t is not None else t(self.wo)), ("w2_t", self.w2_t if self.w2_t is not None else t(self.w2)),
+                ("w1_t", self.w1_t if self.w1_t is not None else t(self.w1)))}
+            self._h2["b1_max"] = float(self.b1.detach().abs().max().item()) * 1.0001
         return self._h2
 
 
@@ -82,6 +84,9 @@ def _tp3_of(t2d: torch.Tensor):
     if cached is not None and cached[0] == (t2d.data_ptr(), t2d._version, t2d.numel()):
         return cached[1]
     return None
+
+
+QUICK_GELU_LIP = 1.125   # sup |d/dx x sigmoid(1.702 x)| = 1.0998 (at x = 1.51), rounded up: bound of the dz rows (tvl_gemm_h2_out)
 
 
 class EncoderLayerTp3Fn(Fn):
@@ -118,10 +123,14 @@ class EncoderLayerTp3Fn(Fn):
         h2, _ = hip.gemm_tp3(o, W["wo"], bias=lw.bo, residual=h2d)
         x2, mean2, rstd2 = ln_fwd(h2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
         z = torch.empty((M, lw.w1.shape[0]), device=h.device, dtype=torch.float32) if need else None
-        _, a = gemm_ln(x2, WL["w1"], want_f32=False, want_tp3=True, bias=lw.b1, act=spec.act, pre_out=z)
-        del x2
         out = torch.empty((B, T, D), device=h.device, dtype=torch.float32)  # a base tensor: deep prompts overwrite rows in place
-        hip.gemm_tp3(a, W["w2"], out=out.view(M, D), bias=lw.b2, residual=h2)
+        if use_h2 and spec.act == hip.ACT_QUICK_GELU:   # fc1's epilogue writes QuickGELU(z) as h2 too: |QuickGELU(z)| <= |z| <= ||x2 row|| max_n ||W1 row n|| + max |b1|
+            _, a = hip.gemm_h2(x2, WL["w1"], want_f32=False, want_h2=True, out_add=WL["b1_max"], bias=lw.b1, act=spec.act, pre_out=z)
+            hip.gemm_h2(a, WL["w2"], out=out.view(M, D), bias=lw.b2, residual=h2)
+        else:
+            _, a = gemm_ln(x2, WL["w1"], want_f32=False, want_tp3=True, bias=lw.b1, act=spec.act, pre_out=z)
+            hip.gemm_tp3(a, W["w2"], out=out.view(M, D), bias=lw.b2, residual=h2)
+        del x2
         if need:
             ctx.save_for_backward(h2d, mean1, rstd1, qkv, o.buf, lse, h2, mean2, rstd2, z)
             ctx.lw, ctx.spec, ctx.shape = lw, spec, (B, T, D)
@@ -143,9 +152,13 @@ class EncoderLayerTp3Fn(Fn):
         WL = lw.h2() if use_h2 else W
         dout_t = _tp3_of(dout)   # attached by the layer above's LayerNorm backward, unless autograd summed into it
         if dout_t is None or isinstance(dout_t, hip.H2) != use_h2:
-            dout_t = hip.h2_pack(dout2d, per_row=True) if use_h2 else hip.tp3_pack(dout2d)
-        _, dz = gemm_ln(dout_t, WL["w2_t"], want_f32=False, want_tp3=True, dact=spec.act, dact_aux=z)
-        dx2, _ = hip.gemm_tp3(dz, W["w1_t"])
+            dout_t = hip.h2_pack(dout2d, per_row=True, want_norm=True) if use_h2 else hip.tp3_pack(dout2d)
+        if use_h2 and spec.act == hip.ACT_QUICK_GELU:   # |dz| <= QUICK_GELU_LIP ||dout row|| max_n ||W2^T row n||
+            _, dz = hip.gemm_h2(dout_t, WL["w2_t"], want_f32=False, want_h2=True, out_mul=QUICK_GELU_LIP * WL["w2_t"]._bound, dact=spec.act, dact_aux=z)
+            dx2, _ = hip.gemm_h2(dz, WL["w1_t"])
+        else:
+            _, dz = gemm_ln(dout_t, WL["w2_t"], want_f32=False, want_tp3=True, dact=spec.act, dact_aux=z)
+            dx2, _ = hip.gemm_tp3(dz, W["w1_t"])
         del dz
         dh2, dh2_t = ln_bwd(dx2, h2, lw.ln2_w, mean2, rstd2, dres=dout2d)
         del dx2
