@@ -288,7 +288,10 @@ def main():
                        ("CRIS (CLIP-RN50) + CoCoOp, 416x416" if cris else "CLIPSeg ViT-B/16 + MaPLe depth 9, 352x352" if maple
                         else "CLIPSeg ViT-B/16 + VPT-10 shallow, 352x352")),
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": MODE_DTYPE[hip.GEMM_MODE],
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (fp32-equivalent: operands split into 2 fp16 pieces with exact power-of-two row scales [6 of a vision layer's 8 GEMMs] or "
+                      "3 bf16 pieces [the rest, attention]; piece products exact on the 16-bit MFMA, fp32 accumulate)"
+                      if hip.GEMM_MODE == "bf16x6" and hip.GEMM_H2 and not cris else MODE_DTYPE[hip.GEMM_MODE]),
             "gemm_mode": hip.GEMM_MODE,
             "data": "synthetic", "per_gpu": round(value / world, 2),
             "config": {"workload": ("CRIS (CLIP-RN50 + cross-attn decoder) + CoCoOp meta-net, 416x416, bs=32/GPU (BASELINE configs[2])" if cris else
