@@ -643,3 +643,22 @@ def test_gemm_h2_with_h2_output_feeds_the_next_gemm(hip):
     y_ref = a_ref @ w2.double().T
     den = a_ref.abs() @ w2.abs().double().T
     assert ((y.cpu().double() - y_ref).abs() / den).max().item() < 5e-6
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 495, 12), (3, 100, 2), (1, 33, 1), (4, 64, 3), (4, 8, 2), (5, 31, 1)])
+def test_attention_on_h2_operands(hip, B, T, H):
+    """Forward and backward attention on two-piece fp16 images of QKV / dO (one power-of-two scale per tensor) against the tp3 kernels
+    (six bf16-piece products): same tiles and mappings, half the MFMAs; dO rows spanning four decades as gradients do."""
+    dh, D = 64, H * 64
+    qkv = dev(rnd(B * T, 3 * D, seed=21))
+    d_o = dev(rnd(B * T, D, seed=22) * torch.logspace(-6, -2, B * T)[:, None])
+    q3 = hip.tp3_pack(qkv)
+    o_ref, lse_ref = hip.attn_tp3_fwd(q3, B, T, H, dh**-0.5)
+    g_ref = hip.attn_tp3_bwd(q3, o_ref, hip.tp3_pack(d_o), lse_ref, B, T, H, dh**-0.5).float()
+    qh = hip.h2_pack(qkv, per_row=False)
+    o, lse = hip.attn_h2_fwd(qh, B, T, H, dh**-0.5)
+    close(o.float(), o_ref.float(), 3e-6, "attn h2 fwd O")
+    close(lse, lse_ref, 2e-6, "attn h2 fwd lse")
+    g = hip.attn_h2_bwd(qh, o, hip.h2_pack(d_o, per_row=False), lse, B, T, H, dh**-0.5).float()
+    for name, c0 in (("dQ", 0), ("dK", D), ("dV", 2 * D)):
+        close(g[:, c0:c0 + D], g_ref[:, c0:c0 + D], 1e-5, f"attn h2 bwd {name}")

@@ -42,6 +42,11 @@ def main():
     do_t = hip.tp3_pack(d_o)
     tb3 = timeit(lambda: hip.attn_tp3_bwd(qkv_t, o_t, do_t, lse_t, B, T, H, dh ** -0.5))
     print(f"bwd on tp3 QKV / O / dO images (dQ kernel incl. delta + dK/dV kernel): {tb3*1e3:.1f} us  {2.5*fl/tb3/1e9:.1f} TF/s")
+    qh, dh_ = hip.h2_pack(qkv, per_row=False), hip.h2_pack(d_o, per_row=False)
+    tfh = timeit(lambda: hip.attn_h2_fwd(qh, B, T, H, dh ** -0.5))
+    oh, lseh = hip.attn_h2_fwd(qh, B, T, H, dh ** -0.5)
+    tbh = timeit(lambda: hip.attn_h2_bwd(qh, oh, dh_, lseh, B, T, H, dh ** -0.5))
+    print(f"two fp16 pieces (3 MFMAs per product): fwd {tfh*1e3:.1f} us  {fl/tfh/1e9:.1f} TF/s   bwd {tbh*1e3:.1f} us  {2.5*fl/tbh/1e9:.1f} TF/s")
     if "--diag" in sys.argv:
         o3 = hip.Tp3(B * T, D, qkv.device)
         lse3 = torch.empty(B, H, T, device="cuda")

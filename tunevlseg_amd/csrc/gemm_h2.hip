@@ -103,6 +103,8 @@ int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
     switch (epi) {
         case E_BIAS | E_TP3 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_TP3 | E_RSCALE, 2>(p, s);
         case E_TP3 | E_RSCALE: return launch<192, 256, 3, E_TP3 | E_RSCALE, 2>(p, s);                                 // dO of the backward
+        case E_BIAS | E_RSCALE | E_H2OUT: return launch<192, 256, 3, E_BIAS | E_RSCALE | E_H2OUT, 2>(p, s);           // qkv -> h2 (attention on fp16 pieces)
+        case E_RSCALE | E_H2OUT: return launch<192, 256, 3, E_RSCALE | E_H2OUT, 2>(p, s);                             // dO -> h2
         case E_BIAS | E_F32 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_F32 | E_RSCALE, 2>(p, s);
         case E_F32 | E_RSCALE: return launch<192, 256, 3, E_F32 | E_RSCALE, 2>(p, s);
         case E_BIAS | E_RES | E_F32 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_RES | E_F32 | E_RSCALE, 2>(p, s);   // out_proj, fc2
@@ -148,7 +150,7 @@ extern "C" int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K,
 // is still a tp3 image: the consumers of this round read three bf16 pieces).  a_row_scale: [M] inverse scales of A's rows (or null);
 // alpha carries the inverse scale of B.
 static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void* c_h2, const float* out_row_norm, float out_mul, float out_add,
-                        float* out_inv_scale, tvlStream_t stream) {
+                        float* out_inv_scale, int out_per_tensor, tvlStream_t stream) {
     TVL_REQUIRE(a != nullptr, "tvl_gemm_h2: null args");
     TVL_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "tvl_gemm_h2: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     TVL_REQUIRE(a->K % 32 == 0 && a->K >= 64 && a->N % 16 == 0, "tvl_gemm_h2: need K %% 32 == 0, K >= 64, N %% 16 == 0 (K=%d N=%d)", a->K, a->N);
@@ -169,7 +171,7 @@ static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void*
     p.C = a->C; p.ldc = a->ldc; p.Cp = reinterpret_cast<unsigned char*>(a->C_tp3);
     p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.act = a->act; p.pre_out = a->pre_out;
     p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha; p.a_scale = a_row_scale;
-    p.Ch2 = reinterpret_cast<unsigned char*>(c_h2); p.out_norm = out_row_norm; p.out_mul = out_mul; p.out_add = out_add; p.out_inv = out_inv_scale;
+    p.Ch2 = reinterpret_cast<unsigned char*>(c_h2); p.out_norm = out_row_norm; p.out_mul = out_mul; p.out_add = out_add; p.out_inv = out_inv_scale; p.out_stride = out_per_tensor ? 0 : 1;
     int bm = a->tile_m;
     if (bm != 256 && bm != 192) {
         const long t256 = ((long)(a->M + 255) / 256) * ((a->N + 255) / 256), t192 = ((long)(a->M + 191) / 192) * ((a->N + 255) / 256);
@@ -182,7 +184,7 @@ static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void*
 }
 
 extern "C" int tvl_gemm_h2(const tvlGemmTp3Args* a, const float* a_row_scale, tvlStream_t stream) {
-    return gemm_h2_impl(a, a_row_scale, nullptr, nullptr, 0.f, 0.f, nullptr, stream);
+    return gemm_h2_impl(a, a_row_scale, nullptr, nullptr, 0.f, 0.f, nullptr, 0, stream);
 }
 
 // The same GEMM with its result ALSO (or only) written as an h2 image, i.e. as the A operand of the next h2 GEMM.  The producer of a
@@ -190,9 +192,11 @@ extern "C" int tvl_gemm_h2(const tvlGemmTp3Args* a, const float* a_row_scale, tv
 // from a bound instead: |out[m, n]| <= out_row_norm[m] * out_mul + out_add with out_row_norm = the L2 norms of A's rows (written by A's
 // own producer), out_mul = max_n ||B row n||_2 (times the Lipschitz constant of the epilogue's activation), out_add = max |bias|.
 // out_inv_scale[M] receives the inverse scales the consumer passes as its a_row_scale.
+// out_per_tensor != 0: ONE scale for the whole output (out_row_norm[0] = the largest row norm of A, out_inv_scale[0]): what the attention
+// kernels read (tvl_attn_h2_fwd / _bwd).
 extern "C" int tvl_gemm_h2_out(const tvlGemmTp3Args* a, const float* a_row_scale, void* c_h2, const float* out_row_norm, float out_mul, float out_add,
-                               float* out_inv_scale, tvlStream_t stream) {
+                               float* out_inv_scale, int32_t out_per_tensor, tvlStream_t stream) {
     TVL_REQUIRE(c_h2 != nullptr, "tvl_gemm_h2_out: null h2 output");
-    return gemm_h2_impl(a, a_row_scale, c_h2, out_row_norm, out_mul, out_add, out_inv_scale, stream);
+    return gemm_h2_impl(a, a_row_scale, c_h2, out_row_norm, out_mul, out_add, out_inv_scale, out_per_tensor, stream);
 }
 

@@ -60,6 +60,7 @@ struct Tp3Params {
     // |out[m, n]| <= out_norm[m] * out_mul + out_add (out_norm = ||A row m||_2 from A's producer, out_mul = max_n ||B row n||_2 times
     // the activation's Lipschitz bound, out_add = max |bias|); the epilogue writes the inverse scale to out_inv[m]
     unsigned char* Ch2; const float* out_norm; float out_mul, out_add; float* out_inv;
+    int out_stride;   // 1: out_norm / out_inv are per row; 0: one bound and one scale for the whole output (out_norm[0], out_inv[0])
     int tiles_m, tiles_n;
 };
 
@@ -145,8 +146,8 @@ __device__ __forceinline__ void emit4(const Tp3Params& p, long row, int col, flo
         for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(o + s * PIECE) = pl[s];
     }
     if (G ? p.Ch2 != nullptr : (EPI & E_H2OUT) != 0) {
-        const float inv = h2::inv_scale_of(p.out_norm[row] * p.out_mul + p.out_add);
-        if (col == 0) p.out_inv[row] = inv;   // once per row: the lane that owns the row's first four columns
+        const float inv = h2::inv_scale_of(p.out_norm[row * p.out_stride] * p.out_mul + p.out_add);
+        if (col == 0 && (p.out_stride || row == 0)) p.out_inv[row * p.out_stride] = inv;   // once per row (or once per tensor)
         const float sc = 1.0f / inv;          // a power of two: exact
         const float w[4] = {v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
         h2::store4(p.Ch2, p.N >> 4, row, col, w);

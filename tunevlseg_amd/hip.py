@@ -148,7 +148,9 @@ _SIGS = {
     "tvl_tp3_unpack": [_P, _L, _I, _P, _L],
     "tvl_gemm_tp3": [C.POINTER(GemmTp3Args)],
     "tvl_h2_pack": [_P, _L, _L, _I, _P, _P, _P, _I, _P],
-    "tvl_gemm_h2_out": [C.POINTER(GemmTp3Args), _P, _P, _P, _F, _F, _P],
+    "tvl_gemm_h2_out": [C.POINTER(GemmTp3Args), _P, _P, _P, _F, _F, _P, _I],
+    "tvl_attn_h2_fwd": [_P, _P, _P, _P, _I, _I, _I, _F],
+    "tvl_attn_h2_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "tvl_gemm_h2": [C.POINTER(GemmTp3Args), _P],
     "tvl_layernorm_fwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F],
     "tvl_layernorm_bwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
@@ -439,6 +441,13 @@ class H2:
         self.row_norm = None   # [rows] L2 norms of the rows (per-row operands whose consumer GEMM writes an h2 output)
         self._bound = None
 
+    @classmethod
+    def wrap(cls, rows: int, cols: int, buf: torch.Tensor, inv_scale: torch.Tensor, per_row: bool) -> "H2":
+        """An H2 over existing storage (tensors saved for the backward)."""
+        t = cls.__new__(cls)
+        t.rows, t.cols, t.per_row, t.buf, t.inv_scale, t._alpha, t.row_norm, t._bound = rows, cols, per_row, buf, inv_scale, None, None, None
+        return t
+
     @property
     def shape(self):
         return (self.rows, self.cols)
@@ -479,7 +488,7 @@ def weight_h2(W: torch.Tensor) -> H2:
 
 def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = None, out_tp3: Tp3 | None = None, want_f32=True,
             want_tp3=False, bias=None, residual=None, act=ACT_NONE, pre_out=None, dact_aux=None, dact=ACT_NONE, tile_m: int = 0,
-            want_h2=False, out_mul: float | None = None, out_add: float = 0.0):
+            want_h2=False, out_mul: float | None = None, out_add: float = 0.0, out_per_tensor: bool = False):
     """epilogue(A . B^T) over h2 operands (A row-scaled, B tensor-scaled); returns (C fp32 or None, C as Tp3 / H2 or None).
     ``want_h2``: the result as an H2 image (next GEMM's A operand); its row scales come from the bound
     ``A.row_norm[m] * out_mul + out_add`` (out_mul defaults to B's largest row norm)."""
@@ -494,7 +503,7 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
     if want_h2:
         if A.row_norm is None or (out_mul is None and B._bound is None):
             raise RuntimeError("gemm_h2(want_h2=True) needs A.row_norm (from A's producer) and a bound factor (weight_h2 / out_mul)")
-        Ch = H2(M, N, dev, per_row=True)
+        Ch = H2(M, N, dev, per_row=not out_per_tensor)
     ldc = Cf.stride(0) if Cf is not None else (pre_out.stride(0) if pre_out is not None else N)
     args = GemmTp3Args(M, N, K, A.buf.data_ptr(), A.rows, B.buf.data_ptr(), B.rows, _ps(Cf), ldc, None if Ct is None else Ct.buf.data_ptr(),
                        _p(bias), _ps(residual), 0 if residual is None else residual.stride(0), act, _ps(pre_out), _ps(dact_aux),
@@ -503,8 +512,10 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if Ch is not None:
-        _call("tvl_gemm_h2_out", C.byref(args), _p(A.inv_scale), Ch.buf.data_ptr(), _p(A.row_norm), float(B._bound if out_mul is None else out_mul),
-              float(out_add), _p(Ch.inv_scale))
+        # per-tensor mode: ONE bound from the largest row norm of A (a one-element device tensor), one scale for the whole image
+        norm = A.row_norm.max().reshape(1) if out_per_tensor else A.row_norm
+        _call("tvl_gemm_h2_out", C.byref(args), _p(A.inv_scale), Ch.buf.data_ptr(), _p(norm), float(B._bound if out_mul is None else out_mul),
+              float(out_add), _p(Ch.inv_scale), 1 if out_per_tensor else 0)
     else:
         _call("tvl_gemm_h2", C.byref(args), _p(A.inv_scale))
     if _gemm_prof is not None:
@@ -514,7 +525,7 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
     return Cf, (Ch if Ch is not None else Ct)
 
 
-_H2_EPI_BUILT = {192: {193, 161, 160, 192, 163}, 256: {213, 197, 200, 405, 389, 392}}   # launch_h2's compile-time epilogues per row tile (csrc/gemm_h2.hip)
+_H2_EPI_BUILT = {192: {193, 161, 160, 192, 163, 385, 384}, 256: {213, 197, 200, 405, 389, 392}}   # launch_h2's compile-time epilogues per row tile (csrc/gemm_h2.hip)
 
 
 def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_m=0, c_h2=False) -> str:
@@ -674,6 +685,7 @@ def layernorm_bwd_tp3(dy2d, x2d, gamma, mean, rstd, dres=None):
 
 
 GEMM_H2 = os.environ.get("TVL_GEMM_H2", "1") != "0"   # the four LayerNorm-fed GEMMs of a tp3 layer on two fp16 pieces (3 MFMAs per product)
+ATTN_H2 = os.environ.get("TVL_ATTN_H2", "1") != "0"   # attention of the tp3 layers on two fp16 pieces (QKV / dO as tensor-scaled h2 images)
 ATTN_TP3 = os.environ.get("TVL_ATTN_TP3", "1") != "0"   # 0: attention of the tp3 layers on the fp32-operand kernels (A/B switch)
 TP3_MIN_ROWS = int(os.environ.get("TVL_TP3_MIN_ROWS", "1024"))  # below this the layer is launch-latency bound either way
 
@@ -720,6 +732,31 @@ def attn_tp3_bwd(qkv_t: Tp3, o_t: Tp3, do_t: Tp3, lse, B: int, T: int, H: int, s
     g = Tp3(B * T, 3 * D, qkv_t.buf.device)
     delta = torch.empty((B, H, T), device=qkv_t.buf.device, dtype=torch.float32)
     _call("tvl_attn_tp3_bwd", qkv_t.buf.data_ptr(), o_t.buf.data_ptr(), do_t.buf.data_ptr(), _p(lse), _p(delta), g.buf.data_ptr(), B, H, T, float(scale))
+    return g
+
+
+def attn_h2_fwd(qkv_h: H2, B: int, T: int, H: int, scale: float, want_lse=True):
+    """Attention over the H2 image (ONE tensor scale) of the packed QKV matrix [B*T, 3*H*64]: returns (Tp3 image of O, lse)."""
+    D = H * 64
+    if qkv_h.rows != B * T or qkv_h.cols != 3 * D or qkv_h.per_row:
+        raise RuntimeError(f"attn_h2_fwd: QKV image is {qkv_h.shape} per_row={qkv_h.per_row}, expected {(B * T, 3 * D)} with one tensor scale")
+    o = Tp3(B * T, D, qkv_h.buf.device)
+    lse = torch.empty((B, H, T), device=qkv_h.buf.device, dtype=torch.float32) if want_lse else None
+    _call("tvl_attn_h2_fwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o.buf.data_ptr(), _p(lse), B, H, T, float(scale))
+    return o, lse
+
+
+def attn_h2_bwd(qkv_h: H2, o_t: Tp3, do_h: H2, lse, B: int, T: int, H: int, scale: float) -> Tp3:
+    """Backward of attn_h2_fwd: QKV and dO as tensor-scaled H2 images, O as Tp3; returns dQ | dK | dV as a Tp3 image."""
+    D = H * 64
+    if qkv_h.per_row or do_h.per_row or do_h.rows != B * T or do_h.cols != D:
+        raise RuntimeError("attn_h2_bwd: QKV / dO must be tensor-scaled H2 images of [B*T, 3D] / [B*T, D]")
+    dev = qkv_h.buf.device
+    g = Tp3(B * T, 3 * D, dev)
+    delta = torch.empty((B, H, T), device=dev, dtype=torch.float32)
+    dn = torch.empty(B * H, device=dev, dtype=torch.int32)
+    _call("tvl_attn_h2_bwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o_t.buf.data_ptr(), do_h.buf.data_ptr(), _p(do_h.inv_scale), _p(lse),
+          _p(delta), dn.data_ptr(), g.buf.data_ptr(), B, H, T, float(scale))
     return g
 
 

@@ -59,6 +59,7 @@ class LayerWeights:
                 ("wo_t", self.wo_t if self.wo_t is not None else t(self.wo)), ("w2_t", self.w2_t if self.w2_t is not None else t(self.w2)),
                 ("w1_t", self.w1_t if self.w1_t is not None else t(self.w1)))}
             self._h2["b1_max"] = float(self.b1.detach().abs().max().item()) * 1.0001
+            self._h2["bqkv_max"] = float(self.bqkv.detach().abs().max().item()) * 1.0001
         return self._h2
 
 
@@ -112,7 +113,13 @@ class EncoderLayerTp3Fn(Fn):
         gemm_ln = hip.gemm_h2 if use_h2 else hip.gemm_tp3
         WL = lw.h2() if use_h2 else W
         x1, mean1, rstd1 = ln_fwd(h2d, lw.ln1_w, lw.ln1_b, spec.eps, want_stats=need)
-        if hip.ATTN_TP3:   # Q | K | V never exist in fp32: the attention kernels read the GEMM epilogue's tp3 image by LDS-DMA
+        attn_h2 = use_h2 and hip.ATTN_H2
+        qkv_inv = None
+        if attn_h2:   # Q | K | V as ONE-scale two-piece fp16 image: 3 MFMAs per attention product (csrc/attention_h2.hip)
+            _, qkv_h = hip.gemm_h2(x1, WL["wqkv"], want_f32=False, want_h2=True, out_per_tensor=True, out_add=WL["bqkv_max"], bias=lw.bqkv)
+            o, lse = hip.attn_h2_fwd(qkv_h, B, T, H, dh**-0.5, want_lse=need)
+            qkv, qkv_inv = qkv_h.buf, qkv_h.inv_scale
+        elif hip.ATTN_TP3:   # Q | K | V never exist in fp32: the attention kernels read the GEMM epilogue's tp3 image by LDS-DMA
             _, qkv_t = gemm_ln(x1, WL["wqkv"], want_f32=False, want_tp3=True, bias=lw.bqkv)
             o, lse = hip.attn_tp3_fwd(qkv_t, B, T, H, dh**-0.5, want_lse=need)
             qkv = qkv_t.buf
@@ -132,13 +139,13 @@ class EncoderLayerTp3Fn(Fn):
             hip.gemm_tp3(a, W["w2"], out=out.view(M, D), bias=lw.b2, residual=h2)
         del x2
         if need:
-            ctx.save_for_backward(h2d, mean1, rstd1, qkv, o.buf, lse, h2, mean2, rstd2, z)
+            ctx.save_for_backward(h2d, mean1, rstd1, qkv, o.buf, lse, h2, mean2, rstd2, z, qkv_inv)
             ctx.lw, ctx.spec, ctx.shape = lw, spec, (B, T, D)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        h2d, mean1, rstd1, qkv, o_buf, lse, h2, mean2, rstd2, z = ctx.saved_tensors
+        h2d, mean1, rstd1, qkv, o_buf, lse, h2, mean2, rstd2, z, qkv_inv = ctx.saved_tensors
         lw, spec = ctx.lw, ctx.spec
         B, T, D = ctx.shape
         M = B * T
@@ -163,7 +170,10 @@ class EncoderLayerTp3Fn(Fn):
         dh2, dh2_t = ln_bwd(dx2, h2, lw.ln2_w, mean2, rstd2, dres=dout2d)
         del dx2
         o_t = hip.Tp3(M, D, o_buf.device, o_buf)
-        if hip.ATTN_TP3:
+        if qkv_inv is not None:   # the forward ran the attention on two fp16 pieces: dO as a one-scale h2 image too
+            _, do = hip.gemm_h2(dh2_t, WL["wo_t"], want_f32=False, want_h2=True, out_per_tensor=True)
+            dqkv = hip.attn_h2_bwd(hip.H2.wrap(M, 3 * D, qkv, qkv_inv, per_row=False), o_t, do, lse, B, T, H, dh**-0.5)
+        elif hip.ATTN_TP3:
             _, do = gemm_ln(dh2_t, WL["wo_t"], want_f32=False, want_tp3=True)
             dqkv = hip.attn_tp3_bwd(hip.Tp3(M, 3 * D, qkv.device, qkv), o_t, do, lse, B, T, H, dh**-0.5)
         else:
