@@ -659,6 +659,13 @@ def test_attention_on_h2_operands(hip, B, T, H):
     o, lse = hip.attn_h2_fwd(qh, B, T, H, dh**-0.5)
     close(o.float(), o_ref.float(), 3e-6, "attn h2 fwd O")
     close(lse, lse_ref, 2e-6, "attn h2 fwd lse")
-    g = hip.attn_h2_bwd(qh, o, hip.h2_pack(d_o, per_row=False), lse, B, T, H, dh**-0.5).float()
+    dh_ = hip.h2_pack(d_o, per_row=False)
+    g = hip.attn_h2_bwd(qh, o, dh_, lse, B, T, H, dh**-0.5).float()
     for name, c0 in (("dQ", 0), ("dK", D), ("dV", 2 * D)):
         close(g[:, c0:c0 + D], g_ref[:, c0:c0 + D], 1e-5, f"attn h2 bwd {name}")
+    # O as an h2 image that shares the QKV scale (the out-projection GEMM's A operand), and the backward reading it
+    o2, lse2 = hip.attn_h2_fwd(qh, B, T, H, dh**-0.5, o_as_h2=True)
+    assert torch.equal(lse2, lse)
+    close(o2.float(), o_ref.float(), 3e-6, "attn h2 fwd O as h2")
+    g2 = hip.attn_h2_bwd(qh, o2, dh_, lse, B, T, H, dh**-0.5).float()
+    close(g2, g, 2e-6, "attn h2 bwd with the h2 O")

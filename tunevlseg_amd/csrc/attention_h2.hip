@@ -145,7 +145,8 @@ __device__ __forceinline__ void mma_cols(unsigned t_rd, const f16x8 (&x0)[2], co
 
 struct FwdP {
     const unsigned char* qkv; int kb; const float* qkv_inv;   // h2 image of [B*T, 3*H*64], kb = 3*H*64/16; its inverse scale [1]
-    unsigned char* o_tp3; int o_kb;                            // tp3 image of O [B*T, H*64]
+    unsigned char* o_tp3; int o_kb;                            // image of O [B*T, H*64]: tp3, or (o_h2 != 0) h2 with the QKV image's scale
+    int o_h2;
     float* lse;
     int B, H, T; float scale;
 };
@@ -240,7 +241,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_h2_kernel(FwdP p) {
         wait_v<0>(vb); acc_o[1] = mma3_t(vb, pf1, acc_o[1]);
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = inv_q * P_INV / l_tot;   // V's scale, P's scale, the softmax denominator
+    // P's scale and the softmax denominator; V's scale is undone for a tp3 image and KEPT for an h2 image: O is a convex combination of
+    // V rows, so |O s| <= max |V s| < 2^14 -- the QKV image's scale is a valid scale for O as well
+    const float inv = (p.o_h2 ? 1.0f : inv_q) * P_INV / l_tot;
     if (qi < T) {
         const long m = (long)b * T + qi;
 #pragma unroll
@@ -248,7 +251,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_h2_kernel(FwdP p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float v[4] = {acc_o[d][4 * g] * inv, acc_o[d][4 * g + 1] * inv, acc_o[d][4 * g + 2] * inv, acc_o[d][4 * g + 3] * inv};
-                tp3::store4(p.o_tp3, p.o_kb, m, head * DH + d * 32 + 8 * g + 4 * h, v);
+                const int col = head * DH + d * 32 + 8 * g + 4 * h;
+                if (p.o_h2) h2::store4(p.o_tp3, p.o_kb, m, col, v);
+                else tp3::store4(p.o_tp3, p.o_kb, m, col, v);
             }
         if (h == 0 && p.lse) p.lse[((long)b * p.H + head) * T + qi] = (m_run * sc2 + log2f(l_tot)) * LN2;
     }
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_h2_kernel(FwdP p) {
 // ---- backward --------------------------------------------------------------------------------------------------------------------
 struct BwdP {
     const unsigned char* qkv; int kb; const float* qkv_inv;     // h2 image of packed QKV + its inverse scale [1]
-    const unsigned char* o_img;                                  // tp3 image of O [B*T, H*64] (the forward's output)
+    const unsigned char* o_img; int o_h2;                        // image of O [B*T, H*64] (the forward's output): tp3, or h2 with the QKV scale
     const unsigned char* do_img; int o_kb; const float* do_inv;  // h2 image of dO [B*T, H*64] + its inverse scale [1]; o_kb = H*64/16
     const float* lse;
     float* delta;                  // [B, H, T]: written by the dQ kernel, read by the dK/dV kernel
@@ -290,12 +295,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_h2_kernel(BwdP p) {
     for (int s = 0; s < 4; ++s) {
         row_frags(p.qkv, p.kb, m_q, head * 4 + s, h, qf[s]);
         row_frags(p.do_img, p.o_kb, m_q, head * 4 + s, h, dof[s]);
-        const unsigned char* osrc = p.o_img + ((m_q >> 5) * p.o_kb + head * 4 + s) * (long)tp3::BLK + (h * 32 + (int)(m_q & 31)) * 16;
-        const uint4 c[3] = {*reinterpret_cast<const uint4*>(osrc), *reinterpret_cast<const uint4*>(osrc + tp3::PIECE),
-                            *reinterpret_cast<const uint4*>(osrc + 2 * tp3::PIECE)};
         float x[8], y[8];
         join8(dof[s], x);
-        tp3::join8(c, y);
+        if (p.o_h2) {
+            f16x8 of[2];
+            row_frags(p.o_img, p.o_kb, m_q, head * 4 + s, h, of);
+            join8(of, y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] *= inv_q;
+        } else {
+            const unsigned char* osrc = p.o_img + ((m_q >> 5) * p.o_kb + head * 4 + s) * (long)tp3::BLK + (h * 32 + (int)(m_q & 31)) * 16;
+            const uint4 c[3] = {*reinterpret_cast<const uint4*>(osrc), *reinterpret_cast<const uint4*>(osrc + tp3::PIECE),
+                                *reinterpret_cast<const uint4*>(osrc + 2 * tp3::PIECE)};
+            tp3::join8(c, y);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { x[e] *= inv_do; dl += x[e] * y[e]; dn2 += x[e] * x[e]; }
     }
@@ -481,16 +494,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_h2_kernel(BwdP p) {
 
 }  // namespace
 
-// O = softmax(Q K^T * scale) V on the h2 image of packed QKV (one tensor scale: qkv_inv[1]); O as a tp3 image, lse [B, H, T].
-extern "C" int tvl_attn_h2_fwd(const void* qkv_h2, const float* qkv_inv, void* o_tp3, float* lse, int32_t B, int32_t H, int32_t T, float scale,
-                               tvlStream_t stream) {
+// O = softmax(Q K^T * scale) V on the h2 image of packed QKV (one tensor scale: qkv_inv[1]); O as a tp3 image or (o_as_h2 != 0) as an h2 image
+// that shares the QKV image's scale; lse [B, H, T].
+extern "C" int tvl_attn_h2_fwd(const void* qkv_h2, const float* qkv_inv, void* o_tp3, int32_t o_as_h2, float* lse, int32_t B, int32_t H, int32_t T,
+                               float scale, tvlStream_t stream) {
     TVL_REQUIRE(qkv_h2 && qkv_inv && o_tp3, "tvl_attn_h2_fwd: null pointer");
     TVL_REQUIRE(B > 0 && H > 0 && T > 0 && scale > 0.f, "tvl_attn_h2_fwd: bad shape / scale");
     TVL_REQUIRE(tvl_aligned16(qkv_h2) && tvl_aligned16(o_tp3), "tvl_attn_h2_fwd: images must be 16-byte aligned");
     TVL_REQUIRE((long)((T + 127) / 128) * H * B < (1L << 31), "tvl_attn_h2_fwd: grid too large");
     FwdP p;
     p.qkv = reinterpret_cast<const unsigned char*>(qkv_h2); p.kb = 3 * H * DH / 16; p.qkv_inv = qkv_inv;
-    p.o_tp3 = reinterpret_cast<unsigned char*>(o_tp3); p.o_kb = H * DH / 16; p.lse = lse;
+    p.o_tp3 = reinterpret_cast<unsigned char*>(o_tp3); p.o_kb = H * DH / 16; p.o_h2 = o_as_h2; p.lse = lse;
     p.B = B; p.H = H; p.T = T; p.scale = scale;
     dim3 grid((unsigned)((T + 127) / 128 * H * B));
     hipLaunchKernelGGL(attn_fwd_h2_kernel, grid, dim3(256), FWD_LDS, reinterpret_cast<hipStream_t>(stream), p);
@@ -499,7 +513,7 @@ extern "C" int tvl_attn_h2_fwd(const void* qkv_h2, const float* qkv_inv, void* o
 }
 
 // Backward: dQ | dK | dV as the tp3 image of the packed gradient.  delta: [B, H, T] fp32 workspace; dnorm_ws: [B, H] 4-byte workspace.
-extern "C" int tvl_attn_h2_bwd(const void* qkv_h2, const float* qkv_inv, const void* o_tp3, const void* do_h2, const float* do_inv, const float* lse,
+extern "C" int tvl_attn_h2_bwd(const void* qkv_h2, const float* qkv_inv, const void* o_tp3, int32_t o_is_h2, const void* do_h2, const float* do_inv, const float* lse,
                                float* delta, void* dnorm_ws, void* dqkv_tp3, int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream) {
     TVL_REQUIRE(qkv_h2 && qkv_inv && o_tp3 && do_h2 && do_inv && lse && delta && dnorm_ws && dqkv_tp3, "tvl_attn_h2_bwd: null pointer");
     TVL_REQUIRE(B > 0 && H > 0 && T > 0 && scale > 0.f, "tvl_attn_h2_bwd: bad shape / scale");
@@ -510,7 +524,7 @@ extern "C" int tvl_attn_h2_bwd(const void* qkv_h2, const float* qkv_inv, const v
     TVL_REQUIRE(e == hipSuccess, "tvl_attn_h2_bwd: memset failed: %s", hipGetErrorString(e));
     BwdP p;
     p.qkv = reinterpret_cast<const unsigned char*>(qkv_h2); p.kb = 3 * H * DH / 16; p.qkv_inv = qkv_inv;
-    p.o_img = reinterpret_cast<const unsigned char*>(o_tp3); p.do_img = reinterpret_cast<const unsigned char*>(do_h2); p.o_kb = H * DH / 16; p.do_inv = do_inv;
+    p.o_img = reinterpret_cast<const unsigned char*>(o_tp3); p.o_h2 = o_is_h2; p.do_img = reinterpret_cast<const unsigned char*>(do_h2); p.o_kb = H * DH / 16; p.do_inv = do_inv;
     p.lse = lse; p.delta = delta; p.dnorm_max = reinterpret_cast<unsigned*>(dnorm_ws); p.g_img = reinterpret_cast<unsigned char*>(dqkv_tp3);
     p.B = B; p.H = H; p.T = T; p.scale = scale;
     dim3 grid((unsigned)((T + 127) / 128 * H * B));

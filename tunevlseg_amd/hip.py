@@ -149,8 +149,8 @@ _SIGS = {
     "tvl_gemm_tp3": [C.POINTER(GemmTp3Args)],
     "tvl_h2_pack": [_P, _L, _L, _I, _P, _P, _P, _I, _P],
     "tvl_gemm_h2_out": [C.POINTER(GemmTp3Args), _P, _P, _P, _F, _F, _P, _I],
-    "tvl_attn_h2_fwd": [_P, _P, _P, _P, _I, _I, _I, _F],
-    "tvl_attn_h2_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
+    "tvl_attn_h2_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _F],
+    "tvl_attn_h2_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "tvl_gemm_h2": [C.POINTER(GemmTp3Args), _P],
     "tvl_layernorm_fwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F],
     "tvl_layernorm_bwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
@@ -494,8 +494,9 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
     ``A.row_norm[m] * out_mul + out_add`` (out_mul defaults to B's largest row norm)."""
     M = A.rows if M is None else M
     N, K = B.rows, A.cols
-    if B.cols != K or not A.per_row or B.per_row:
-        raise RuntimeError(f"gemm_h2: need A {A.shape} per-row scaled and B {B.shape} per-tensor scaled with equal K")
+    if B.cols != K or B.per_row:
+        raise RuntimeError(f"gemm_h2: need B {B.shape} per-tensor scaled and K = {K}")
+    a_scale = A.inv_scale if A.per_row else A.inv_scale.expand(A.rows).contiguous()   # a one-scale activation image (attention's O)
     dev = A.buf.device
     Cf = out if out is not None else (torch.empty((M, N), device=dev, dtype=torch.float32) if want_f32 else None)
     Ct = out_tp3 if out_tp3 is not None else (Tp3(M, N, dev) if want_tp3 else None)
@@ -514,10 +515,10 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
     if Ch is not None:
         # per-tensor mode: ONE bound from the largest row norm of A (a one-element device tensor), one scale for the whole image
         norm = A.row_norm.max().reshape(1) if out_per_tensor else A.row_norm
-        _call("tvl_gemm_h2_out", C.byref(args), _p(A.inv_scale), Ch.buf.data_ptr(), _p(norm), float(B._bound if out_mul is None else out_mul),
+        _call("tvl_gemm_h2_out", C.byref(args), _p(a_scale), Ch.buf.data_ptr(), _p(norm), float(B._bound if out_mul is None else out_mul),
               float(out_add), _p(Ch.inv_scale), 1 if out_per_tensor else 0)
     else:
-        _call("tvl_gemm_h2", C.byref(args), _p(A.inv_scale))
+        _call("tvl_gemm_h2", C.byref(args), _p(a_scale))
     if _gemm_prof is not None:
         e1.record()
         _gemm_prof.append((h2_kernel_name(M, N, bias is not None, residual is not None, act, dact, pre_out is not None, Cf is not None,
@@ -735,19 +736,25 @@ def attn_tp3_bwd(qkv_t: Tp3, o_t: Tp3, do_t: Tp3, lse, B: int, T: int, H: int, s
     return g
 
 
-def attn_h2_fwd(qkv_h: H2, B: int, T: int, H: int, scale: float, want_lse=True):
-    """Attention over the H2 image (ONE tensor scale) of the packed QKV matrix [B*T, 3*H*64]: returns (Tp3 image of O, lse)."""
+def attn_h2_fwd(qkv_h: H2, B: int, T: int, H: int, scale: float, want_lse=True, o_as_h2=False):
+    """Attention over the H2 image (ONE tensor scale) of the packed QKV matrix [B*T, 3*H*64]: returns (image of O, lse); O as Tp3, or
+    (o_as_h2) as an H2 image that shares the QKV image's scale (|O| <= max |V|)."""
     D = H * 64
     if qkv_h.rows != B * T or qkv_h.cols != 3 * D or qkv_h.per_row:
         raise RuntimeError(f"attn_h2_fwd: QKV image is {qkv_h.shape} per_row={qkv_h.per_row}, expected {(B * T, 3 * D)} with one tensor scale")
-    o = Tp3(B * T, D, qkv_h.buf.device)
+    if o_as_h2:
+        o = H2(B * T, D, qkv_h.buf.device, per_row=False)
+        o.inv_scale = qkv_h.inv_scale
+    else:
+        o = Tp3(B * T, D, qkv_h.buf.device)
     lse = torch.empty((B, H, T), device=qkv_h.buf.device, dtype=torch.float32) if want_lse else None
-    _call("tvl_attn_h2_fwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o.buf.data_ptr(), _p(lse), B, H, T, float(scale))
+    _call("tvl_attn_h2_fwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o.buf.data_ptr(), 1 if o_as_h2 else 0, _p(lse), B, H, T, float(scale))
     return o, lse
 
 
-def attn_h2_bwd(qkv_h: H2, o_t: Tp3, do_h: H2, lse, B: int, T: int, H: int, scale: float) -> Tp3:
-    """Backward of attn_h2_fwd: QKV and dO as tensor-scaled H2 images, O as Tp3; returns dQ | dK | dV as a Tp3 image."""
+def attn_h2_bwd(qkv_h: H2, o_t, do_h: H2, lse, B: int, T: int, H: int, scale: float) -> Tp3:
+    """Backward of attn_h2_fwd: QKV and dO as tensor-scaled H2 images, O as Tp3 or as the H2 image the forward wrote; returns
+    dQ | dK | dV as a Tp3 image."""
     D = H * 64
     if qkv_h.per_row or do_h.per_row or do_h.rows != B * T or do_h.cols != D:
         raise RuntimeError("attn_h2_bwd: QKV / dO must be tensor-scaled H2 images of [B*T, 3D] / [B*T, D]")
@@ -755,7 +762,8 @@ def attn_h2_bwd(qkv_h: H2, o_t: Tp3, do_h: H2, lse, B: int, T: int, H: int, scal
     g = Tp3(B * T, 3 * D, dev)
     delta = torch.empty((B, H, T), device=dev, dtype=torch.float32)
     dn = torch.empty(B * H, device=dev, dtype=torch.int32)
-    _call("tvl_attn_h2_bwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o_t.buf.data_ptr(), do_h.buf.data_ptr(), _p(do_h.inv_scale), _p(lse),
+    _call("tvl_attn_h2_bwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o_t.buf.data_ptr(), 1 if isinstance(o_t, H2) else 0, do_h.buf.data_ptr(),
+          _p(do_h.inv_scale), _p(lse),
           _p(delta), dn.data_ptr(), g.buf.data_ptr(), B, H, T, float(scale))
     return g
 

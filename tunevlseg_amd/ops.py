@@ -55,7 +55,7 @@ class LayerWeights:
         if self._h2 is None:
             t = lambda w: w.detach().t().contiguous()  # noqa: E731
             self._h2 = {k: hip.weight_h2(w) for k, w in (
-                ("wqkv", self.wqkv), ("w1", self.w1), ("w2", self.w2),
+                ("wqkv", self.wqkv), ("wo", self.wo), ("w1", self.w1), ("w2", self.w2),
                 ("wo_t", self.wo_t if self.wo_t is not None else t(self.wo)), ("w2_t", self.w2_t if self.w2_t is not None else t(self.w2)),
                 ("w1_t", self.w1_t if self.w1_t is not None else t(self.w1)))}
             self._h2["b1_max"] = float(self.b1.detach().abs().max().item()) * 1.0001
@@ -117,7 +117,7 @@ class EncoderLayerTp3Fn(Fn):
         qkv_inv = None
         if attn_h2:   # Q | K | V as ONE-scale two-piece fp16 image: 3 MFMAs per attention product (csrc/attention_h2.hip)
             _, qkv_h = hip.gemm_h2(x1, WL["wqkv"], want_f32=False, want_h2=True, out_per_tensor=True, out_add=WL["bqkv_max"], bias=lw.bqkv)
-            o, lse = hip.attn_h2_fwd(qkv_h, B, T, H, dh**-0.5, want_lse=need)
+            o, lse = hip.attn_h2_fwd(qkv_h, B, T, H, dh**-0.5, want_lse=need, o_as_h2=True)   # O shares the QKV scale: |O| <= max |V|
             qkv, qkv_inv = qkv_h.buf, qkv_h.inv_scale
         elif hip.ATTN_TP3:   # Q | K | V never exist in fp32: the attention kernels read the GEMM epilogue's tp3 image by LDS-DMA
             _, qkv_t = gemm_ln(x1, WL["wqkv"], want_f32=False, want_tp3=True, bias=lw.bqkv)
@@ -127,7 +127,10 @@ class EncoderLayerTp3Fn(Fn):
             qkv, _ = hip.gemm_tp3(x1, W["wqkv"], bias=lw.bqkv)
             o, lse = hip.attn_fwd_packed_tp3(qkv, B, T, H, dh, dh**-0.5, want_lse=need)
         del x1
-        h2, _ = hip.gemm_tp3(o, W["wo"], bias=lw.bo, residual=h2d)
+        if isinstance(o, hip.H2):
+            h2, _ = hip.gemm_h2(o, WL["wo"], bias=lw.bo, residual=h2d)
+        else:
+            h2, _ = hip.gemm_tp3(o, W["wo"], bias=lw.bo, residual=h2d)
         x2, mean2, rstd2 = ln_fwd(h2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
         z = torch.empty((M, lw.w1.shape[0]), device=h.device, dtype=torch.float32) if need else None
         out = torch.empty((B, T, D), device=h.device, dtype=torch.float32)  # a base tensor: deep prompts overwrite rows in place
@@ -169,7 +172,7 @@ class EncoderLayerTp3Fn(Fn):
         del dz
         dh2, dh2_t = ln_bwd(dx2, h2, lw.ln2_w, mean2, rstd2, dres=dout2d)
         del dx2
-        o_t = hip.Tp3(M, D, o_buf.device, o_buf)
+        o_t = hip.H2.wrap(M, D, o_buf, qkv_inv, per_row=False) if qkv_inv is not None else hip.Tp3(M, D, o_buf.device, o_buf)
         if qkv_inv is not None:   # the forward ran the attention on two fp16 pieces: dO as a one-scale h2 image too
             _, do = hip.gemm_h2(dh2_t, WL["wo_t"], want_f32=False, want_h2=True, out_per_tensor=True)
             dqkv = hip.attn_h2_bwd(hip.H2.wrap(M, 3 * D, qkv, qkv_inv, per_row=False), o_t, do, lse, B, T, H, dh**-0.5)
