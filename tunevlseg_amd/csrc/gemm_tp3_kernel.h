@@ -99,8 +99,9 @@ __device__ __forceinline__ long tp3_off(long row, int col, int kblocks) { return
 // instruction-fetch rate (20 us per 192x256 tile; stamps in profiles/r2_gemm_experiments.md), not at the store rate.
 enum { E_BIAS = 1, E_RES = 2, E_QGELU = 4, E_DQGELU = 8, E_PRE = 16, E_F32 = 32, E_TP3 = 64, E_RSCALE = 128, E_H2OUT = 256 };
 
+// h2_sc: the row's power-of-two scale of an h2 output (computed once per row by epilogue(), not once per four columns)
 template <int EPI, bool NOSTORE = false>
-__device__ __forceinline__ void emit4(const Tp3Params& p, long row, int col, float4 a) {
+__device__ __forceinline__ void emit4(const Tp3Params& p, long row, int col, float4 a, float h2_sc = 1.0f) {
     constexpr bool G = EPI < 0;
     float v[4] = {a.x, a.y, a.z, a.w};
     if (G || (EPI & E_RSCALE)) {   // alpha, and the operand row scale of the two-piece fp16 format
@@ -146,10 +147,7 @@ __device__ __forceinline__ void emit4(const Tp3Params& p, long row, int col, flo
         for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(o + s * PIECE) = pl[s];
     }
     if (G ? p.Ch2 != nullptr : (EPI & E_H2OUT) != 0) {
-        const float inv = h2::inv_scale_of(p.out_norm[row * p.out_stride] * p.out_mul + p.out_add);
-        if (col == 0 && (p.out_stride || row == 0)) p.out_inv[row * p.out_stride] = inv;   // once per row (or once per tensor)
-        const float sc = 1.0f / inv;          // a power of two: exact
-        const float w[4] = {v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
+        const float w[4] = {v[0] * h2_sc, v[1] * h2_sc, v[2] * h2_sc, v[3] * h2_sc};
         h2::store4(p.Ch2, p.N >> 4, row, col, w);
     }
 }
@@ -162,6 +160,22 @@ __device__ __forceinline__ void epilogue(const Tp3Params& p, f32x16 (&acc)[TM][T
     constexpr int LDS_ROW = 36;
     const int l31 = lane & 31, h = lane >> 5;
     const int rr = lane >> 3, cc = (lane & 7) * 4;
+    // h2 output: the rows' scales (a bound -> a power of two, tp3.h) once per row into the tail of the wave's scratch; the workgroup
+    // that owns the rows' first columns also publishes the inverse scales for the consuming GEMM
+    constexpr bool H2O = EPI < 0 || (EPI & E_H2OUT) != 0;
+    float* rowsc = scratch + TM * 32 * LDS_ROW;
+    const bool h2o = H2O && (EPI >= 0 || p.Ch2 != nullptr);
+    if (h2o) {
+        for (int rl = lane; rl < TM * 32; rl += 64) {
+            const int row = row_base + rl;
+            float inv = 1.0f;
+            if (row < p.M) {
+                inv = h2::inv_scale_of(p.out_norm[(long)row * p.out_stride] * p.out_mul + p.out_add);
+                if (col_base == 0 && (p.out_stride || row == 0)) p.out_inv[(long)row * p.out_stride] = inv;
+            }
+            rowsc[rl] = 1.0f / inv;   // a power of two: exact
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -176,7 +190,7 @@ __device__ __forceinline__ void epilogue(const Tp3Params& p, f32x16 (&acc)[TM][T
             for (int rl = rr; rl < TM * 32; rl += 8) {
                 const float4 v = *reinterpret_cast<const float4*>(&scratch[rl * LDS_ROW + cc]);
                 const int row = row_base + rl;
-                if (row < p.M) emit4<EPI, NOSTORE>(p, row, col, v);
+                if (row < p.M) emit4<EPI, NOSTORE>(p, row, col, v, h2o ? rowsc[rl] : 1.0f);
             }
         }
     }
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     stamp(2);
     __syncthreads();  // every wave is past its last LDS read: the stages become epilogue scratch
     stamp(4);
-    float* scratch = reinterpret_cast<float*>(smem) + wave * (TM * 32 * 36);
+    float* scratch = reinterpret_cast<float*>(smem) + wave * (TM * 32 * 37);   // 36 floats per row of the strip + 1 per row for an h2 output's scale
     epilogue<TM, TN, EPI, ABL_NOSTORE>(p, acc, tile_m * BM + wm * WM, tile_n * BN + wn * WN, lane, scratch);
     if constexpr (STAMP) {
         stamp(5);
@@ -385,7 +399,7 @@ int launch(const Tp3Params& p0, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     constexpr size_t stage_bytes = (size_t)3 * (NP * (BM + BN) / 32) * PIECE;
-    constexpr size_t epi_bytes = (size_t)NWAVE * (BM / 2) * 36 * sizeof(float);
+    constexpr size_t epi_bytes = (size_t)NWAVE * (BM / 2) * 37 * sizeof(float);
     constexpr size_t smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = gemm_tp3_kernel<BM, BN, VARIANT, EPI, NP>;
