@@ -306,12 +306,16 @@ int tvl_gemm_h2(const tvlGemmTp3Args* args, const float* a_row_scale, tvlStream_
  * activation's Lipschitz bound; out_add = max |bias|); the inverse scales are written to out_inv_scale[M]. */
 int tvl_gemm_h2_out(const tvlGemmTp3Args* args, const float* a_row_scale, void* c_h2, const float* out_row_norm, float out_mul, float out_add,
                     float* out_inv_scale, int32_t out_per_tensor /* != 0: one bound out_row_norm[0] and one scale out_inv_scale[0] */, tvlStream_t stream);
+/* tvl_gemm_h2 with A scaled per (row, 64-column chunk of K): a_kscale[M][K / 64] inverse scales (the packed attention gradient written by
+ * tvl_attn_h2_bwd with g_as_h2 != 0); plain fp32 output: the QKV data gradient. */
+int tvl_gemm_h2_ks(const tvlGemmTp3Args* args, const float* a_kscale, tvlStream_t stream);
 /* Attention on two-piece fp16 operands (3 MFMAs per product; csrc/attention_h2.hip): packed QKV and dO as h2 images with ONE scale each
  * (tvl_gemm_h2_out in per-tensor mode), O and dQ | dK | dV as tp3 images.  delta: [B, H, T] fp32 workspace; dnorm_ws: [B, H] x 4 bytes. */
 int tvl_attn_h2_fwd(const void* qkv_h2, const float* qkv_inv, void* o_img, int32_t o_as_h2 /* O as an h2 image sharing the QKV scale, else tp3 */,
                     float* lse, int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream);
 int tvl_attn_h2_bwd(const void* qkv_h2, const float* qkv_inv, const void* o_img, int32_t o_is_h2, const void* do_h2, const float* do_inv, const float* lse,
-                    float* delta, void* dnorm_ws, void* dqkv_tp3, int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream);
+                    float* delta, void* dnorm_ws, void* dqkv_img, int32_t g_as_h2 /* h2 image + g_kscale [B*T, 3*H], else tp3 */, float* g_kscale,
+                    int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream);
 /* LayerNorm forward / backward writing their result as an h2 operand (+ inv_scale[rows]); otherwise as tvl_layernorm_fwd_tp3 / _bwd_tp3 */
 int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const float* beta, void* y_h2, float* inv_scale, float* row_norm /* or null */, float* mean, float* rstd,
                          int64_t rows, int32_t cols, float eps, tvlStream_t stream);

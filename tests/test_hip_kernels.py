@@ -669,3 +669,15 @@ def test_attention_on_h2_operands(hip, B, T, H):
     close(o2.float(), o_ref.float(), 3e-6, "attn h2 fwd O as h2")
     g2 = hip.attn_h2_bwd(qh, o2, dh_, lse, B, T, H, dh**-0.5).float()
     close(g2, g, 2e-6, "attn h2 bwd with the h2 O")
+    # the gradient as an h2 image with one exact scale per (row, head, part), and the GEMM that rescales its accumulators per 64-column chunk
+    gk = hip.attn_h2_bwd(qh, o2, dh_, lse, B, T, H, dh**-0.5, out_h2=True)
+    inv = gk.kscale.cpu()
+    assert torch.equal(inv, torch.exp2(torch.round(torch.log2(inv))))
+    blocks = g2.cpu().view(B * T, 3 * H, 64)
+    err = (gk.float().cpu().view(B * T, 3 * H, 64) - blocks).abs().amax(2)
+    assert (err <= blocks.abs().amax(2) * 2.0**-19 + 1e-30).all()   # every (row, head) block keeps its own precision
+    w = dev(rnd(D, 3 * D, seed=23) * 0.03)
+    ref = g2.double().cpu() @ w.double().cpu().T
+    den = g2.abs().double().cpu() @ w.abs().double().cpu().T
+    got = hip.gemm_h2_ks(gk, hip.weight_h2(w)).cpu().double()
+    assert ((got - ref).abs() / (den + 1e-300)).max().item() < 5e-6

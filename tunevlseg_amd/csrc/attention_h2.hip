@@ -267,12 +267,37 @@ struct BwdP {
     const float* lse;
     float* delta;                  // [B, H, T]: written by the dQ kernel, read by the dK/dV kernel
     unsigned* dnorm_max;           // [B, H]: bits of max_q ||dO_q|| (true units) per (sample, head); zeroed by the entry point
-    unsigned char* g_img;          // tp3 image of dQ | dK | dV [B*T, 3*H*64]
+    unsigned char* g_img;          // image of dQ | dK | dV [B*T, 3*H*64]: tp3, or (g_h2 != 0) h2 with one scale per (row, 64-column block):
+    int g_h2; float* g_kscale;     // g_kscale[m * 3H + part * H + head] = that block's inverse scale (exact: the writer holds the block)
     int B, H, T; float scale;
 };
 
 constexpr int BWD_STAGE = 16 * PIECE + 256;   // two 8-piece tiles + 64 floats (log-sum-exp | delta of a query tile; dK/dV kernel only)
 constexpr int BWD_LDS = 2 * BWD_STAGE;
+
+// one (row, 64-column block) of the packed gradient: the lane pair (l31, l31 + 32) holds its 64 values (factor f already applied)
+__device__ __forceinline__ void store_block(const BwdP& p, long m, int col0, int chunk, int h, const f32x16 (&acc)[2], float f) {
+    if (p.g_h2) {
+        float amax = 0.f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(acc[d][r] * f));
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const float inv = h2::inv_scale_of(amax);
+        if (h == 0) p.g_kscale[m * (3L * p.H) + chunk] = inv;
+        f *= 1.0f / inv;
+    }
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float v[4] = {acc[d][4 * g] * f, acc[d][4 * g + 1] * f, acc[d][4 * g + 2] * f, acc[d][4 * g + 3] * f};
+            const int col = col0 + d * 32 + 8 * g + 4 * h;
+            if (p.g_h2) h2::store4(p.g_img, p.kb, m, col, v);
+            else tp3::store4(p.g_img, p.kb, m, col, v);
+        }
+}
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_h2_kernel(BwdP p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -371,17 +396,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_h2_kernel(BwdP p) {
         pieces_of(ds, x0, x1);
         mma_cols(st + tr_off, x0, x1, acc_dq);                     // dQ^T += K^T . dS^T
     }
-    if (qi < T) {
-        const long m = (long)b * T + qi;
-        const float f = p.scale * inv_q * ds_inv;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float v[4] = {acc_dq[d][4 * g] * f, acc_dq[d][4 * g + 1] * f, acc_dq[d][4 * g + 2] * f, acc_dq[d][4 * g + 3] * f};
-                tp3::store4(p.g_img, p.kb, m, head * DH + d * 32 + 8 * g + 4 * h, v);
-            }
-    }
+    if (qi < T) store_block(p, (long)b * T + qi, head * DH, head, h, acc_dq, p.scale * inv_q * ds_inv);
 }
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_h2_kernel(BwdP p) {
@@ -478,17 +493,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_h2_kernel(BwdP p) {
     }
     if (key_ok) {
         const long m = (long)b * T + ki;
-        const float fk = p.scale * inv_q * ds_inv, fv = inv_do * P_INV;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = head * DH + d * 32 + 8 * g + 4 * h;
-                const float vk[4] = {acc_dk[d][4 * g] * fk, acc_dk[d][4 * g + 1] * fk, acc_dk[d][4 * g + 2] * fk, acc_dk[d][4 * g + 3] * fk};
-                const float vv[4] = {acc_dv[d][4 * g] * fv, acc_dv[d][4 * g + 1] * fv, acc_dv[d][4 * g + 2] * fv, acc_dv[d][4 * g + 3] * fv};
-                tp3::store4(p.g_img, p.kb, m, D + col, vk);
-                tp3::store4(p.g_img, p.kb, m, 2 * D + col, vv);
-            }
+        store_block(p, m, D + head * DH, p.H + head, h, acc_dk, p.scale * inv_q * ds_inv);
+        store_block(p, m, 2 * D + head * DH, 2 * p.H + head, h, acc_dv, inv_do * P_INV);
     }
 }
 
@@ -512,13 +518,16 @@ extern "C" int tvl_attn_h2_fwd(const void* qkv_h2, const float* qkv_inv, void* o
     return 0;
 }
 
-// Backward: dQ | dK | dV as the tp3 image of the packed gradient.  delta: [B, H, T] fp32 workspace; dnorm_ws: [B, H] 4-byte workspace.
+// Backward: dQ | dK | dV as the tp3 image of the packed gradient, or (g_as_h2 != 0) as an h2 image with one exact scale per (row, 64-column
+// block) in g_kscale [B*T, 3*H] (the A operand of tvl_gemm_h2_ks).  delta: [B, H, T] fp32 workspace; dnorm_ws: [B, H] 4-byte workspace.
 extern "C" int tvl_attn_h2_bwd(const void* qkv_h2, const float* qkv_inv, const void* o_tp3, int32_t o_is_h2, const void* do_h2, const float* do_inv, const float* lse,
-                               float* delta, void* dnorm_ws, void* dqkv_tp3, int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream) {
+                               float* delta, void* dnorm_ws, void* dqkv_tp3, int32_t g_as_h2, float* g_kscale, int32_t B, int32_t H, int32_t T, float scale,
+                               tvlStream_t stream) {
     TVL_REQUIRE(qkv_h2 && qkv_inv && o_tp3 && do_h2 && do_inv && lse && delta && dnorm_ws && dqkv_tp3, "tvl_attn_h2_bwd: null pointer");
     TVL_REQUIRE(B > 0 && H > 0 && T > 0 && scale > 0.f, "tvl_attn_h2_bwd: bad shape / scale");
     TVL_REQUIRE(tvl_aligned16(qkv_h2) && tvl_aligned16(o_tp3) && tvl_aligned16(do_h2) && tvl_aligned16(dqkv_tp3), "tvl_attn_h2_bwd: images must be 16-byte aligned");
     TVL_REQUIRE((long)((T + 127) / 128) * H * B < (1L << 31), "tvl_attn_h2_bwd: grid too large");
+    TVL_REQUIRE(!g_as_h2 || g_kscale, "tvl_attn_h2_bwd: an h2 gradient image needs g_kscale [B*T, 3*H]");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(dnorm_ws, 0, sizeof(unsigned) * (size_t)B * H, s);
     TVL_REQUIRE(e == hipSuccess, "tvl_attn_h2_bwd: memset failed: %s", hipGetErrorString(e));
@@ -526,6 +535,7 @@ extern "C" int tvl_attn_h2_bwd(const void* qkv_h2, const float* qkv_inv, const v
     p.qkv = reinterpret_cast<const unsigned char*>(qkv_h2); p.kb = 3 * H * DH / 16; p.qkv_inv = qkv_inv;
     p.o_img = reinterpret_cast<const unsigned char*>(o_tp3); p.o_h2 = o_is_h2; p.do_img = reinterpret_cast<const unsigned char*>(do_h2); p.o_kb = H * DH / 16; p.do_inv = do_inv;
     p.lse = lse; p.delta = delta; p.dnorm_max = reinterpret_cast<unsigned*>(dnorm_ws); p.g_img = reinterpret_cast<unsigned char*>(dqkv_tp3);
+    p.g_h2 = g_as_h2; p.g_kscale = g_kscale;
     p.B = B; p.H = H; p.T = T; p.scale = scale;
     dim3 grid((unsigned)((T + 127) / 128 * H * B));
     hipLaunchKernelGGL(attn_bwd_dq_h2_kernel, grid, dim3(256), BWD_LDS, s, p);      // writes delta and dnorm_max ...

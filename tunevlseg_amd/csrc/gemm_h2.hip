@@ -200,3 +200,22 @@ extern "C" int tvl_gemm_h2_out(const tvlGemmTp3Args* a, const float* a_row_scale
     return gemm_h2_impl(a, a_row_scale, c_h2, out_row_norm, out_mul, out_add, out_inv_scale, out_per_tensor, stream);
 }
 
+// A with one inverse scale per (row, 64-column chunk of K): a_kscale[M][K / 64] -- the packed attention gradient dQ | dK | dV, whose
+// (row, head) blocks are written by different workgroups, each with the block's exact maximum (tvl_attn_h2_bwd, h2 output).  fp32 output.
+extern "C" int tvl_gemm_h2_ks(const tvlGemmTp3Args* a, const float* a_kscale, tvlStream_t stream) {
+    TVL_REQUIRE(a != nullptr && a_kscale != nullptr, "tvl_gemm_h2_ks: null args");
+    TVL_REQUIRE(a->M > 0 && a->N > 0 && a->K >= 64 && a->K % 64 == 0 && a->K <= 4096 && a->N % 16 == 0, "tvl_gemm_h2_ks: need K %% 64 == 0, 64 <= K <= 4096, N %% 16 == 0 (K=%d N=%d)", a->K, a->N);
+    TVL_REQUIRE(a->A && a->B && a->C && !a->C_tp3 && !a->bias && !a->residual && !a->pre_out && !a->dact && !a->act, "tvl_gemm_h2_ks: plain fp32 output only");
+    TVL_REQUIRE(tvl_aligned16(a->A) && tvl_aligned16(a->B) && tvl_aligned16(a->C) && a->ldc >= a->N && a->ldc % 4 == 0, "tvl_gemm_h2_ks: alignment / ldc");
+    TVL_REQUIRE(a->a_rows >= a->M && a->b_rows >= a->N, "tvl_gemm_h2_ks: operand images hold fewer rows than M / N");
+    Tp3Params p = {};
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.A = reinterpret_cast<const unsigned char*>(a->A); p.a_rb = (int)((a->a_rows + 31) / 32);
+    p.B = reinterpret_cast<const unsigned char*>(a->B); p.b_rb = (int)((a->b_rows + 31) / 32);
+    p.C = a->C; p.ldc = a->ldc; p.alpha = a->alpha; p.a_kscale = a_kscale; p.k_chunks = a->K / 64;
+    const int rc = launch<192, 256, 3, E_F32 | E_RSCALE, 2, true>(p, reinterpret_cast<hipStream_t>(stream));
+    TVL_REQUIRE(rc == 0, "tvl_gemm_h2_ks: launch failed (dynamic LDS opt-in?)");
+    TVL_LAUNCH_CHECK("tvl_gemm_h2_ks");
+    return 0;
+}
+

@@ -60,6 +60,9 @@ struct Tp3Params {
     // |out[m, n]| <= out_norm[m] * out_mul + out_add (out_norm = ||A row m||_2 from A's producer, out_mul = max_n ||B row n||_2 times
     // the activation's Lipschitz bound, out_add = max |bias|); the epilogue writes the inverse scale to out_inv[m]
     unsigned char* Ch2; const float* out_norm; float out_mul, out_add; float* out_inv;
+    // A with one scale per (row, 64-column chunk of K) -- dQ | dK | dV: every (row, head) block is written by one attention workgroup that
+    // knows its exact maximum.  a_kscale[m * k_chunks + c] = inverse scale of A's columns 64 c .. 64 c + 63 in row m (KS kernels only)
+    const float* a_kscale; int k_chunks;
     int out_stride;   // 1: out_norm / out_inv are per row; 0: one bound and one scale for the whole output (out_norm[0], out_inv[0])
     int tiles_m, tiles_n;
 };
@@ -105,7 +108,8 @@ __device__ __forceinline__ void emit4(const Tp3Params& p, long row, int col, flo
     constexpr bool G = EPI < 0;
     float v[4] = {a.x, a.y, a.z, a.w};
     if (G || (EPI & E_RSCALE)) {   // alpha, and the operand row scale of the two-piece fp16 format
-        const float f = (G ? (p.a_scale != nullptr) : true) ? p.alpha * p.a_scale[row] : p.alpha;
+        const float f = p.a_kscale ? p.alpha * p.a_kscale[row * p.k_chunks + p.k_chunks - 1]   // the accumulator carries the LAST chunk's scale
+                                   : ((G ? (p.a_scale != nullptr) : true) ? p.alpha * p.a_scale[row] : p.alpha);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= f;
     }
@@ -218,7 +222,10 @@ __device__ __forceinline__ void read_all(Frags<TM, TN, NP>& f, unsigned a_addr, 
 
 // NP = pieces per operand element: 3 (bf16 pieces, 6 products per k-step: the tp3 format) or 2 (fp16 pieces, 3 products: the "h2" format,
 // gemm_h2.hip -- same block order, 2 KiB per 32 x 16 block, operands pre-scaled by exact powers of two)
-template <int BM, int BN, int VARIANT, int EPI, int NP = 3>
+// KS: A carries one power-of-two scale per (row, 64-column chunk of K) (a_kscale).  The accumulators hold the sum scaled by the CURRENT
+// chunk's scale; at a chunk boundary (every four 16-deep slabs) each lane multiplies its rows' accumulators by s_next / s_cur -- a power of
+// two, exact -- and the epilogue undoes the last chunk's scale.  The ratios sit in LDS behind the three stages (BM x k_chunks floats).
+template <int BM, int BN, int VARIANT, int EPI, int NP = 3, bool KS = false>
 __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     Tp3Params p = p_in;
     float* const stamp_buf = p_in.pre_out;
@@ -309,6 +316,19 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     const unsigned a_frag = lds0 + lane * 16 + wm * (TM * BLKP);
     const unsigned b_frag = lds0 + lane * 16 + PA * PIECE + wn * (TN * BLKP);
 
+    // KS: ratio table R[row][c] = inv[row][c-1] / inv[row][c] (c >= 1) behind the stages, before any LDS-DMA is in flight
+    const unsigned ktab = lds0 + 3 * STAGE;
+    if constexpr (KS) {
+        float* tab = reinterpret_cast<float*>(smem + 3 * STAGE);
+        const int nch = p.k_chunks;
+        for (int e = threadIdx.x; e < BM * nch; e += NTH) {
+            const int rl = e / nch, c = e - rl * nch;
+            long row = (long)tile_m * BM + rl;
+            row = row < p.M ? row : p.M - 1;
+            tab[e] = c ? p.a_kscale[row * nch + c - 1] / p.a_kscale[row * nch + c] : 1.0f;
+        }
+        __syncthreads();
+    }
     // prologue: three slabs in flight, wait for the first
     issue(0, 0);
     if (nk > 1) issue(1, 1);
@@ -325,10 +345,31 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     // One slab.  `cur` holds slab kt's fragments (requested one slab ago); unless LAST, `nxt` receives slab kt+1's.
     //   INFLIGHT: DMA groups that may stay in flight while slab kt+1 is awaited (1 in steady state, 0 near the end);
     //   ISSUE:    slab kt+3 exists and is requested into the stage slab kt has just left.
+    float kratio[TM];   // KS: this lane's rows' ratios for the next chunk boundary (requested one boundary ahead)
+    auto kratio_request = [&](int c) {
+        if constexpr (KS) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                asm volatile("ds_read_b32 %0, %1" : "=v"(kratio[i]) : "v"(ktab + (unsigned)(((wm * WM + i * 32 + (lane & 31)) * p.k_chunks + c) * 4)));
+        }
+    };
+    if constexpr (KS) kratio_request(1);
     auto step = [&]<int INFLIGHT, bool ISSUE, bool LAST>(StepMode<INFLIGHT, ISSUE, LAST>, int kt, int st_cur, Frags<TM, TN, NP>& cur,
                                                          Frags<TM, TN, NP>& nxt) {
         if constexpr (!LAST && !ABL_NODMA) wait_groups<PT>(INFLIGHT, extra);   // this wave's pieces of slab kt+1 have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // `cur` is complete and this wave no longer reads stage st_cur
+        if constexpr (KS) {
+            if ((kt & 3) == 0 && kt) {   // slab kt opens chunk kt / 4: bring the accumulators to its scale, request the next boundary's ratios
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] *= kratio[i];
+                const int cn = (kt >> 2) + 1;
+                kratio_request(cn < p.k_chunks ? cn : p.k_chunks - 1);
+            }
+        }
         if constexpr (!LAST) __builtin_amdgcn_s_barrier();        // ... nor does any other wave, and their pieces landed too
         __builtin_amdgcn_sched_barrier(0);
         const int st_nxt = st_cur == 2 ? 0 : st_cur + 1;
@@ -393,16 +434,17 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     }
 }
 
-template <int BM, int BN, int VARIANT, int EPI, int NP = 3>
+template <int BM, int BN, int VARIANT, int EPI, int NP = 3, bool KS = false>
 int launch(const Tp3Params& p0, hipStream_t s) {
     Tp3Params p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     constexpr size_t stage_bytes = (size_t)3 * (NP * (BM + BN) / 32) * PIECE;
     constexpr size_t epi_bytes = (size_t)NWAVE * (BM / 2) * 37 * sizeof(float);
-    constexpr size_t smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    constexpr size_t ks_bytes = KS ? (size_t)BM * 64 * sizeof(float) : 0;   // ratio table: up to 64 chunks (K <= 4096)
+    constexpr size_t smem = (stage_bytes + ks_bytes) > epi_bytes ? (stage_bytes + ks_bytes) : epi_bytes;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = gemm_tp3_kernel<BM, BN, VARIANT, EPI, NP>;
+    auto kern = gemm_tp3_kernel<BM, BN, VARIANT, EPI, NP, KS>;
     static int attr_dev_mask = 0;  // per device: the opt-in for > 64 KiB of dynamic LDS is a per-device function attribute
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1;
@@ -432,11 +474,11 @@ int launch_epi(const Tp3Params& p, int epi, hipStream_t s) {
 
 // compile-time epilogue code of a call, or -1 (generic) when it uses anything the specialised set does not cover
 inline int epi_code(const Tp3Params& p) {
-    if ((p.alpha != 1.0f && !p.a_scale) || (p.act & TVL_ACT_POST_RESIDUAL)) return -1;
+    if ((p.alpha != 1.0f && !p.a_scale && !p.a_kscale) || (p.act & TVL_ACT_POST_RESIDUAL)) return -1;
     const int act = p.act & 0xff;
     if ((act != TVL_ACT_NONE && act != TVL_ACT_QUICK_GELU) || (p.dact != TVL_ACT_NONE && p.dact != TVL_ACT_QUICK_GELU)) return -1;
     return (p.bias ? E_BIAS : 0) | (p.residual ? E_RES : 0) | (act ? E_QGELU : 0) | (p.dact ? E_DQGELU : 0) | (p.pre_out ? E_PRE : 0) |
-           (p.C ? E_F32 : 0) | (p.Cp ? E_TP3 : 0) | (p.a_scale ? E_RSCALE : 0) | (p.Ch2 ? E_H2OUT : 0);
+           (p.C ? E_F32 : 0) | (p.Cp ? E_TP3 : 0) | ((p.a_scale || p.a_kscale) ? E_RSCALE : 0) | (p.Ch2 ? E_H2OUT : 0);
 }
 
 }  // namespace

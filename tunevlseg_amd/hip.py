@@ -150,7 +150,8 @@ _SIGS = {
     "tvl_h2_pack": [_P, _L, _L, _I, _P, _P, _P, _I, _P],
     "tvl_gemm_h2_out": [C.POINTER(GemmTp3Args), _P, _P, _P, _F, _F, _P, _I],
     "tvl_attn_h2_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _F],
-    "tvl_attn_h2_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
+    "tvl_attn_h2_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _F],
+    "tvl_gemm_h2_ks": [C.POINTER(GemmTp3Args), _P],
     "tvl_gemm_h2": [C.POINTER(GemmTp3Args), _P],
     "tvl_layernorm_fwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F],
     "tvl_layernorm_bwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
@@ -686,6 +687,7 @@ def layernorm_bwd_tp3(dy2d, x2d, gamma, mean, rstd, dres=None):
 
 
 GEMM_H2 = os.environ.get("TVL_GEMM_H2", "1") != "0"   # the four LayerNorm-fed GEMMs of a tp3 layer on two fp16 pieces (3 MFMAs per product)
+DQKV_H2 = os.environ.get("TVL_DQKV_H2", "1") != "0"   # dQ | dK | dV as an h2 image with per-(row, head) scales; QKV data gradient on tvl_gemm_h2_ks
 ATTN_H2 = os.environ.get("TVL_ATTN_H2", "1") != "0"   # attention of the tp3 layers on two fp16 pieces (QKV / dO as tensor-scaled h2 images)
 ATTN_TP3 = os.environ.get("TVL_ATTN_TP3", "1") != "0"   # 0: attention of the tp3 layers on the fp32-operand kernels (A/B switch)
 TP3_MIN_ROWS = int(os.environ.get("TVL_TP3_MIN_ROWS", "1024"))  # below this the layer is launch-latency bound either way
@@ -752,19 +754,56 @@ def attn_h2_fwd(qkv_h: H2, B: int, T: int, H: int, scale: float, want_lse=True, 
     return o, lse
 
 
-def attn_h2_bwd(qkv_h: H2, o_t, do_h: H2, lse, B: int, T: int, H: int, scale: float) -> Tp3:
+class H2K:
+    """dQ | dK | dV as two fp16 pieces with one exact power-of-two scale per (row, 64-column block): ``kscale`` [rows, cols / 64] inverse
+    scales.  The A operand of ``gemm_h2_ks`` (the QKV data gradient)."""
+
+    __slots__ = ("buf", "rows", "cols", "kscale")
+
+    def __init__(self, rows: int, cols: int, device):
+        self.rows, self.cols = rows, cols
+        n = (rows + 31) // 32 * (cols // 16) * 2048
+        self.buf = (torch.zeros if rows % 32 else torch.empty)(n, device=device, dtype=torch.uint8)
+        self.kscale = torch.empty((rows, cols // 64), device=device, dtype=torch.float32)
+
+    def float(self) -> torch.Tensor:
+        RB, KB = (self.rows + 31) // 32, self.cols // 16
+        h = self.buf.view(torch.float16).view(RB, KB, 2, 2, 32, 8).float().sum(2)
+        x = h.permute(0, 3, 1, 2, 4).reshape(RB * 32, self.cols)[: self.rows]
+        return x * self.kscale.repeat_interleave(64, dim=1)
+
+
+def gemm_h2_ks(A: H2K, B: H2, out: torch.Tensor | None = None) -> torch.Tensor:
+    """A . B^T with A scaled per (row, 64-column block of K) and B a tensor-scaled H2 weight: fp32 result (the QKV data gradient)."""
+    M, N, K = A.rows, B.rows, A.cols
+    if B.cols != K or B.per_row:
+        raise RuntimeError(f"gemm_h2_ks: need B {B.shape} per-tensor scaled and K = {K}")
+    Cf = out if out is not None else torch.empty((M, N), device=A.buf.device, dtype=torch.float32)
+    args = GemmTp3Args(M, N, K, A.buf.data_ptr(), A.rows, B.buf.data_ptr(), B.rows, _ps(Cf), Cf.stride(0), None, None, None, 0, ACT_NONE, None, None, 0,
+                       ACT_NONE, B.alpha(), 0, 0)
+    if _gemm_prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _call("tvl_gemm_h2_ks", C.byref(args), _p(A.kscale))
+    if _gemm_prof is not None:
+        e1.record()
+        _gemm_prof.append(("gemm_tp3_kernel<192, 256, 3, 160, 2, true>", 2.0 * M * N * K, e0, e1))
+    return Cf
+
+
+def attn_h2_bwd(qkv_h: H2, o_t, do_h: H2, lse, B: int, T: int, H: int, scale: float, out_h2: bool = False):
     """Backward of attn_h2_fwd: QKV and dO as tensor-scaled H2 images, O as Tp3 or as the H2 image the forward wrote; returns
-    dQ | dK | dV as a Tp3 image."""
+    dQ | dK | dV as a Tp3 image, or (out_h2) as an H2K image with exact per-(row, head) scales."""
     D = H * 64
     if qkv_h.per_row or do_h.per_row or do_h.rows != B * T or do_h.cols != D:
         raise RuntimeError("attn_h2_bwd: QKV / dO must be tensor-scaled H2 images of [B*T, 3D] / [B*T, D]")
     dev = qkv_h.buf.device
-    g = Tp3(B * T, 3 * D, dev)
+    g = H2K(B * T, 3 * D, dev) if out_h2 else Tp3(B * T, 3 * D, dev)
     delta = torch.empty((B, H, T), device=dev, dtype=torch.float32)
     dn = torch.empty(B * H, device=dev, dtype=torch.int32)
     _call("tvl_attn_h2_bwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o_t.buf.data_ptr(), 1 if isinstance(o_t, H2) else 0, do_h.buf.data_ptr(),
           _p(do_h.inv_scale), _p(lse),
-          _p(delta), dn.data_ptr(), g.buf.data_ptr(), B, H, T, float(scale))
+          _p(delta), dn.data_ptr(), g.buf.data_ptr(), 1 if out_h2 else 0, _p(g.kscale) if out_h2 else None, B, H, T, float(scale))
     return g
 
 

@@ -57,7 +57,8 @@ class LayerWeights:
             self._h2 = {k: hip.weight_h2(w) for k, w in (
                 ("wqkv", self.wqkv), ("wo", self.wo), ("w1", self.w1), ("w2", self.w2),
                 ("wo_t", self.wo_t if self.wo_t is not None else t(self.wo)), ("w2_t", self.w2_t if self.w2_t is not None else t(self.w2)),
-                ("w1_t", self.w1_t if self.w1_t is not None else t(self.w1)))}
+                ("w1_t", self.w1_t if self.w1_t is not None else t(self.w1)),
+                ("wqkv_t", self.wqkv_t if self.wqkv_t is not None else t(self.wqkv)))}
             self._h2["b1_max"] = float(self.b1.detach().abs().max().item()) * 1.0001
             self._h2["bqkv_max"] = float(self.bqkv.detach().abs().max().item()) * 1.0001
         return self._h2
@@ -175,7 +176,7 @@ class EncoderLayerTp3Fn(Fn):
         o_t = hip.H2.wrap(M, D, o_buf, qkv_inv, per_row=False) if qkv_inv is not None else hip.Tp3(M, D, o_buf.device, o_buf)
         if qkv_inv is not None:   # the forward ran the attention on two fp16 pieces: dO as a one-scale h2 image too
             _, do = hip.gemm_h2(dh2_t, WL["wo_t"], want_f32=False, want_h2=True, out_per_tensor=True)
-            dqkv = hip.attn_h2_bwd(hip.H2.wrap(M, 3 * D, qkv, qkv_inv, per_row=False), o_t, do, lse, B, T, H, dh**-0.5)
+            dqkv = hip.attn_h2_bwd(hip.H2.wrap(M, 3 * D, qkv, qkv_inv, per_row=False), o_t, do, lse, B, T, H, dh**-0.5, out_h2=hip.DQKV_H2)
         elif hip.ATTN_TP3:
             _, do = gemm_ln(dh2_t, WL["wo_t"], want_f32=False, want_tp3=True)
             dqkv = hip.attn_tp3_bwd(hip.Tp3(M, 3 * D, qkv.device, qkv), o_t, do, lse, B, T, H, dh**-0.5)
@@ -183,7 +184,10 @@ class EncoderLayerTp3Fn(Fn):
             do, _ = hip.gemm_tp3(dh2_t, W["wo_t"])
             dqkv = hip.attn_bwd_packed_tp3(qkv, o_t, do, lse, B, T, H, dh, dh**-0.5)
         del dh2_t, do
-        dx1, _ = hip.gemm_tp3(dqkv, W["wqkv_t"])
+        if isinstance(dqkv, hip.H2K):   # exact power-of-two scale per (row, head, Q / K / V part): the GEMM rescales its accumulators at the chunk boundaries
+            dx1 = hip.gemm_h2_ks(dqkv, WL["wqkv_t"])
+        else:
+            dx1, _ = hip.gemm_tp3(dqkv, W["wqkv_t"])
         del dqkv
         dh_in, dh_in_t = ln_bwd(dx1, h2d, lw.ln1_w, mean1, rstd1, dres=dh2)
         g = dh_in.view(B, T, D)
