@@ -421,7 +421,7 @@ def tp3_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, alph
           (32 if c_f32 else 0) | (64 if c_tp3 else 0)
     if alpha != 1.0 or (act & ~0xFF) or epi not in _TP3_EPI_BUILT:
         epi = -1
-    return f"gemm_tp3_kernel<{tile}, 256, {variant}, {epi}, 3>"
+    return f"gemm_tp3_kernel<{tile}, 256, {variant}, {epi}, 3, false>"
 
 
 class H2:
@@ -540,7 +540,7 @@ def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_
           (32 if c_f32 else 0) | (64 if c_tp3 else 0) | 128 | (256 if c_h2 else 0)
     if (act & ~0xFF) or epi not in _H2_EPI_BUILT[tile]:
         epi = -1
-    return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2>"
+    return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2, false>"
 
 
 def tp3_tile(M: int, N: int) -> int:
