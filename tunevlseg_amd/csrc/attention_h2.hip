@@ -12,7 +12,9 @@
 //               with ||dO_q|| exact (the lane holds the row) and ||V_k|| <= 8 * 2^14 * qkv_inv
 //   dS (dK)     one scale per (sample, head) -- the contraction of dK = dS^T Q runs over queries -- from the largest ||dO_q|| of the
 //               (sample, head), which the dQ kernel leaves in dnorm_max by atomicMax on the float's bits
-// O and dQ | dK | dV leave as tp3 images (three bf16 pieces): their consumers read that format.
+// Outputs: O as an h2 image that shares the QKV scale (|O| <= max |V|) and dQ | dK | dV as an h2 image with one exact scale per
+// (row, 64-column block) -- each such block is written by one lane pair that holds all of it (store_block) -- for tvl_gemm_h2 /
+// tvl_gemm_h2_ks; or both as tp3 images (three bf16 pieces) for the tp3 consumers.
 #include "common.h"
 #include "tp3.h"
 
