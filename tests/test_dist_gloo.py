@@ -60,7 +60,8 @@ def _worker(rank, world, port, global_b, q):
     d, j = DiceSamples(), JaccardBinary()
     d.update(counts)
     j.update(counts)
-    res = (flat.grad * scale).clone(), d.compute(), j.compute()
+    # plain numpy / floats through the queue: a tensor travels as a shared-memory handle that dies with this process
+    res = (flat.grad * scale).numpy().copy(), float(d.compute()), float(j.compute())
     dist.barrier()
     if rank == 0:
         q.put(res)
@@ -77,6 +78,7 @@ def test_flat_allreduce_equals_single_process_global_batch():
     for p in procs:
         p.start()
     flat_grad, dice, iou = q.get(timeout=240)
+    flat_grad = torch.from_numpy(flat_grad)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -122,7 +124,7 @@ def _exchange_worker(rank, world, port, q):
     net(x).sum().backward()
     in_backward = ex.launched_in_backward
     scale = ex.finish()
-    res = (flat.grad * scale).clone(), in_backward, len(ex.buckets)
+    res = (flat.grad * scale).numpy().copy(), in_backward, len(ex.buckets)   # numpy: see _worker
     dist.barrier()
     if rank == 0:
         q.put(res)
@@ -139,6 +141,7 @@ def test_grad_exchange_buckets_fire_during_backward_and_sum_like_one_process():
     for p in procs:
         p.start()
     flat_grad, in_backward, n_buckets = q.get(timeout=240)
+    flat_grad = torch.from_numpy(flat_grad)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
