@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import hip
 from .backbone import _Embedding, _Node
 from .cris_config import CRISConfig
 from .cris_ops import FrozenConv3, FrozenLinear
@@ -46,7 +47,8 @@ def conv3_matrices(w4: torch.Tensor, b: torch.Tensor | None, need_dgrad: bool) -
 
 def linear_matrices(w2: torch.Tensor, b: torch.Tensor | None) -> FrozenLinear:
     w2 = w2.contiguous()
-    return FrozenLinear(w2, None if b is None else b.contiguous(), w2.t().contiguous())
+    # persistent, never written again: lets hip.gemm keep their two-piece fp16 images (hip.weight_h2_cached)
+    return FrozenLinear(hip.mark_frozen(w2), None if b is None else b.contiguous(), hip.mark_frozen(w2.t().contiguous()))
 
 
 def _numel(shape) -> int:

@@ -375,6 +375,16 @@ def weight_tp3(W: torch.Tensor) -> Tp3:
     return img
 
 
+def weight_h2_cached(W: torch.Tensor) -> "H2":
+    """H2 image of a frozen weight, cached on the tensor object (valid while its storage and version stay the same)."""
+    cached = getattr(W, "_tvl_h2", None)
+    if cached is not None and cached[0] == (W.data_ptr(), W._version):
+        return cached[1]
+    img = weight_h2(W)
+    W._tvl_h2 = ((W.data_ptr(), W._version), img)
+    return img
+
+
 def mark_frozen(t: torch.Tensor) -> torch.Tensor:
     """Declare a prepared weight tensor immutable for its lifetime (enables the tp3 cache)."""
     t._tvl_frozen = True
@@ -561,6 +571,19 @@ def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias
     args = GemmArgs(layout, M, N, K, _ps(A) if A.dim() == 2 else _p(A), lda, _p(B), ldb, _ps(Cout) if Cout.dim() == 2 else _p(Cout), ldc,
                     _p(bias), _ps(residual) if (residual is not None and residual.dim() == 2) else _p(residual), ldr, act, _p(pre_out),
                     _p(dact_aux), ld_aux, dact, alpha, a_map or _ident(), c_map or _ident())
+    # Large NT problems over a FROZEN weight (mark_frozen): both operands as two-piece fp16 images -- the weight's image is cached on the
+    # tensor, the activation is packed on the way in (two passes for its exact row scales: 8 B/element of extra traffic, repaid several
+    # times over by 3 MFMAs per product on the DMA-ring kernel instead of 6 on the in-kernel-split one)
+    if (layout == NT and GEMM_MODE == "bf16x6" and GEMM_H2 and PACK_H2 and getattr(B, "_tvl_frozen", False) and a_map is None and c_map is None
+            and alpha == 1.0 and M >= 2048 and N >= 128 and N % 16 == 0 and K % 32 == 0 and K >= 64 and 2.0 * M * N * K >= 3e9
+            and A.dim() == 2 and A.stride(1) == 1 and A.stride(0) == lda and lda % 4 == 0 and B.dim() == 2 and B.is_contiguous() and ldb == K
+            and Cout.dim() == 2 and Cout.stride(1) == 1 and Cout.stride(0) == ldc and ldc % 4 == 0
+            and (residual is None or (residual.dim() == 2 and residual.stride(1) == 1 and residual.stride(0) == ldr))
+            and (pre_out is None or (pre_out.dim() == 2 and pre_out.stride(0) == ldc))
+            and (dact_aux is None or (dact_aux.dim() == 2 and dact_aux.stride(0) == ld_aux))):
+        gemm_h2(h2_pack(A[:M], per_row=True), weight_h2_cached(B), out=Cout[:M], bias=bias, residual=None if residual is None else residual[:M],
+                act=act, pre_out=None if pre_out is None else pre_out[:M], dact_aux=None if dact_aux is None else dact_aux[:M], dact=dact)
+        return Cout
     split = _NSPLIT.get(GEMM_MODE, 0) if (layout == NT and M >= 256) else 0
     # skinny and deep (text-tower GEMMs: a few dozen 64x64 tiles, 48-64 k-slabs each): split K over more workgroups
     tiles64 = ((M + 63) // 64) * ((N + 63) // 64)
@@ -686,6 +709,7 @@ def layernorm_bwd_tp3(dy2d, x2d, gamma, mean, rstd, dres=None):
     return dx, dxt
 
 
+PACK_H2 = os.environ.get("TVL_PACK_H2", "1") != "0"   # generic large Linears over frozen weights: pack the activation to h2 on the way in (hip.gemm)
 GEMM_H2 = os.environ.get("TVL_GEMM_H2", "1") != "0"   # the four LayerNorm-fed GEMMs of a tp3 layer on two fp16 pieces (3 MFMAs per product)
 DQKV_H2 = os.environ.get("TVL_DQKV_H2", "1") != "0"   # dQ | dK | dV as an h2 image with per-(row, head) scales; QKV data gradient on tvl_gemm_h2_ks
 ATTN_H2 = os.environ.get("TVL_ATTN_H2", "1") != "0"   # attention of the tp3 layers on two fp16 pieces (QKV / dO as tensor-scaled h2 images)
