@@ -15,6 +15,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 from functools import partial
@@ -253,7 +254,7 @@ def main():
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         gemm_ms = sum(v["ms"] for v in prof.values()) / 2
         split = "bf16s" in name or "tp3" in name
-        two_piece = ", 2, false>" in name or ", 2, true>" in name   # the h2 format: two fp16 pieces, 3 MFMAs per fp32 product
+        two_piece = re.search(r", 2, (true|false), (true|false)>", name) is not None   # the h2 format: two fp16 pieces, 3 MFMAs per fp32 product
         peak = (PEAK_BF16_MFMA_TFLOPS / 3 if two_piece else MODE_PEAK[hip.GEMM_MODE]) if split else PEAK_F32_MFMA_TFLOPS
         # HBM bytes per launch of that kernel: recorded by two separate rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE; FETCH_SIZE
         # doubled per the gfx950 note of MI355X_MICROARCH.md §HBM) and committed under profiles/.  It is a RECORDED number: reported

@@ -200,3 +200,34 @@ def test_conv3x3_implicit_gemm_wide_tile(hip, B, C, H, W, Cout):
     ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
     y = hip.conv3x3(dev(nhwc(x)), B, H, W, dev(w.permute(0, 2, 3, 1).reshape(Cout, 9 * C)), dev(b), hip.ACT_RELU)
     close(nchw(y, B, H, W), ref, 2e-5, "conv3x3 wide tile")
+
+
+@pytest.mark.parametrize("B,C,H,W,Cout,bias_relu", [(32, 512, 26, 26, 512, True), (16, 32, 64, 64, 256, True), (5, 96, 21, 23, 144, False),
+                                                    (2, 128, 40, 33, 128, True), (1, 64, 50, 47, 384, False)])
+def test_conv3x3_two_piece_fp16(hip, B, C, H, W, Cout, bias_relu):
+    """hip.conv3x3 over a frozen weight with C % 32 == 0: implicit GEMM on two fp16 pieces (tvl_conv3x3_h2), taps gathered by LDS-DMA, the
+    padding taps from the zero block; ragged M (not a multiple of 32), both row tiles, generic and plain epilogue."""
+    from tunevlseg_amd.hip import conv_h2_kernel_name
+
+    assert hip.CONV_H2 and hip.GEMM_MODE == "bf16x6"
+    x, w, b = rnd(B, C, H, W, seed=41), rnd(Cout, C, 3, 3, seed=42) * (9 * C) ** -0.5, rnd(Cout, seed=43)
+    x[:, : C // 2] *= 1e-3   # a wide range under the one tensor scale
+    ref = F.conv2d(x.double(), w.double(), b.double() if bias_relu else None, padding=1)
+    ref = F.relu(ref) if bias_relu else ref
+    wm = hip.mark_frozen(dev(w.permute(0, 2, 3, 1).reshape(Cout, 9 * C)))
+    prof = []
+    hip._gemm_prof, old = prof, hip._gemm_prof
+    try:
+        y = hip.conv3x3(dev(nhwc(x)), B, H, W, wm, dev(b) if bias_relu else None, hip.ACT_RELU if bias_relu else hip.ACT_NONE)
+        torch.cuda.synchronize()
+    finally:
+        hip._gemm_prof = old
+    assert prof and prof[0][0] == conv_h2_kernel_name(B * H * W, Cout, bias_relu, bias_relu), prof   # the h2 kernel ran, not the bf16 one
+    close(nchw(y, B, H, W), ref, 2e-5, "conv3x3 h2")
+    # against the three-bf16-piece implicit GEMM on the same input: both are fp32-equivalent
+    hip.CONV_H2 = False
+    try:
+        y3 = hip.conv3x3(dev(nhwc(x)), B, H, W, wm, dev(b) if bias_relu else None, hip.ACT_RELU if bias_relu else hip.ACT_NONE)
+    finally:
+        hip.CONV_H2 = True
+    close(y, y3, 1e-5, "conv3x3 h2 vs bf16x3")

@@ -42,7 +42,8 @@ def conv3_matrices(w4: torch.Tensor, b: torch.Tensor | None, need_dgrad: bool) -
     cout, cin = w4.shape[:2]
     wm = _pad_cols(w4.permute(0, 2, 3, 1).reshape(cout, 9 * cin))
     wd = _pad_cols(w4.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout)) if need_dgrad else None
-    return FrozenConv3(wm, None if b is None else b.contiguous(), wd, cin, cout)
+    # persistent, never written again: hip.conv3x3 keeps their two-piece fp16 images
+    return FrozenConv3(hip.mark_frozen(wm), None if b is None else b.contiguous(), None if wd is None else hip.mark_frozen(wd), cin, cout)
 
 
 def linear_matrices(w2: torch.Tensor, b: torch.Tensor | None) -> FrozenLinear:

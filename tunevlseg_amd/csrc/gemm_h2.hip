@@ -112,6 +112,17 @@ int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
     }
 }
 
+// 3x3 conv as an implicit GEMM (the A fragments are gathered tap by tap from the pixel matrix' image): generic epilogue (bias + ReLU of the
+// folded eval BatchNorm) and the plain one of the data gradient
+int launch_h2_conv(const Tp3Params& p, int bm, int epi, hipStream_t s) {
+    if (bm == 256) {
+        if (epi == (E_F32 | E_RSCALE)) return launch<256, 256, 2, E_F32 | E_RSCALE, 2, false, true>(p, s);
+        return launch<256, 256, 2, -1, 2, false, true>(p, s);
+    }
+    if (epi == (E_F32 | E_RSCALE)) return launch<192, 256, 3, E_F32 | E_RSCALE, 2, false, true>(p, s);
+    return launch<192, 256, 3, -1, 2, false, true>(p, s);
+}
+
 }  // namespace
 
 extern "C" int64_t tvl_h2_bytes(int64_t rows, int32_t K) {
@@ -150,7 +161,7 @@ extern "C" int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K,
 // is still a tp3 image: the consumers of this round read three bf16 pieces).  a_row_scale: [M] inverse scales of A's rows (or null);
 // alpha carries the inverse scale of B.
 static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void* c_h2, const float* out_row_norm, float out_mul, float out_add,
-                        float* out_inv_scale, int out_per_tensor, tvlStream_t stream) {
+                        float* out_inv_scale, int out_per_tensor, tvlStream_t stream, const tvlConvGeom* conv = nullptr) {
     TVL_REQUIRE(a != nullptr, "tvl_gemm_h2: null args");
     TVL_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "tvl_gemm_h2: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     TVL_REQUIRE(a->K % 32 == 0 && a->K >= 64 && a->N % 16 == 0, "tvl_gemm_h2: need K %% 32 == 0, K >= 64, N %% 16 == 0 (K=%d N=%d)", a->K, a->N);
@@ -177,10 +188,29 @@ static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void*
         const long t256 = ((long)(a->M + 255) / 256) * ((a->N + 255) / 256), t192 = ((long)(a->M + 191) / 192) * ((a->N + 255) / 256);
         bm = ((t256 + 255) / 256) * 256 <= ((t192 + 255) / 256) * 192 ? 256 : 192;   // rounds x rows per tile; ties go to the larger tile
     }
-    const int rc = launch_h2(p, bm, epi_code(p), reinterpret_cast<hipStream_t>(stream));
+    if (conv) {
+        p.cH = conv->H; p.cW = conv->W; p.cC16 = conv->C / 16;
+        p.a_rb = (int)((a->a_rows + 31) / 32);   // = the index of the appended zero block row
+    }
+    const int rc = conv ? launch_h2_conv(p, bm, epi_code(p), reinterpret_cast<hipStream_t>(stream))
+                        : launch_h2(p, bm, epi_code(p), reinterpret_cast<hipStream_t>(stream));
     TVL_REQUIRE(rc == 0, "tvl_gemm_h2: launch failed (dynamic LDS opt-in?)");
     TVL_LAUNCH_CHECK("tvl_gemm_h2");
     return 0;
+}
+
+// 3x3 / pad 1 / stride 1 conv of an NHWC pixel matrix as an implicit GEMM over h2 operands.  args->A = the h2 image of the pixel matrix
+// [B*H*W, C] (ONE scale for the tensor: a_row_scale[m] all equal) followed by one all-zero 32-row block (the source of the padding taps:
+// the image holds tvl_h2_bytes(B*H*W, C) + tvl_h2_bytes(32, C) bytes); args->a_rows = args->M = B*H*W; args->B = the h2 image of the
+// weights [N, 9*C], columns ordered (ky, kx, c); args->K = 9*C.  Epilogue as tvl_gemm_h2 (fp32 output).  Needs C % 32 == 0.
+extern "C" int tvl_conv3x3_h2(const tvlGemmTp3Args* a, const tvlConvGeom* g, const float* a_row_scale, tvlStream_t stream) {
+    TVL_REQUIRE(a != nullptr && g != nullptr, "tvl_conv3x3_h2: null args");
+    TVL_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0 && g->H < 32768 && g->W < 32768 && g->C > 0 && g->C % 32 == 0 && g->stride == 1,
+                "tvl_conv3x3_h2: need C %% 32 == 0 and stride 1 (C=%d stride=%d)", g->C, g->stride);
+    TVL_REQUIRE((int64_t)g->B * g->H * g->W == a->M && a->a_rows == a->M && a->K == 9 * g->C && (int64_t)a->M + 64 < (1ll << 31),
+                "tvl_conv3x3_h2: M must be B*H*W (= a_rows) and K = 9*C (M=%d K=%d)", a->M, a->K);
+    TVL_REQUIRE(a->C && !a->C_tp3, "tvl_conv3x3_h2: fp32 output only");
+    return gemm_h2_impl(a, a_row_scale, nullptr, nullptr, 0.f, 0.f, nullptr, 0, stream, g);
 }
 
 extern "C" int tvl_gemm_h2(const tvlGemmTp3Args* a, const float* a_row_scale, tvlStream_t stream) {

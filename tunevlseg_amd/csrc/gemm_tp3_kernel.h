@@ -64,6 +64,9 @@ struct Tp3Params {
     // knows its exact maximum.  a_kscale[m * k_chunks + c] = inverse scale of A's columns 64 c .. 64 c + 63 in row m (KS kernels only)
     const float* a_kscale; int k_chunks;
     int out_stride;   // 1: out_norm / out_inv are per row; 0: one bound and one scale for the whole output (out_norm[0], out_inv[0])
+    // CONV kernels: A is the image of the NHWC pixel matrix [B*cH*cW, 16*cC16] with one all-zero 32-row block appended (block row a_rb);
+    // row m of the GEMM gathers its nine taps from it (3x3, pad 1, stride 1; K = 9 * 16 * cC16 ordered (ky, kx, c))
+    int cH, cW, cC16;
     int tiles_m, tiles_n;
 };
 
@@ -225,7 +228,7 @@ __device__ __forceinline__ void read_all(Frags<TM, TN, NP>& f, unsigned a_addr, 
 // KS: A carries one power-of-two scale per (row, 64-column chunk of K) (a_kscale).  The accumulators hold the sum scaled by the CURRENT
 // chunk's scale; at a chunk boundary (every four 16-deep slabs) each lane multiplies its rows' accumulators by s_next / s_cur -- a power of
 // two, exact -- and the epilogue undoes the last chunk's scale.  The ratios sit in LDS behind the three stages (BM x k_chunks floats).
-template <int BM, int BN, int VARIANT, int EPI, int NP = 3, bool KS = false>
+template <int BM, int BN, int VARIANT, int EPI, int NP = 3, bool KS = false, bool CONV = false>
 __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     Tp3Params p = p_in;
     float* const stamp_buf = p_in.pre_out;
@@ -295,15 +298,52 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
         }
     }
     const unsigned lane16 = lane * 16;
+    // CONV: the output pixel behind this lane's row of the wave's A pieces (only pieces 0 and 1 of a wave can be A pieces), and the
+    // (tap, channel block) of the NEXT slab to be requested -- slabs are requested in order, conv_advance() after each
+    static_assert(!CONV || PA <= 2 * NWAVE, "conv: at most two A pieces per wave");
+    int cv_row[2] = {-1, -1}, cv_yx[2] = {0, 0};
+    int cv_dy = -1, cv_dx = -1, cv_cb = 0;
+    if constexpr (CONV) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pc = wave + NWAVE * i;
+            if (pc < PA) {
+                const int r = tile_m * BM + (pc / NP) * 32 + (lane & 31);
+                const int hw = p.cH * p.cW;
+                const int rem = r % hw, oy = rem / p.cW;
+                cv_row[i] = r < p.M ? r : -1;
+                cv_yx[i] = (oy << 16) | (rem - oy * p.cW);
+            }
+        }
+    }
+    auto conv_advance = [&]() {
+        if constexpr (CONV) {
+            if (++cv_cb == p.cC16) {
+                cv_cb = 0;
+                if (++cv_dx == 2) { cv_dx = -1; ++cv_dy; }
+            }
+        }
+    };
     // request piece i of this wave for k-slab `slab` into LDS stage `stage`
     auto issue_piece = [&](auto idx, int slab, int stage) {
         constexpr int i = decltype(idx)::value;
         const int pc = wave + NWAVE * i;
+        if constexpr (CONV && i < 2) {
+            if (pc < PA) {   // wave-uniform
+                const int iy = (cv_yx[i] >> 16) + cv_dy, ix = (cv_yx[i] & 0xffff) + cv_dx;
+                const bool ok = cv_row[i] >= 0 && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
+                const int rin = ok ? cv_row[i] + cv_dy * p.cW + cv_dx : p.a_rb * 32;
+                const unsigned long off = ((unsigned long)((rin >> 5) * p.cC16 + cv_cb)) * BLKP + (unsigned)((pc % NP) * PIECE + (((lane >> 5) * 32 + (rin & 31)) * 16));
+                glds16(p.A + off, lds0 + stage * STAGE + pc * PIECE);
+                return;
+            }
+        }
         if ((i + 1) * NWAVE <= PT || pc < PT) glds16((src[i] + (long)(ABL_SLAB0 ? (slab & 1) : slab) * BLKP) + lane16, lds0 + stage * STAGE + pc * PIECE);
     };
     auto issue = [&](int slab, int stage) {
         [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(std::integral_constant<int, I>{}, slab, stage), ...); }(std::make_integer_sequence<int, PW>{});
     };
+    auto issue_next = [&](int slab, int stage) { issue(slab, stage); conv_advance(); };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -330,9 +370,9 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
         __syncthreads();
     }
     // prologue: three slabs in flight, wait for the first
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 2) issue(2, 2);
+    issue_next(0, 0);
+    if (nk > 1) issue_next(1, 1);
+    if (nk > 2) issue_next(2, 2);
     wait_groups<PT>((nk < 3 ? nk : 3) - 1, extra);
     __builtin_amdgcn_s_barrier();
     stamp(1);
@@ -395,6 +435,7 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
         };
         if constexpr (ISSUE && !ABL_NODMA && !DMA_SPREAD) issue(kt + 3, st_cur);
         [&]<int... Q>(std::integer_sequence<int, Q...>) { (body(std::integral_constant<int, Q>{}), ...); }(std::make_integer_sequence<int, NMFMA>{});
+        if constexpr (ISSUE) conv_advance();
     };
     using Steady = StepMode<1, true, false>;
     using Drain1 = StepMode<1, false, false>;
@@ -434,7 +475,7 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     }
 }
 
-template <int BM, int BN, int VARIANT, int EPI, int NP = 3, bool KS = false>
+template <int BM, int BN, int VARIANT, int EPI, int NP = 3, bool KS = false, bool CONV = false>
 int launch(const Tp3Params& p0, hipStream_t s) {
     Tp3Params p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -444,7 +485,7 @@ int launch(const Tp3Params& p0, hipStream_t s) {
     constexpr size_t ks_bytes = KS ? (size_t)BM * 64 * sizeof(float) : 0;   // ratio table: up to 64 chunks (K <= 4096)
     constexpr size_t smem = (stage_bytes + ks_bytes) > epi_bytes ? (stage_bytes + ks_bytes) : epi_bytes;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = gemm_tp3_kernel<BM, BN, VARIANT, EPI, NP, KS>;
+    auto kern = gemm_tp3_kernel<BM, BN, VARIANT, EPI, NP, KS, CONV>;
     static int attr_dev_mask = 0;  // per device: the opt-in for > 64 KiB of dynamic LDS is a per-device function attribute
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1;

@@ -152,6 +152,7 @@ _SIGS = {
     "tvl_attn_h2_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _F],
     "tvl_attn_h2_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _F],
     "tvl_gemm_h2_ks": [C.POINTER(GemmTp3Args), _P],
+    "tvl_conv3x3_h2": [C.POINTER(GemmTp3Args), C.POINTER(ConvGeom), _P],
     "tvl_gemm_h2": [C.POINTER(GemmTp3Args), _P],
     "tvl_layernorm_fwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F],
     "tvl_layernorm_bwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
@@ -431,7 +432,7 @@ def tp3_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, alph
           (32 if c_f32 else 0) | (64 if c_tp3 else 0)
     if alpha != 1.0 or (act & ~0xFF) or epi not in _TP3_EPI_BUILT:
         epi = -1
-    return f"gemm_tp3_kernel<{tile}, 256, {variant}, {epi}, 3, false>"
+    return f"gemm_tp3_kernel<{tile}, 256, {variant}, {epi}, 3, false, false>"
 
 
 class H2:
@@ -441,12 +442,16 @@ class H2:
 
     __slots__ = ("buf", "rows", "cols", "inv_scale", "per_row", "_alpha", "row_norm", "_bound")
 
-    def __init__(self, rows: int, cols: int, device, per_row: bool):
+    def __init__(self, rows: int, cols: int, device, per_row: bool, zero_tail: bool = False):
         if cols % 16:
             raise RuntimeError(f"h2 needs cols % 16 == 0, got {cols}")
         self.rows, self.cols, self.per_row = rows, cols, per_row
         n = (rows + 31) // 32 * (cols // 16) * 2048
-        self.buf = (torch.zeros if rows % 32 else torch.empty)(n, device=device, dtype=torch.uint8)
+        if zero_tail:   # one more 32-row block of zeros: where the padding taps of conv3x3_h2 read
+            self.buf = torch.empty(n + (cols // 16) * 2048, device=device, dtype=torch.uint8)
+            self.buf[n:].zero_()
+        else:
+            self.buf = (torch.zeros if rows % 32 else torch.empty)(n, device=device, dtype=torch.uint8)
         self.inv_scale = torch.empty(rows if per_row else 1, device=device, dtype=torch.float32)
         self._alpha = None   # host copy of a per-tensor inverse scale, read once (frozen weights)
         self.row_norm = None   # [rows] L2 norms of the rows (per-row operands whose consumer GEMM writes an h2 output)
@@ -466,7 +471,7 @@ class H2:
     def float(self) -> torch.Tensor:
         """Back to fp32: (h0 + h1) * inverse scale.  Tests and debugging (plain tensor ops on the byte image)."""
         RB, KB = (self.rows + 31) // 32, self.cols // 16
-        h = self.buf.view(torch.float16).view(RB, KB, 2, 2, 32, 8).float().sum(2)   # [rb, kb, k-half, row, 8]
+        h = self.buf[: RB * KB * 2048].view(torch.float16).view(RB, KB, 2, 2, 32, 8).float().sum(2)   # [rb, kb, k-half, row, 8]
         x = h.permute(0, 3, 1, 2, 4).reshape(RB * 32, self.cols)[: self.rows]
         return x * (self.inv_scale[:, None] if self.per_row else self.inv_scale)
 
@@ -477,10 +482,10 @@ class H2:
         return self._alpha
 
 
-def h2_pack(x2d: torch.Tensor, per_row: bool, want_norm: bool = False) -> H2:
+def h2_pack(x2d: torch.Tensor, per_row: bool, want_norm: bool = False, zero_tail: bool = False) -> H2:
     """fp32 [rows, cols] -> H2 (per_row: activations, the A operand; per tensor: frozen weights, the B operand)."""
     rows, cols = x2d.shape
-    out = H2(rows, cols, x2d.device, per_row)
+    out = H2(rows, cols, x2d.device, per_row, zero_tail)
     work = None if per_row else torch.zeros(1, device=x2d.device, dtype=torch.int32)
     if per_row and want_norm:
         out.row_norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
@@ -550,7 +555,15 @@ def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_
           (32 if c_f32 else 0) | (64 if c_tp3 else 0) | 128 | (256 if c_h2 else 0)
     if (act & ~0xFF) or epi not in _H2_EPI_BUILT[tile]:
         epi = -1
-    return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2, false>"
+    return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2, false, false>"
+
+
+def conv_h2_kernel_name(M, N, bias, act) -> str:
+    """Instantiation tvl_conv3x3_h2 launches (CONV = true as the last template argument)."""
+    t256, t192 = -(-M // 256) * -(-N // 256), -(-M // 192) * -(-N // 256)
+    tile = 256 if -(-t256 // 256) * 256 <= -(-t192 // 256) * 192 else 192
+    epi = -1 if (bias or act) else 160
+    return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2, false, true>"
 
 
 def tp3_tile(M: int, N: int) -> int:
@@ -709,6 +722,7 @@ def layernorm_bwd_tp3(dy2d, x2d, gamma, mean, rstd, dres=None):
     return dx, dxt
 
 
+CONV_H2 = os.environ.get("TVL_CONV_H2", "1") != "0"   # 3x3 convs over frozen weights (C % 32 == 0, N >= 128) as an implicit GEMM on two fp16 pieces
 PACK_H2 = os.environ.get("TVL_PACK_H2", "1") != "0"   # generic large Linears over frozen weights: pack the activation to h2 on the way in (hip.gemm)
 GEMM_H2 = os.environ.get("TVL_GEMM_H2", "1") != "0"   # the four LayerNorm-fed GEMMs of a tp3 layer on two fp16 pieces (3 MFMAs per product)
 DQKV_H2 = os.environ.get("TVL_DQKV_H2", "1") != "0"   # dQ | dK | dV as an h2 image with per-(row, head) scales; QKV data gradient on tvl_gemm_h2_ks
@@ -811,7 +825,7 @@ def gemm_h2_ks(A: H2K, B: H2, out: torch.Tensor | None = None) -> torch.Tensor:
     _call("tvl_gemm_h2_ks", C.byref(args), _p(A.kscale))
     if _gemm_prof is not None:
         e1.record()
-        _gemm_prof.append(("gemm_tp3_kernel<192, 256, 3, 160, 2, true>", 2.0 * M * N * K, e0, e1))
+        _gemm_prof.append(("gemm_tp3_kernel<192, 256, 3, 160, 2, true, false>", 2.0 * M * N * K, e0, e1))
     return Cf
 
 
@@ -1240,6 +1254,21 @@ def conv3x3(x2d: torch.Tensor, B: int, H: int, W: int, Wm: torch.Tensor, bias=No
     M, N = B * Ho * Wo, Wm.shape[0]
     y = _out2d(out, M, N, x2d)
     split = _NSPLIT.get(GEMM_MODE, 0)
+    if (GEMM_MODE == "bf16x6" and GEMM_H2 and CONV_H2 and stride == 1 and Cc % 32 == 0 and N >= 128 and N % 16 == 0 and M >= 2048
+            and getattr(Wm, "_tvl_frozen", False) and Wm.shape[1] == 9 * Cc and x2d.stride(0) % 4 == 0 and y.stride(0) % 4 == 0):
+        # two fp16 pieces: the map packed with one scale (+ a zero block for the padding taps), the taps gathered by the GEMM's LDS-DMA
+        xa, wb = h2_pack(x2d, per_row=False, zero_tail=True), weight_h2_cached(Wm)
+        args = GemmTp3Args(M, N, 9 * Cc, xa.buf.data_ptr(), M, wb.buf.data_ptr(), wb.rows, _ps(y), y.stride(0), None, _p(bias), None, 0, act, None, None, 0,
+                           ACT_NONE, wb.alpha(), 0, 0)
+        geom = ConvGeom(B, H, W, Cc, 1)
+        if _gemm_prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _call("tvl_conv3x3_h2", C.byref(args), C.byref(geom), _p(xa.inv_scale.expand(M).contiguous()))
+        if _gemm_prof is not None:
+            e1.record()
+            _gemm_prof.append((conv_h2_kernel_name(M, N, bias is not None, act), 2.0 * M * N * 9 * Cc, e0, e1))
+        return y
     if split == 3 and Cc % 4 == 0 and M >= 256 and x2d.stride(0) % 4 == 0:
         args = GemmArgs(NT, M, N, 9 * Cc, _ps(x2d), x2d.stride(0), _p(Wm), Wm.shape[1], _ps(y), y.stride(0), _p(bias), None, 0, act,
                         None, None, 0, ACT_NONE, 1.0, _ident(), _ident())
