@@ -17,73 +17,129 @@ constexpr int BLK2 = 2 * PIECE;
 
 __device__ __forceinline__ float pow2_scale_inv(float amax) { return h2::inv_scale_of(amax); }
 
-// per-row maxima -> inverse scales [rows]; one wave per row
-__global__ __launch_bounds__(256) void h2_rowscale_kernel(const float* __restrict__ x, long ldx, long rows, int K, float* __restrict__ inv_scale,
-                                                          float* __restrict__ row_norm) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    float m = 0.f, ss = 0.f;
-    for (int c = lane * 4; c < K; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); ss += __shfl_xor(ss, o, 64); }
-    if (lane == 0) {
-        inv_scale[row] = pow2_scale_inv(m);
-        if (row_norm) row_norm[row] = sqrtf(ss) * 1.0001f;
-    }
+// whole-tensor maximum -> one inverse scale (two stages: block maxima by atomicMax on the bit pattern of a non-negative float).
+// Rows that follow one another in memory (ldx == K) are read as one flat array, four independent 16-byte loads per thread and trip.
+__device__ __forceinline__ float amax4(float m, const float4 v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
-
-// whole-tensor maximum -> one inverse scale (two stages: block maxima by atomicMax on the bit pattern of a non-negative float)
 __global__ __launch_bounds__(256) void h2_absmax_kernel(const float* __restrict__ x, long ldx, long rows, int K, unsigned* __restrict__ bits) {
     float m = 0.f;
     const long total = rows * (K >> 2);
-    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-        const long r = t / (K >> 2);
-        const int c = (int)(t - r * (K >> 2)) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const long stride = (long)gridDim.x * 256;
+    long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (ldx == K) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (; t + 3 * stride < total; t += 4 * stride) {
+            const float4 a = x4[t], b = x4[t + stride], c = x4[t + 2 * stride], d = x4[t + 3 * stride];
+            m = amax4(amax4(amax4(amax4(m, a), b), c), d);
+        }
+        for (; t < total; t += stride) m = amax4(m, x4[t]);
+    } else {
+        const unsigned k4 = (unsigned)(K >> 2);
+        for (; t < total; t += stride) {
+            const unsigned r = (unsigned)t / k4;   // total < 2^32 (host check)
+            const unsigned c = ((unsigned)t - r * k4) * 4;
+            m = amax4(m, *reinterpret_cast<const float4*>(x + (long)r * ldx + c));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(bits, __builtin_bit_cast(unsigned, m));
+    // one atomic per workgroup, and only when it can raise the maximum: thousands of atomics on one address serialise in L2
+    __shared__ float s_m[4];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        const unsigned mb = __builtin_bit_cast(unsigned, m);
+        if (mb > __hip_atomic_load(bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bits, mb);
+    }
 }
-__global__ void h2_tensorscale_kernel(const unsigned* __restrict__ bits, float* __restrict__ inv_scale) {
-    inv_scale[0] = pow2_scale_inv(__builtin_bit_cast(float, bits[0]));
-}
-
 // one thread = 8 consecutive k of one row -> one 16-byte store per piece (same mapping as tp3_pack_kernel)
-__global__ void h2_pack_kernel(const float* __restrict__ x, long ldx, long rows, int K, const float* __restrict__ inv_scale, int per_row,
-                               unsigned char* __restrict__ out, long rows_padded) {
-    const int KB = K >> 4;
-    const long total = rows_padded * (K >> 3);
+__device__ __forceinline__ void h2_pack8(const float* __restrict__ xr, float s, unsigned char* __restrict__ o) {
+    const float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
+    const float v[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
+    uint4 pl[2];
+    h2::split8(v, pl);
+    *reinterpret_cast<uint4*>(o) = pl[0];
+    *reinterpret_cast<uint4*>(o + PIECE) = pl[1];
+}
+// (tensor mode: `bits` = the maximum found by h2_absmax_kernel; the first thread publishes the inverse scale)
+__global__ __launch_bounds__(256) void h2_pack_kernel(const float* __restrict__ x, long ldx, long rows, int K, const unsigned* __restrict__ bits,
+                                                      float* __restrict__ inv_scale, unsigned char* __restrict__ out, long rows_padded) {
+    const unsigned KB = (unsigned)(K >> 4);
+    const long total = rows_padded * (K >> 3);   // blocks * 64 < 2^31 * 64 (host check on the block count)
+    const float inv_all = pow2_scale_inv(__builtin_bit_cast(float, bits[0]));
+    const float s_all = 1.0f / inv_all;   // a power of two: exact
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv_scale[0] = inv_all;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(t & 63);
-        const long blk = t >> 6;
-        const long rb = blk / KB;
-        const int kb = (int)(blk - rb * KB);
+        const unsigned blk = (unsigned)(t >> 6);
+        const unsigned rb = blk / KB;
+        const unsigned kb = blk - rb * KB;
         const int r = lane & 31, h = lane >> 5;
-        const long row = rb * 32 + r;
-        _Float16 h0[8], h1[8];
+        const long row = (long)rb * 32 + r;
+        unsigned char* o = out + (long)blk * BLK2 + lane * 16;
         if (row < rows) {
-            const float s = 1.0f / inv_scale[per_row ? row : 0];   // a power of two: exact
-            const float* xr = x + row * ldx + kb * 16 + h * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = xr[e] * s;
-                h0[e] = (_Float16)v;
-                h1[e] = (_Float16)(v - (float)h0[e]);
-            }
+            h2_pack8(x + row * ldx + kb * 16 + h * 8, s_all, o);
         } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { h0[e] = (_Float16)0.f; h1[e] = (_Float16)0.f; }
+            *reinterpret_cast<uint4*>(o) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(o + PIECE) = make_uint4(0, 0, 0, 0);
         }
-        unsigned char* o = out + blk * BLK2 + lane * 16;
-        *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(h0);
-        *reinterpret_cast<uint4*>(o + PIECE) = *reinterpret_cast<const uint4*>(h1);
+    }
+}
+
+// per-row mode in one pass over HBM: a workgroup owns one 32-row block; its four waves first reduce eight rows each (maximum -> scale,
+// L2 norm), then all 256 threads pack the block, whose second read comes from L2
+__global__ __launch_bounds__(256) void h2_rowpack_kernel(const float* __restrict__ x, long ldx, long rows, int K, float* __restrict__ inv_scale,
+                                                         float* __restrict__ row_norm, unsigned char* __restrict__ out) {
+    __shared__ float s_mul[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rb = blockIdx.x;
+    // the wave's eight rows side by side: eight independent loads in flight per trip
+    float m[8], ss[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { m[i] = 0.f; ss[i] = 0.f; }
+    const long row0 = rb * 32 + wave * 8;
+    for (int c = lane * 4; c < K; c += 256) {
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long row = row0 + i < rows ? row0 + i : rows - 1;
+            v[i] = *reinterpret_cast<const float4*>(x + row * ldx + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            m[i] = amax4(m[i], v[i]);
+            ss[i] += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { m[i] = fmaxf(m[i], __shfl_xor(m[i], o, 64)); ss[i] += __shfl_xor(ss[i], o, 64); }
+    }
+    if (lane < 8 && row0 + lane < rows) {
+        float mm = m[0], s2 = ss[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { mm = lane == i ? m[i] : mm; s2 = lane == i ? ss[i] : s2; }
+        const float inv = pow2_scale_inv(mm);
+        inv_scale[row0 + lane] = inv;
+        if (row_norm) row_norm[row0 + lane] = sqrtf(s2) * 1.0001f;
+        s_mul[wave * 8 + lane] = 1.0f / inv;
+    }
+    __syncthreads();
+    const int KB = K >> 4;
+    const int r = lane & 31, h = lane >> 5;
+    const long row = rb * 32 + r;
+#pragma unroll 4
+    for (int kb = wave; kb < KB; kb += 4) {
+        unsigned char* o = out + (rb * KB + kb) * (long)BLK2 + lane * 16;
+        if (row < rows) {
+            h2_pack8(x + row * ldx + kb * 16 + h * 8, s_mul[r], o);
+        } else {
+            *reinterpret_cast<uint4*>(o) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(o + PIECE) = make_uint4(0, 0, 0, 0);
+        }
     }
 }
 
@@ -138,21 +194,22 @@ extern "C" int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K,
     TVL_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ldx >= K && ldx % 4 == 0, "tvl_h2_pack: need K %% 16 == 0, ldx >= K, ldx %% 4 == 0");
     TVL_REQUIRE(tvl_aligned16(out) && tvl_aligned16(x), "tvl_h2_pack: operands must be 16-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long rp = (rows + 31) / 32 * 32;
+    TVL_REQUIRE(rp / 32 * (K / 16) < (1ll << 31) && rows * (K / 4) < (1ll << 32), "tvl_h2_pack: image too large (%ld blocks)", rp / 32 * (K / 16));
     if (per_row) {
-        hipLaunchKernelGGL(h2_rowscale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, (long)ldx, (long)rows, K, inv_scale, row_norm);
+        hipLaunchKernelGGL(h2_rowpack_kernel, dim3((unsigned)(rp / 32)), dim3(256), 0, s, x, (long)ldx, (long)rows, K, inv_scale, row_norm,
+                           reinterpret_cast<unsigned char*>(out));
     } else {
         hipError_t e = hipMemsetAsync(work, 0, 4, s);
         TVL_REQUIRE(e == hipSuccess, "tvl_h2_pack: memset failed: %s", hipGetErrorString(e));
-        long nb = (rows * (K / 4) + 255) / 256;
-        nb = nb > 2048 ? 2048 : nb;
+        long nb = (rows * (K / 4) + 1023) / 1024;
+        nb = nb > 4096 ? 4096 : nb;
         hipLaunchKernelGGL(h2_absmax_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, reinterpret_cast<unsigned*>(work));
-        hipLaunchKernelGGL(h2_tensorscale_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<const unsigned*>(work), inv_scale);
+        nb = (rp * (K / 8) + 255) / 256;
+        nb = nb > 1048576 ? 1048576 : nb;
+        hipLaunchKernelGGL(h2_pack_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, reinterpret_cast<const unsigned*>(work),
+                           inv_scale, reinterpret_cast<unsigned char*>(out), rp);
     }
-    const long rp = (rows + 31) / 32 * 32;
-    long nb = (rp * (K / 8) + 255) / 256;
-    nb = nb > 1048576 ? 1048576 : nb;
-    hipLaunchKernelGGL(h2_pack_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, (const float*)inv_scale, per_row,
-                       reinterpret_cast<unsigned char*>(out), rp);
     TVL_LAUNCH_CHECK("tvl_h2_pack");
     return 0;
 }
