@@ -446,6 +446,10 @@ def main():
                   net_kw=base_old, img_size=128)
     run_cris_case("cris_tiny_coop_trunc_n12_b1", preset="tiny", wseed=31, learner_kind="coop", iseed=35, B=1, L=70,
                   learner_kw=dict(prompt_depth=2, num_context=12, vector_std=0.02), net_kw=base_new)
+    # unfrozen projector head (coop_cris.py:88-94: proj.txt and proj.vis[-1] train): weight / bias gradients of both
+    run_cris_case("cris_tiny_coop_n4_d2_nofreeze_last", preset="tiny", wseed=31, learner_kind="coop", iseed=36, B=2, L=7,
+                  learner_kw=dict(prompt_depth=2, num_context=4, vector_std=0.02),
+                  net_kw=dict(use_new_last_layer=False, no_freeze_last_layer=True))
     run_cris_case("cris_rn50_cocoop_n4_d1_newlast", preset="rn50", wseed=41, learner_kind="cocoop", iseed=41, B=1, L=8,
                   learner_kw=dict(prompt_depth=1, num_context=4, vector_std=0.02, use_unified_projection=False,
                                   intermediate_dim=64, use_proj_norm=True, use_lora_proj=False, norm_image_features=False,

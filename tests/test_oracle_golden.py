@@ -18,6 +18,9 @@ def run_oracle(fx):
     if fx["meta"].get("family") == "cris":
         cfg, sd = cris_config_of(fx), cris_state_of(fx)
         params = trainable_of(fx)
+        for k, v in params.items():  # no_freeze_last_layer: the trainable projector head of the fixture replaces the frozen one
+            if k.startswith("proj."):
+                sd[k] = v
         pix, ids, am, mask = inputs_of(fx)
         logits = OC.cris_forward(sd, cfg, oracle_learner(fx, params), pix, ids, am, cris_new_last_of(params))
         loss = O.dice_ce_loss(logits, mask)

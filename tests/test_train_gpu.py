@@ -126,6 +126,61 @@ def test_cris_two_adamw_steps_match_oracle():
         assert err <= 2e-3 * 2e-2, f"{name}: {err:.3e}"
 
 
+def test_cris_unfrozen_projector_head_two_adamw_steps_match_oracle():
+    """no_freeze_last_layer on CRIS (reference coop_cris.py:88-94): proj.txt and the projector's last 1x1 conv train next to the
+    prompts; two AdamW steps against the oracle, and the prepared (frozen) matrices are built once, not once per step."""
+    from oracle import clipseg_oracle as O
+    from oracle import cris_oracle as OC
+    from tunevlseg_amd import nets
+    from tunevlseg_amd.cris_config import CRISConfig
+    from tunevlseg_amd.nets.context_learner import CoOpContextLearner
+    from tunevlseg_amd.task import DiceCELoss, FusedAdamW, ImageTextMaskModule
+    from tunevlseg_amd.weights import init_cris_state_dict
+
+    cfg = CRISConfig.tiny()
+    sd = init_cris_state_dict(cfg, 31)
+    torch.manual_seed(0)
+    net = nets.COOPCRIS(model_cfg={"clip_pretrain": {"config": cfg, "state_dict": sd}, "img_size": cfg.img_size},
+                        context_learner=partial(CoOpContextLearner, prompt_depth=2, num_context=3), use_new_last_layer=False,
+                        no_freeze_last_layer=True)
+    head = ("proj.txt.weight", "proj.txt.bias", "proj.vis.4.weight", "proj.vis.4.bias")
+    assert {k for k, p in net.named_parameters() if p.requires_grad} == {"context_learner.context_vectors", *head}
+    module = ImageTextMaskModule(net, DiceCELoss(sigmoid=True, lambda_dice=1, lambda_ce=0.2), optimizer=partial(FusedAdamW, lr=2e-3),
+                                 scheduler=None, weight_decay=0.01).cuda()
+    g = torch.Generator().manual_seed(6)
+    pix = torch.randn(2, 3, cfg.img_size, cfg.img_size, generator=g)
+    ids = torch.tensor([[62, 5, 9, 63, 0, 0], [62, 7, 11, 13, 63, 0]])
+    mask = (torch.rand(2, 1, cfg.img_size, cfg.img_size, generator=g) > 0.7).float()
+    own = dict(net.named_parameters())
+    ctx = net.context_learner.context_vectors.detach().cpu().clone().requires_grad_(True)
+    ref = {k: own[k].detach().cpu().clone().requires_grad_(True) for k in head}
+    sd_ref = dict(sd)
+    sd_ref.update(ref)
+    ropt = torch.optim.AdamW([{"params": [ref["proj.txt.weight"], ref["proj.vis.4.weight"]], "weight_decay": 0.01},
+                              {"params": [ctx, ref["proj.txt.bias"], ref["proj.vis.4.bias"]], "weight_decay": 0.0}], lr=2e-3)
+    module.setup("fit")
+    opt = module.configure_optimizers()["optimizer"]
+    am = (ids != 0).long()
+    batch = {"image": pix.cuda(), "input_ids": ids.cuda(), "attention_mask": am.cuda(), "mask": mask.cuda()}
+    preps = []
+    for _ in range(2):
+        opt.zero_grad()
+        module.training_step(batch).backward()
+        opt.step()
+        preps.append(net.weights.prepared())
+        ropt.zero_grad()
+        logits = OC.cris_forward(sd_ref, cfg, {"kind": "coop", "ctx": ctx}, pix, ids, am, None)
+        O.dice_ce_loss(logits, mask).backward()
+        ropt.step()
+    assert preps[0] is preps[1]
+    for k in head:
+        err = (own[k].detach().cpu() - ref[k].detach()).abs().max().item()
+        assert err <= 2e-3 * 2e-2, f"{k}: {err:.3e}"
+        assert (own[k].detach().cpu() - sd[k].reshape(own[k].shape)).abs().max().item() > 1e-4, f"{k} did not train"
+    err = (net.context_learner.context_vectors.detach().cpu() - ctx.detach()).abs().max().item()
+    assert err <= 2e-3 * 2e-2, f"ctx: {err:.3e}"
+
+
 def test_two_rank_step_on_hip_path_equals_global_batch_step(tmp_path):
     """N > 1 on the product path: two fresh child processes (ranks 0 / 1, gloo, one device) each run the HIP net on their half of
     the global batch; the bucketed all-reduce rides on the backward (tunevlseg_amd.dist.GradExchange) and the fused AdamW

@@ -36,6 +36,9 @@ def _pad_cols(m: torch.Tensor, mult: int = 4) -> torch.Tensor:
     return out
 
 
+TRAINABLE_HEAD = ("proj.txt.weight", "proj.txt.bias", "proj.vis.4.weight", "proj.vis.4.bias")   # no_freeze_last_layer
+
+
 def conv3_matrices(w4: torch.Tensor, b: torch.Tensor | None, need_dgrad: bool) -> FrozenConv3:
     """[Cout, Cin, 3, 3] -> GEMM operands.  Forward columns are (ky, kx, ci); the data-gradient matrix is
     Wd[ci, (ky, kx, co)] = w[co, ci, 2-ky, 2-kx] so that dX = im2col(dY) . Wd^T (transposed conv, stride 1)."""
@@ -150,13 +153,16 @@ class CRISWeights(_Node):
     # ------------------------------------------------------------------ GEMM-ready frozen weights
     def prepared(self) -> dict[str, Any]:
         dev = self.backbone.logit_scale.device
-        key = (dev, sum(p._version for p in self.parameters()))
+        # the projector head may train (no_freeze_last_layer, coop_cris.py:88-94): the net reads those four tensors from the parameter
+        # tree, so they neither invalidate nor enter the prepared matrices
+        key = (dev, sum(p._version for p in self.parameters() if not p.requires_grad))
         if self._prep is not None and self._prep_key == key:
             return self._prep
-        if any(p.requires_grad for p in self.parameters()):
+        loose = [n for n, p in self.named_parameters() if p.requires_grad and n not in TRAINABLE_HEAD]
+        if loose:
             raise NotImplementedError(
-                "only the prompt-tuning path is implemented: the CRIS model must be frozen (freeze_all=True); fine-tuning "
-                "(e2e_cris / no_freeze_last_layer) is outside the hot path (SURVEY.md §8)")
+                "only the prompt-tuning path is implemented: the CRIS model must be frozen (freeze_all=True) apart from the projector "
+                f"head; fine-tuning (e2e_cris) is outside the hot path (SURVEY.md §8): {loose[:3]}")
         P = {k: v.detach() for k, v in self.state_dict().items()}
         cfg = self.config
 

@@ -59,13 +59,14 @@ class COOPCRIS(nn.Module):
 
     # ------------------------------------------------------------------ learnability (coop_cris.py:58-94)
     def assign_model_learnability(self, freeze_all, no_freeze_last_layer, use_new_last_layer, new_last_layer_kernel_size, residual_ratio):
-        if not freeze_all or no_freeze_last_layer and not use_new_last_layer:
+        if not freeze_all:
             raise NotImplementedError(
                 "only the prompt-tuning path is implemented for CRIS: frozen model (freeze_all=True) with the prompts and the "
-                "optional new last layer trainable (SURVEY.md §8)")
+                "optional new last layer / unfrozen projector head trainable (SURVEY.md §8)")
         self.eval()
         self.requires_grad_(False)
         self.additive_decoder_layer = None
+        self._train_proj_head = False
         if use_new_last_layer:
             k = new_last_layer_kernel_size
             if not isinstance(k, int):
@@ -79,6 +80,11 @@ class COOPCRIS(nn.Module):
                 nn.Conv2d(64, 1, kernel_size=k, padding="same", padding_mode="replicate"),
             )
             self.residual_ratio = nn.Parameter(torch.tensor(residual_ratio))
+        elif no_freeze_last_layer:
+            # the text alignment layer and the last 1x1 conv of the visual branch train (coop_cris.py:88-94)
+            self.proj.txt.requires_grad_(True)
+            self.proj.vis._modules["4"].requires_grad_(True)
+            self._train_proj_head = True
 
     @property
     def weights(self) -> CRISWeights:
@@ -232,8 +238,13 @@ class COOPCRIS(nn.Module):
         x = C.fconv3_g(x, pj["vis1"], B, 2 * H, 2 * W)
         x = C.BilinearUpFn.apply(x, B, 2 * H, 2 * W, 2)
         x = C.fconv3_g(x, pj["vis3"], B, 4 * H, 4 * W)
-        x = C.flinear_g(x, pj["vis4"])
-        word = C.flinear_g(state, pj["txt"])
+        if self._train_proj_head:   # trainable copies live in the parameter tree, not in the prepared (frozen) matrices
+            v4 = self.proj.vis._modules["4"]
+            x = ops.linear(x, v4.weight.view(v4.weight.shape[0], -1), v4.bias)
+            word = ops.linear(state, self.proj.txt.weight, self.proj.txt.bias)
+        else:
+            x = C.flinear_g(x, pj["vis4"])
+            word = C.flinear_g(state, pj["txt"])
         return C.DynConvFn.apply(x, word, B, 4 * H, 4 * W)  # [B, 4H, 4W]
 
     def get_unimodal_outputs(self, image_input: torch.Tensor, input_ids: torch.Tensor, *args, **kwargs):
