@@ -588,7 +588,7 @@ def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias
     # tensor, the activation is packed on the way in (two passes for its exact row scales: 8 B/element of extra traffic, repaid several
     # times over by 3 MFMAs per product on the DMA-ring kernel instead of 6 on the in-kernel-split one)
     if (layout == NT and GEMM_MODE == "bf16x6" and GEMM_H2 and PACK_H2 and getattr(B, "_tvl_frozen", False) and a_map is None and c_map is None
-            and alpha == 1.0 and M >= 2048 and N >= 128 and N % 16 == 0 and K % 32 == 0 and K >= 64 and 2.0 * M * N * K >= 3e9
+            and alpha == 1.0 and M >= 2048 and N >= PACK_H2_MIN_N and N % 16 == 0 and K % 32 == 0 and K >= PACK_H2_MIN_K and 2.0 * M * N * K >= 3e9
             and A.dim() == 2 and A.stride(1) == 1 and A.stride(0) == lda and lda % 4 == 0 and B.dim() == 2 and B.is_contiguous() and ldb == K
             and Cout.dim() == 2 and Cout.stride(1) == 1 and Cout.stride(0) == ldc and ldc % 4 == 0
             and (residual is None or (residual.dim() == 2 and residual.stride(1) == 1 and residual.stride(0) == ldr))
@@ -723,6 +723,8 @@ def layernorm_bwd_tp3(dy2d, x2d, gamma, mean, rstd, dres=None):
 
 
 CONV_H2 = os.environ.get("TVL_CONV_H2", "1") != "0"   # 3x3 convs over frozen weights (C % 32 == 0, N >= 128) as an implicit GEMM on two fp16 pieces
+PACK_H2_MIN_N = int(os.environ.get("TVL_PACK_H2_MIN_N", "256"))
+PACK_H2_MIN_K = int(os.environ.get("TVL_PACK_H2_MIN_K", "256"))
 PACK_H2 = os.environ.get("TVL_PACK_H2", "1") != "0"   # generic large Linears over frozen weights: pack the activation to h2 on the way in (hip.gemm)
 GEMM_H2 = os.environ.get("TVL_GEMM_H2", "1") != "0"   # the four LayerNorm-fed GEMMs of a tp3 layer on two fp16 pieces (3 MFMAs per product)
 DQKV_H2 = os.environ.get("TVL_DQKV_H2", "1") != "0"   # dQ | dK | dV as an h2 image with per-(row, head) scales; QKV data gradient on tvl_gemm_h2_ks
