@@ -558,10 +558,16 @@ def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_
     return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2, false, false>"
 
 
+def conv_h2_tile(M: int, N: int) -> int:
+    """Rows per workgroup of tvl_conv3x3_h2 (the rule of csrc/gemm_h2.hip): fewest rounds x rows, ties to the larger tile.  (A 128-row
+    tile for the 26 x 26 / 13 x 13 maps measured no gain on the CRIS step and was dropped.)"""
+    t256, t192 = -(-M // 256) * -(-N // 256), -(-M // 192) * -(-N // 256)
+    return 256 if -(-t256 // 256) * 256 <= -(-t192 // 256) * 192 else 192
+
+
 def conv_h2_kernel_name(M, N, bias, act) -> str:
     """Instantiation tvl_conv3x3_h2 launches (CONV = true as the last template argument)."""
-    t256, t192 = -(-M // 256) * -(-N // 256), -(-M // 192) * -(-N // 256)
-    tile = 256 if -(-t256 // 256) * 256 <= -(-t192 // 256) * 192 else 192
+    tile = conv_h2_tile(M, N)
     epi = -1 if (bias or act) else 160
     return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2, false, true>"
 
