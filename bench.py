@@ -273,6 +273,7 @@ def main():
                                   "algorithmic fp32 FLOP/s ceiling = dense bf16 MFMA peak (2.5 PFLOP/s) / 6 MFMAs per fp32 product") if split
                     else "dense f32-input MFMA peak",
                     "launches_per_step": d["launches"] // 2, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1),
+                    "event_pair_overhead_us": round(1e3 * hip.last_empty_pair_ms, 1),   # an empty event pair's reading, already taken off every launch
                     "flops_per_launch": round(d["flops"] / d["launches"]), "all_gemm_ms_per_step": round(gemm_ms, 2),
                     # every GEMM instantiation of the step (one instantiation serves several shapes: the average mixes them)
                     "gemm_kernels": [{"kernel": k.replace("gemm_bf16s_kernel", "bf16s").replace("gemm_f32_kernel", "f32").replace("gemm_tp3_kernel", "tp3"),
@@ -290,9 +291,11 @@ def main():
                         else "CLIPSeg ViT-B/16 + VPT-10 shallow, 352x352")),
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (fp32-equivalent: operands split into 2 fp16 pieces with exact power-of-two row scales [6 of a vision layer's 8 GEMMs] or "
-                      "3 bf16 pieces [the rest, attention]; piece products exact on the 16-bit MFMA, fp32 accumulate)"
-                      if hip.GEMM_MODE == "bf16x6" and hip.GEMM_H2 and not cris else MODE_DTYPE[hip.GEMM_MODE]),
+            "dtype": (("f32 (fp32-equivalent: operands split into 2 fp16 pieces with exact power-of-two scales [3x3 convs with C_in % 32 == 0 and C_out >= 128, "
+                       "Linears / 1x1 convs with N, K >= 256] or 3 bf16 pieces [the rest]; piece products exact on the 16-bit MFMA, fp32 accumulate)" if cris else
+                       "f32 (fp32-equivalent: operands split into 2 fp16 pieces with exact power-of-two scales [the 8 GEMMs and the attention of a vision layer] or "
+                       "3 bf16 pieces [text tower, decoder]; piece products exact on the 16-bit MFMA, fp32 accumulate)")
+                      if hip.GEMM_MODE == "bf16x6" and hip.GEMM_H2 else MODE_DTYPE[hip.GEMM_MODE]),
             "gemm_mode": hip.GEMM_MODE,
             "data": "synthetic", "per_gpu": round(value / world, 2),
             "config": {"workload": ("CRIS (CLIP-RN50 + cross-attn decoder) + CoCoOp meta-net, 416x416, bs=32/GPU (BASELINE configs[2])" if cris else

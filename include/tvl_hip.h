@@ -310,11 +310,12 @@ int tvl_gemm_h2_out(const tvlGemmTp3Args* args, const float* a_row_scale, void* 
  * tvl_attn_h2_bwd with g_as_h2 != 0); plain fp32 output: the QKV data gradient. */
 int tvl_gemm_h2_ks(const tvlGemmTp3Args* args, const float* a_kscale, tvlStream_t stream);
 /* tvl_conv3x3_bf16s on h2 operands (3 MFMAs per product): 3x3 / pad 1 / stride 1, C % 32 == 0.  args->A = the h2 image of the NHWC pixel
- * matrix [B*H*W, C] packed with ONE scale (tvl_h2_pack, per_row = 0; a_row_scale[m] all equal to it) and followed by one all-zero 32-row
+ * matrix [B*H*W, C] packed with ONE scale (tvl_h2_pack, per_row = 0; a_scale points at its inverse) and followed by one all-zero 32-row
  * block, i.e. tvl_h2_bytes(B*H*W, C) + tvl_h2_bytes(32, C) bytes (the padding taps read it); args->a_rows = args->M = B*H*W;
- * args->B = the h2 image of the GEMM-ordered weights [N, 9*C]; args->K = 9*C; fp32 output with the epilogue of tvl_gemm_h2.
+ * args->B = the h2 image of the weights [N, 9*C] with the columns ordered (c / 16, ky, kx, c % 16) (taps innermost per 16-channel block:
+ * consecutive k-slabs gather from the same rows); args->K = 9*C; fp32 output with the epilogue of tvl_gemm_h2.
  * Replaces the frozen 3x3 convs of reference model/layers.py:12-17,96-119,412-445 and clip.py:44-47 (eval BatchNorm folded). */
-int tvl_conv3x3_h2(const tvlGemmTp3Args* args, const tvlConvGeom* geom, const float* a_row_scale, tvlStream_t stream);
+int tvl_conv3x3_h2(const tvlGemmTp3Args* args, const tvlConvGeom* geom, const float* a_scale /* [1] */, tvlStream_t stream);
 /* Attention on two-piece fp16 operands (3 MFMAs per product; csrc/attention_h2.hip): packed QKV and dO as h2 images with ONE scale each
  * (tvl_gemm_h2_out in per-tensor mode), O and dQ | dK | dV as tp3 images.  delta: [B, H, T] fp32 workspace; dnorm_ws: [B, H] x 4 bytes. */
 int tvl_attn_h2_fwd(const void* qkv_h2, const float* qkv_inv, void* o_img, int32_t o_as_h2 /* O as an h2 image sharing the QKV scale, else tp3 */,

@@ -238,7 +238,7 @@ static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void*
     p.B = reinterpret_cast<const unsigned char*>(a->B); p.b_rb = (int)((a->b_rows + 31) / 32);
     p.C = a->C; p.ldc = a->ldc; p.Cp = reinterpret_cast<unsigned char*>(a->C_tp3);
     p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.act = a->act; p.pre_out = a->pre_out;
-    p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha; p.a_scale = a_row_scale;
+    p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha; p.a_scale = a_row_scale; p.a_sstride = conv ? 0 : 1;
     p.Ch2 = reinterpret_cast<unsigned char*>(c_h2); p.out_norm = out_row_norm; p.out_mul = out_mul; p.out_add = out_add; p.out_inv = out_inv_scale; p.out_stride = out_per_tensor ? 0 : 1;
     int bm = a->tile_m;
     if (bm != 256 && bm != 192) {
@@ -257,17 +257,18 @@ static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void*
 }
 
 // 3x3 / pad 1 / stride 1 conv of an NHWC pixel matrix as an implicit GEMM over h2 operands.  args->A = the h2 image of the pixel matrix
-// [B*H*W, C] (ONE scale for the tensor: a_row_scale[m] all equal) followed by one all-zero 32-row block (the source of the padding taps:
+// [B*H*W, C] (ONE scale for the tensor: a_scale points at that one inverse scale) followed by one all-zero 32-row block (the source of the padding taps:
 // the image holds tvl_h2_bytes(B*H*W, C) + tvl_h2_bytes(32, C) bytes); args->a_rows = args->M = B*H*W; args->B = the h2 image of the
-// weights [N, 9*C], columns ordered (ky, kx, c); args->K = 9*C.  Epilogue as tvl_gemm_h2 (fp32 output).  Needs C % 32 == 0.
-extern "C" int tvl_conv3x3_h2(const tvlGemmTp3Args* a, const tvlConvGeom* g, const float* a_row_scale, tvlStream_t stream) {
+// weights [N, 9*C], columns ordered (c / 16, ky, kx, c % 16) -- the nine taps of a 16-channel block are consecutive k-slabs, so their
+// gathers re-read rows that are still in L2; args->K = 9*C.  Epilogue as tvl_gemm_h2 (fp32 output).  Needs C % 32 == 0.
+extern "C" int tvl_conv3x3_h2(const tvlGemmTp3Args* a, const tvlConvGeom* g, const float* a_scale, tvlStream_t stream) {
     TVL_REQUIRE(a != nullptr && g != nullptr, "tvl_conv3x3_h2: null args");
     TVL_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0 && g->H < 32768 && g->W < 32768 && g->C > 0 && g->C % 32 == 0 && g->stride == 1,
                 "tvl_conv3x3_h2: need C %% 32 == 0 and stride 1 (C=%d stride=%d)", g->C, g->stride);
     TVL_REQUIRE((int64_t)g->B * g->H * g->W == a->M && a->a_rows == a->M && a->K == 9 * g->C && (int64_t)a->M + 64 < (1ll << 31),
                 "tvl_conv3x3_h2: M must be B*H*W (= a_rows) and K = 9*C (M=%d K=%d)", a->M, a->K);
-    TVL_REQUIRE(a->C && !a->C_tp3, "tvl_conv3x3_h2: fp32 output only");
-    return gemm_h2_impl(a, a_row_scale, nullptr, nullptr, 0.f, 0.f, nullptr, 0, stream, g);
+    TVL_REQUIRE(a->C && !a->C_tp3 && a_scale, "tvl_conv3x3_h2: fp32 output only; the map's inverse scale is required");
+    return gemm_h2_impl(a, a_scale, nullptr, nullptr, 0.f, 0.f, nullptr, 0, stream, g);
 }
 
 extern "C" int tvl_gemm_h2(const tvlGemmTp3Args* a, const float* a_row_scale, tvlStream_t stream) {
@@ -299,7 +300,7 @@ extern "C" int tvl_gemm_h2_ks(const tvlGemmTp3Args* a, const float* a_kscale, tv
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.A = reinterpret_cast<const unsigned char*>(a->A); p.a_rb = (int)((a->a_rows + 31) / 32);
     p.B = reinterpret_cast<const unsigned char*>(a->B); p.b_rb = (int)((a->b_rows + 31) / 32);
-    p.C = a->C; p.ldc = a->ldc; p.alpha = a->alpha; p.a_kscale = a_kscale; p.k_chunks = a->K / 64;
+    p.C = a->C; p.ldc = a->ldc; p.alpha = a->alpha; p.a_kscale = a_kscale; p.k_chunks = a->K / 64; p.a_sstride = 1;
     const int rc = launch<192, 256, 3, E_F32 | E_RSCALE, 2, true>(p, reinterpret_cast<hipStream_t>(stream));
     TVL_REQUIRE(rc == 0, "tvl_gemm_h2_ks: launch failed (dynamic LDS opt-in?)");
     TVL_LAUNCH_CHECK("tvl_gemm_h2_ks");

@@ -56,6 +56,7 @@ struct Tp3Params {
     const float* dact_aux; int ld_aux; int dact;
     float alpha;
     const float* a_scale;   // optional per-row factor of the result (two-piece fp16 operands carry power-of-two row scales), or null
+    int a_sstride;          // 1: a_scale[row]; 0: one factor for every row (a tensor-scaled A operand: the conv's pixel matrix)
     // h2 OUTPUT (the next GEMM's A operand as two fp16 pieces): its row scale comes from a Cauchy-Schwarz bound on the row,
     // |out[m, n]| <= out_norm[m] * out_mul + out_add (out_norm = ||A row m||_2 from A's producer, out_mul = max_n ||B row n||_2 times
     // the activation's Lipschitz bound, out_add = max |bias|); the epilogue writes the inverse scale to out_inv[m]
@@ -65,7 +66,7 @@ struct Tp3Params {
     const float* a_kscale; int k_chunks;
     int out_stride;   // 1: out_norm / out_inv are per row; 0: one bound and one scale for the whole output (out_norm[0], out_inv[0])
     // CONV kernels: A is the image of the NHWC pixel matrix [B*cH*cW, 16*cC16] with one all-zero 32-row block appended (block row a_rb);
-    // row m of the GEMM gathers its nine taps from it (3x3, pad 1, stride 1; K = 9 * 16 * cC16 ordered (ky, kx, c))
+    // row m of the GEMM gathers its nine taps from it (3x3, pad 1, stride 1; K = 9 * 16 * cC16 ordered (c / 16, ky, kx, c % 16))
     int cH, cW, cC16;
     int tiles_m, tiles_n;
 };
@@ -112,7 +113,7 @@ __device__ __forceinline__ void emit4(const Tp3Params& p, long row, int col, flo
     float v[4] = {a.x, a.y, a.z, a.w};
     if (G || (EPI & E_RSCALE)) {   // alpha, and the operand row scale of the two-piece fp16 format
         const float f = p.a_kscale ? p.alpha * p.a_kscale[row * p.k_chunks + p.k_chunks - 1]   // the accumulator carries the LAST chunk's scale
-                                   : ((G ? (p.a_scale != nullptr) : true) ? p.alpha * p.a_scale[row] : p.alpha);
+                                   : ((G ? (p.a_scale != nullptr) : true) ? p.alpha * p.a_scale[row * p.a_sstride] : p.alpha);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= f;
     }
@@ -318,9 +319,10 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     }
     auto conv_advance = [&]() {
         if constexpr (CONV) {
-            if (++cv_cb == p.cC16) {
-                cv_cb = 0;
-                if (++cv_dx == 2) { cv_dx = -1; ++cv_dy; }
+            // taps innermost: the nine requests for one channel block hit the same few rows while they are still in L2
+            if (++cv_dx == 2) {
+                cv_dx = -1;
+                if (++cv_dy == 2) { cv_dy = -1; ++cv_cb; }
             }
         }
     };
