@@ -299,8 +299,12 @@ __device__ __forceinline__ void epilogue_t(const GemmParams& p, f32x16 (&acc)[TM
     }
 }
 
+// STAGES: 1 = one LDS buffer, the next slab waits in registers; 2 = two LDS buffers; 3 = one LDS buffer and TWO slabs ahead in registers
+// (the latency-bound 64x64 tile: a slab's global loads get two k-steps to land instead of one)
 template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV>
 __device__ __forceinline__ void gemm_bf16s_body(const GemmParams& p) {
+    constexpr bool AHEAD2 = STAGES == 3;
+    static_assert(!AHEAD2 || !CONV, "two-ahead prefetch: plain operands only");
     constexpr int LDB = BK + 8;  // bf16 elements per LDS row: 80 B (BK 32) / 48 B (BK 16), both conflict free for ds_read_b128
     constexpr int STAGE_ELEMS = S * (BM + BN) * LDB;
     constexpr int WGN = NWAVES / WGM;
@@ -342,6 +346,8 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmParams& p) {
 
     StageRegs<BM, BK> sa;
     StageRegs<BN, BK> sb;
+    StageRegs<BM, BK> sa2;   // AHEAD2 only: the slab after next
+    StageRegs<BN, BK> sb2;
     const tvlRowMap ident = {0, 0, 0};
     const int nk = (p.K + BK - 1) / BK;
 
@@ -355,16 +361,29 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmParams& p) {
     gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, 0, p.K, ident);
     sstore<BM, BK, S>(sa, smem);
     sstore<BN, BK, S>(sb, smem + S * BM * LDB);
+    if constexpr (AHEAD2) {   // slab 1 -> (sa, sb), slab 2 -> (sa2, sb2); inside the loop the two register sets alternate
+        if (nk > 1) {
+            gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, BK, p.K, p.a_map);
+            gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, BK, p.K, ident);
+        }
+        if (nk > 2) {
+            gload<BM, BK, VEC>(sa2, p.A, p.lda, m0, p.M, 2 * BK, p.K, p.a_map);
+            gload<BN, BK, VEC>(sb2, p.B, p.ldb, n0, p.N, 2 * BK, p.K, ident);
+        }
+    }
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // one k-slab: MFMAs of slab kt out of LDS, then slab kt+1 goes from registers (ra, rb) to LDS; AHEAD2: (ra, rb) then receive slab kt+3
+    auto slab = [&](int kt, StageRegs<BM, BK>& ra, StageRegs<BN, BK>& rb) {
         const int cur = STAGES == 2 ? (kt & 1) : 0;
         const __bf16* As = smem + cur * STAGE_ELEMS;
         const __bf16* Bs = As + S * BM * LDB;
-        if (kt + 1 < nk) {
-            if constexpr (CONV) gload_conv<BM, BK>(sa, crows, p, (kt + 1) * BK);
-            else gload<BM, BK, VEC>(sa, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, p.a_map);
-            gload<BN, BK, VEC>(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, ident);
+        if constexpr (!AHEAD2) {
+            if (kt + 1 < nk) {
+                if constexpr (CONV) gload_conv<BM, BK>(ra, crows, p, (kt + 1) * BK);
+                else gload<BM, BK, VEC>(ra, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, p.a_map);
+                gload<BN, BK, VEC>(rb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, ident);
+            }
         }
         if constexpr (TM * TN <= 4) {
             // all fragment reads of the slab are issued before its first MFMA; the compiler then waits with counted
@@ -430,13 +449,27 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmParams& p) {
                 }
             }
         }
-        if (STAGES == 1) __syncthreads();  // every wave is done reading this slab before it is overwritten
+        if (STAGES != 2) __syncthreads();  // every wave is done reading this slab before it is overwritten
         if (kt + 1 < nk) {
             __bf16* dst = smem + (STAGES == 2 ? (cur ^ 1) * STAGE_ELEMS : 0);
-            sstore<BM, BK, S>(sa, dst);
-            sstore<BN, BK, S>(sb, dst + S * BM * LDB);
+            sstore<BM, BK, S>(ra, dst);
+            sstore<BN, BK, S>(rb, dst + S * BM * LDB);
+            if constexpr (AHEAD2) {
+                if (kt + 3 < nk) {
+                    gload<BM, BK, VEC>(ra, p.A, p.lda, m0, p.M, (kt + 3) * BK, p.K, p.a_map);
+                    gload<BN, BK, VEC>(rb, p.B, p.ldb, n0, p.N, (kt + 3) * BK, p.K, ident);
+                }
+            }
         }
         __syncthreads();
+    };
+    if constexpr (AHEAD2) {
+        for (int kt = 0; kt < nk; kt += 2) {   // the two register sets alternate: static register indices, counted vmcnt waits
+            slab(kt, sa, sb);
+            if (kt + 1 < nk) slab(kt + 1, sa2, sb2);
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) slab(kt, sa, sb);
     }
     // two copies of the epilogue so that the common order (activation, then residual) keeps its straight-line code
     // fast path: every epilogue operand 16-byte aligned and the wave's columns inside N -> coalesced stores through LDS
@@ -572,7 +605,7 @@ int launch_v(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    constexpr size_t stage_bytes = (size_t)STAGES * S * (BM + BN) * (BK + 8) * sizeof(__bf16);
+    constexpr size_t stage_bytes = (size_t)(STAGES == 2 ? 2 : 1) * S * (BM + BN) * (BK + 8) * sizeof(__bf16);
     constexpr size_t epi_bytes = (size_t)NWAVES * (BM / WGM) * 36 * sizeof(float);  // per-wave scratch of the coalesced epilogue: its WM rows
     constexpr size_t smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static int attr_dev_mask = 0;  // the > 64 KiB dynamic-LDS opt-in is a per-device function attribute
@@ -608,7 +641,7 @@ int launch_tile(int bm, const GemmParams& p, hipStream_t s) {
     // round trip (~1 us) around ~100 cycles of MFMA, so a 64-deep slab halves the kernel's duration; TVL_GEMM_SMALL_BK=32 restores it
     static const int small_bk = getenv("TVL_GEMM_SMALL_BK") ? atoi(getenv("TVL_GEMM_SMALL_BK")) : 64;
     if constexpr (S == 3) {
-        if (small_bk == 64) return launch_v<64, 64, 2, S, VEC, 64, 1>(p, s);
+        if (small_bk == 64) return launch_v<64, 64, 2, S, VEC, 64, 3>(p, s);   // + two slabs ahead in registers
     }
     return launch<64, 64, 2, S, VEC>(p, s);
 }

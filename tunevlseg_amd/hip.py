@@ -331,7 +331,7 @@ def gemm_kernel_key(layout: int, M: int, N: int, vec: bool = True, split: int = 
     if split:
         tile = _bf16s_tile(M, N, K)
         bk = 64 if (tile[0] == 64 and split == 3 and os.environ.get("TVL_GEMM_SMALL_BK", "64") == "64") else 32
-        return f"gemm_bf16s_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {split}, {'true' if vec else 'false'}, {bk}, 1, false>"
+        return f"gemm_bf16s_kernel<{tile[0]}, {tile[1]}, {tile[2]}, {split}, {'true' if vec else 'false'}, {bk}, {3 if bk == 64 else 1}, false>"
     best, tile = None, (64, 64, 2)
     for bm, bn, per_cu, wgm in ((128, 128, 2, 2), (96, 128, 2, 1), (64, 64, 4, 2)):
         if bm == 96 and layout == TN:
