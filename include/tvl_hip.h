@@ -300,6 +300,7 @@ int tvl_gemm_tp3(const tvlGemmTp3Args* args, tvlStream_t stream);
 int64_t tvl_h2_bytes(int64_t rows, int32_t K);
 int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, float* inv_scale, float* row_norm /* [rows] or null */,
                 int32_t per_row, void* work, tvlStream_t stream);
+int tvl_h2_absmax(const float* x, int64_t ldx, int64_t rows, int32_t K, void* bits /* 4 bytes: max |x| as float bits */, tvlStream_t stream);
 int tvl_gemm_h2(const tvlGemmTp3Args* args, const float* a_row_scale, tvlStream_t stream);
 /* ... with the result written as an h2 image (the next GEMM's A operand).  Its row scales come from the bound
  * |out[m, n]| <= out_row_norm[m] * out_mul + out_add (L2 norms of A's rows from A's producer; out_mul = max_n ||B row n||_2 times the
@@ -335,6 +336,10 @@ int tvl_avgpool_bwd(const float* dy, int32_t lddy, float* dx, int32_t lddx, int3
 /* F.interpolate(scale_factor=s, mode="bilinear") / nn.Upsample (align_corners=False), integer s; bwd: H, W = input sizes */
 int tvl_bilinear_up_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t s, tvlStream_t stream);
 int tvl_bilinear_up_bwd(const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t s, tvlStream_t stream);
+/* tvl_bilinear_up_fwd written directly as the h2 image (one scale = the input's, amax_bits from tvl_h2_absmax over x) the next 3x3 conv reads (tvl_conv3x3_h2);
+ * C % 16 == 0.  Replaces F.interpolate + the conv's own packing of reference layers.py:100-107. */
+int tvl_bilinear_up_h2(const float* x, int32_t ldx, const void* amax_bits, void* out, float* inv_scale, int32_t B, int32_t H, int32_t W, int32_t C,
+                       int32_t s, tvlStream_t stream);
 /* y[b] = a * F.interpolate(x[b], (Ho,Wo), mode="bicubic", align_corners=True) + r * extra[b]  (extra may be NULL);
  * single-channel maps [B,Hi,Wi] -> [B,Ho,Wo] (coop_cris.py:235,240-242); bwd: dx = a * bicubic^T(dy) */
 int tvl_bicubic_ac_fwd(const float* x, float* y, const float* extra, float a, float r, int32_t B, int32_t Hi, int32_t Wi,

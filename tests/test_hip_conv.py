@@ -231,3 +231,27 @@ def test_conv3x3_two_piece_fp16(hip, B, C, H, W, Cout, bias_relu):
     finally:
         hip.CONV_H2 = True
     close(y, y3, 1e-5, "conv3x3 h2 vs bf16x3")
+
+
+@pytest.mark.parametrize("B,C,H,W,s,Cout", [(2, 64, 13, 11, 2, 128), (3, 96, 9, 10, 2, 144)])
+def test_bilinear_upsample_written_as_conv_operand(hip, B, C, H, W, s, Cout):
+    """tvl_bilinear_up_h2: the upsample as the h2 image of its result (one scale = the input's; ragged row count), and the 3x3 conv reading it
+    (``conv3x3(packed=...)``) against the conv of the fp32 upsample."""
+    x = dev(rnd(B * H * W, C, seed=51))
+    x[:, : C // 2] *= 1e-2
+    up = hip.bilinear_up_fwd(x, B, H, W, s)
+    img = hip.bilinear_up_h2(x, B, H, W, s)
+    assert not img.per_row and img.rows == B * H * s * W * s
+    amax = x.abs().max().item()
+    assert 2.0**13 <= amax / img.inv_scale.item() < 2.0**14   # the input's maximum sets the scale
+    close(img.float(), up, 2.0**-20, "upsample as h2")
+    assert img.buf[-(C // 16) * 2048:].abs().max().item() == 0   # the zero block the padding taps read
+    w, b = rnd(Cout, C, 3, 3, seed=52) * (9 * C) ** -0.5, rnd(Cout, seed=53)
+    wm = hip.mark_frozen(dev(w.permute(0, 2, 3, 1).reshape(Cout, 9 * C)))
+    Ho, Wo = H * s, W * s
+    if hip.conv3x3_takes_h2(B * Ho * Wo, C, wm):
+        y = hip.conv3x3(None, B, Ho, Wo, wm, dev(b), hip.ACT_RELU, packed=img)
+        y_ref = hip.conv3x3(up, B, Ho, Wo, wm, dev(b), hip.ACT_RELU)
+        close(y, y_ref, 1e-5, "conv over the packed upsample")
+        ref = F.relu(F.conv2d(F.interpolate(nchw(x.cpu(), B, H, W).double(), scale_factor=s, mode="bilinear"), w.double(), b.double(), padding=1))
+        close(nchw(y, B, Ho, Wo), ref, 2e-5, "upsample + conv vs float64")

@@ -101,6 +101,38 @@ def fconv3_g(x2d, fc: FrozenConv3, B: int, H: int, W: int, act: int = hip.ACT_RE
     return FConv3Fn.apply(x2d, fc, B, H, W, act)
 
 
+class UpConv3Fn(Fn):
+    """``conv3x3(F.interpolate(x, scale_factor=s, mode="bilinear"))`` + folded BN + ReLU (the projector, reference layers.py:100-107) as one
+    node: where the conv runs on two fp16 pieces, the upsample writes the conv's operand image itself and the upsampled map never exists in
+    fp32 (nothing needs it again: frozen weights have no weight gradient, the ReLU mask comes from the output)."""
+
+    @staticmethod
+    def forward(ctx, x2d, fc: FrozenConv3, B, H, W, s, act):
+        x2d = _c(x2d)
+        Ho, Wo = H * s, W * s
+        if hip.conv3x3_takes_h2(B * Ho * Wo, x2d.shape[1], fc.Wm) and x2d.stride(0) % 4 == 0:
+            y = hip.conv3x3(None, B, Ho, Wo, fc.Wm, fc.b, act, packed=hip.bilinear_up_h2(x2d, B, H, W, s))
+        else:
+            y = fconv3(hip.bilinear_up_fwd(x2d, B, H, W, s), fc, B, Ho, Wo, act)
+        ctx.fc, ctx.act, ctx.geom = fc, act, (B, H, W, s)
+        ctx.save_for_backward(y if act == hip.ACT_RELU else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        B, H, W, s = ctx.geom
+        dy2d = _c(dy)
+        if ctx.act == hip.ACT_RELU:
+            dy2d = hip.dact_mul(dy2d, y, hip.ACT_RELU)
+        dup = hip.conv3x3(dy2d, B, H * s, W * s, ctx.fc.Wd)
+        return hip.bilinear_up_bwd(dup, B, H, W, s), None, None, None, None, None, None
+
+
+def up_conv3_g(x2d, fc: FrozenConv3, B: int, H: int, W: int, s: int = 2, act: int = hip.ACT_RELU):
+    return UpConv3Fn.apply(x2d, fc, B, H, W, s, act)
+
+
 class ReluFn(Fn):
     @staticmethod
     def forward(ctx, x):

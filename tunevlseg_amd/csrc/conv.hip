@@ -3,6 +3,7 @@
 // 1x1 conv is a plain GEMM over the map, a 3x3 conv a GEMM over the im2col matrix built here, and channel concatenation
 // is a column offset into a wider matrix (ld > C).  Every kernel is one coalesced pass (channels on consecutive lanes).
 #include "common.h"
+#include "tp3.h"
 
 namespace {
 
@@ -123,6 +124,50 @@ __global__ void bilinear_up_fwd_kernel(const float* __restrict__ x, int ldx, flo
         const T v10 = *reinterpret_cast<const T*>(xb + ((long)y1 * W + x0) * ldx), v11 = *reinterpret_cast<const T*>(xb + ((long)y1 * W + x1) * ldx);
         const T top = vadd(vmul(v00, 1.f - lx), vmul(v01, lx)), bot = vadd(vmul(v10, 1.f - lx), vmul(v11, lx));
         *reinterpret_cast<T*>(y + r * ldy + c) = vadd(vmul(top, 1.f - ly), vmul(bot, ly));
+    }
+}
+// The same upsample written directly as the h2 image of the result (csrc/tp3.h; the next 3x3 conv's operand, tvl_conv3x3_h2): one thread
+// = 8 consecutive channels of one output pixel = one 16-byte store per piece, lane order as in h2_pack_kernel.  Bilinear weights are a convex
+// combination, so the input's maximum (bits, from tvl_h2_absmax) bounds the output: the image carries the input's scale.
+__global__ __launch_bounds__(256) void bilinear_up_h2_kernel(const float* __restrict__ x, int ldx, const unsigned* __restrict__ bits,
+                                                             float* __restrict__ inv_scale, unsigned char* __restrict__ out, int B, int H, int W, int C,
+                                                             int s, long rows_padded) {
+    const int Ho = H * s, Wo = W * s;
+    const unsigned KB = (unsigned)(C >> 4);
+    const float inv_s = 1.0f / (float)s;
+    const long rows = (long)B * Ho * Wo;
+    const float inv_all = h2::inv_scale_of(__builtin_bit_cast(float, bits[0]));
+    const float sc = 1.0f / inv_all;   // a power of two: exact
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv_scale[0] = inv_all;
+    const long total = rows_padded * (C >> 3);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(t & 63);
+        const unsigned blk = (unsigned)(t >> 6);
+        const unsigned rb = blk / KB, kb = blk - rb * KB;
+        const long r = (long)rb * 32 + (lane & 31);
+        const int c = (int)kb * 16 + (lane >> 5) * 8;
+        uint4 pl[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        if (r < rows) {
+            const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), b = (int)(r / ((long)Wo * Ho));
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bil_src(oy, inv_s, H, y0, y1, ly);
+            bil_src(ox, inv_s, W, x0, x1, lx);
+            const float* xb = x + (long)b * H * W * ldx + c;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 v00 = *reinterpret_cast<const float4*>(xb + ((long)y0 * W + x0) * ldx + 4 * q), v01 = *reinterpret_cast<const float4*>(xb + ((long)y0 * W + x1) * ldx + 4 * q);
+                const float4 v10 = *reinterpret_cast<const float4*>(xb + ((long)y1 * W + x0) * ldx + 4 * q), v11 = *reinterpret_cast<const float4*>(xb + ((long)y1 * W + x1) * ldx + 4 * q);
+                const float4 top = vadd(vmul(v00, 1.f - lx), vmul(v01, lx)), bot = vadd(vmul(v10, 1.f - lx), vmul(v11, lx));
+                const float4 o = vadd(vmul(top, 1.f - ly), vmul(bot, ly));   // the same operation order as bilinear_up_fwd_kernel: identical fp32 values
+                v[4 * q] = o.x * sc; v[4 * q + 1] = o.y * sc; v[4 * q + 2] = o.z * sc; v[4 * q + 3] = o.w * sc;
+            }
+            h2::split8(v, pl);
+        }
+        unsigned char* o = out + (long)blk * h2::BLK + lane * 16;
+        *reinterpret_cast<uint4*>(o) = pl[0];
+        *reinterpret_cast<uint4*>(o + h2::PIECE) = pl[1];
     }
 }
 // gather form of the transpose: input pixel i receives from the outputs whose (i0, i1) touch it
@@ -466,6 +511,21 @@ extern "C" int tvl_bilinear_up_fwd(const float* x, int32_t ldx, float* y, int32_
         hipLaunchKernelGGL(bilinear_up_fwd_kernel<1>, dim3(nblk((long)B * H * s * W * s * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
                            y, ldy, B, H, W, C, s);
     TVL_LAUNCH_CHECK("tvl_bilinear_up_fwd");
+    return 0;
+}
+// x [B*H*W, C] -> the h2 image of F.interpolate(x, scale_factor=s, mode="bilinear") as a pixel matrix [B*(sH)*(sW), C], one scale for the
+// tensor (inv_scale[0]); amax_bits: the bit pattern of max |x| (tvl_h2_absmax).  C % 16 == 0.  The caller appends the zero block
+// tvl_conv3x3_h2 wants (this kernel writes tvl_h2_bytes(B*sH*sW, C) bytes).
+extern "C" int tvl_bilinear_up_h2(const float* x, int32_t ldx, const void* amax_bits, void* out, float* inv_scale, int32_t B, int32_t H, int32_t W,
+                                  int32_t C, int32_t s, tvlStream_t stream) {
+    TVL_REQUIRE(x && amax_bits && out && inv_scale, "tvl_bilinear_up_h2: null pointer");
+    TVL_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0 && s >= 1 && s <= 16, "tvl_bilinear_up_h2: bad shape (C %% 16 == 0)");
+    TVL_REQUIRE(ldx >= C && ldx % 4 == 0 && tvl_aligned16(x) && tvl_aligned16(out), "tvl_bilinear_up_h2: ldx %% 4 == 0 and 16-byte aligned operands");
+    const long rows = (long)B * H * s * W * s, rp = (rows + 31) / 32 * 32;
+    TVL_REQUIRE(rp / 32 * (C / 16) < (1ll << 31), "tvl_bilinear_up_h2: image too large");
+    hipLaunchKernelGGL(bilinear_up_h2_kernel, dim3(nblk(rp * (C / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
+                       reinterpret_cast<const unsigned*>(amax_bits), inv_scale, reinterpret_cast<unsigned char*>(out), B, H, W, C, s, rp);
+    TVL_LAUNCH_CHECK("tvl_bilinear_up_h2");
     return 0;
 }
 extern "C" int tvl_bilinear_up_bwd(const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t s,

@@ -214,6 +214,21 @@ extern "C" int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K,
     return 0;
 }
 
+// max |x| over [rows, K] as the bit pattern of a non-negative float in bits[0] (4 bytes, zeroed here): the first half of the per-tensor
+// tvl_h2_pack, for producers that write their own h2 image (tvl_bilinear_up_h2)
+extern "C" int tvl_h2_absmax(const float* x, int64_t ldx, int64_t rows, int32_t K, void* bits, tvlStream_t stream) {
+    TVL_REQUIRE(x && bits && rows > 0 && K > 0 && K % 4 == 0 && ldx >= K && ldx % 4 == 0 && tvl_aligned16(x), "tvl_h2_absmax: need K %% 4 == 0, ldx >= K, ldx %% 4 == 0, alignment");
+    TVL_REQUIRE(rows * (K / 4) < (1ll << 32), "tvl_h2_absmax: tensor too large");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(bits, 0, 4, s);
+    TVL_REQUIRE(e == hipSuccess, "tvl_h2_absmax: memset failed: %s", hipGetErrorString(e));
+    long nb = (rows * (K / 4) + 1023) / 1024;
+    nb = nb > 4096 ? 4096 : nb;
+    hipLaunchKernelGGL(h2_absmax_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, reinterpret_cast<unsigned*>(bits));
+    TVL_LAUNCH_CHECK("tvl_h2_absmax");
+    return 0;
+}
+
 // epilogue(alpha * a_row_scale[m] * A . B^T) over h2 operands; same argument block as tvl_gemm_tp3 (A / B are h2 images; C_tp3, if given,
 // is still a tp3 image: the consumers of this round read three bf16 pieces).  a_row_scale: [M] inverse scales of A's rows (or null);
 // alpha carries the inverse scale of B.

@@ -160,6 +160,8 @@ _SIGS = {
     "tvl_avgpool_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_bilinear_up_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
+    "tvl_bilinear_up_h2": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I],
+    "tvl_h2_absmax": [_P, _L, _L, _I, _P],
     "tvl_bilinear_up_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_bicubic_ac_fwd": [_P, _P, _P, _F, _F, _I, _I, _I, _I, _I],
     "tvl_bicubic_ac_bwd": [_P, _F, _P, _I, _I, _I, _I, _I],
@@ -1237,6 +1239,17 @@ def bilinear_up_bwd(dy2d, B: int, H: int, W: int, s: int, out=None):
     return dx
 
 
+def bilinear_up_h2(x2d: torch.Tensor, B: int, H: int, W: int, s: int) -> "H2":
+    """bilinear_up_fwd written directly as the tensor-scaled H2 image (+ zero block) that ``conv3x3`` reads (``packed=``): the upsampled
+    map never exists in fp32.  Its scale is the input's (a bilinear tap is a convex combination)."""
+    Cc = x2d.shape[1]
+    out = H2(B * H * s * W * s, Cc, x2d.device, per_row=False, zero_tail=True)
+    bits = torch.empty(1, device=x2d.device, dtype=torch.int32)
+    _call("tvl_h2_absmax", _ps(x2d), x2d.stride(0), x2d.shape[0], Cc, bits.data_ptr())
+    _call("tvl_bilinear_up_h2", _ps(x2d), x2d.stride(0), bits.data_ptr(), out.buf.data_ptr(), _p(out.inv_scale), B, H, W, Cc, s)
+    return out
+
+
 def bicubic_ac_fwd(x, Ho: int, Wo: int, extra=None, a: float = 1.0, r: float = 0.0):
     """x [B,Hi,Wi] -> a * bicubic(x; align_corners=True) [+ r * extra] as [B,Ho,Wo]."""
     B, Hi, Wi = x.shape
@@ -1279,20 +1292,30 @@ def copy2d(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     return dst
 
 
-def conv3x3(x2d: torch.Tensor, B: int, H: int, W: int, Wm: torch.Tensor, bias=None, act: int = ACT_NONE, stride: int = 1, out=None):
+def conv3x3_takes_h2(M: int, Cc: int, Wm: torch.Tensor, stride: int = 1) -> bool:
+    """Will ``conv3x3`` run this problem on two fp16 pieces (tvl_conv3x3_h2)?  (Producers that can write the h2 image themselves ask.)"""
+    N = Wm.shape[0]
+    return bool(GEMM_MODE == "bf16x6" and GEMM_H2 and CONV_H2 and stride == 1 and Cc % 32 == 0 and N >= 128 and N % 16 == 0 and M >= 2048
+                and getattr(Wm, "_tvl_frozen", False) and Wm.shape[1] == 9 * Cc)
+
+
+def conv3x3(x2d: torch.Tensor | None, B: int, H: int, W: int, Wm: torch.Tensor, bias=None, act: int = ACT_NONE, stride: int = 1, out=None,
+            packed: "H2 | None" = None):
     """3x3 / pad 1 conv of an NHWC pixel matrix with GEMM-ordered weights ``Wm`` [Cout, >=9C] (+ bias, activation).
 
     Split-bf16 modes run it as an implicit GEMM (no im2col matrix); the exact-fp32 mode and shapes the implicit kernel does
     not take (C % 4 != 0, tiny maps) build the im2col matrix and call the plain GEMM."""
-    Cc = x2d.shape[1]
+    Cc = packed.cols if packed is not None else x2d.shape[1]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     M, N = B * Ho * Wo, Wm.shape[0]
-    y = _out2d(out, M, N, x2d)
+    if packed is not None and (packed.per_row or packed.rows != M or not conv3x3_takes_h2(M, Cc, Wm, stride)):
+        raise RuntimeError("conv3x3(packed=...): needs a tensor-scaled H2 image of the [B*H*W, C] map and a problem conv3x3_takes_h2 accepts")
+    y = _out2d(out, M, N, x2d if x2d is not None else packed.buf)
     split = _NSPLIT.get(GEMM_MODE, 0)
-    if (GEMM_MODE == "bf16x6" and GEMM_H2 and CONV_H2 and stride == 1 and Cc % 32 == 0 and N >= 128 and N % 16 == 0 and M >= 2048
-            and getattr(Wm, "_tvl_frozen", False) and Wm.shape[1] == 9 * Cc and x2d.stride(0) % 4 == 0 and y.stride(0) % 4 == 0):
+    if packed is not None or (conv3x3_takes_h2(M, Cc, Wm, stride) and x2d.stride(0) % 4 == 0 and y.stride(0) % 4 == 0):
         # two fp16 pieces: the map packed with one scale (+ a zero block for the padding taps), the taps gathered by the GEMM's LDS-DMA
-        xa, wb = h2_pack(x2d, per_row=False, zero_tail=True), conv_weight_h2_cached(Wm, Cc)
+        xa = packed if packed is not None else h2_pack(x2d, per_row=False, zero_tail=True)
+        wb = conv_weight_h2_cached(Wm, Cc)
         args = GemmTp3Args(M, N, 9 * Cc, xa.buf.data_ptr(), M, wb.buf.data_ptr(), wb.rows, _ps(y), y.stride(0), None, _p(bias), None, 0, act, None, None, 0,
                            ACT_NONE, wb.alpha(), 0, 0)
         geom = ConvGeom(B, H, W, Cc, 1)

@@ -234,10 +234,8 @@ class COOPCRIS(nn.Module):
     def proj_forward(self, fq: torch.Tensor, H: int, W: int, state: torch.Tensor) -> torch.Tensor:
         pj = self.weights.prepared()["proj"]
         B = state.shape[0]
-        x = C.BilinearUpFn.apply(fq, B, H, W, 2)
-        x = C.fconv3_g(x, pj["vis1"], B, 2 * H, 2 * W)
-        x = C.BilinearUpFn.apply(x, B, 2 * H, 2 * W, 2)
-        x = C.fconv3_g(x, pj["vis3"], B, 4 * H, 4 * W)
+        x = C.up_conv3_g(fq, pj["vis1"], B, H, W, 2)            # Upsample(x2) -> conv 3x3 + BN + ReLU
+        x = C.up_conv3_g(x, pj["vis3"], B, 2 * H, 2 * W, 2)
         if self._train_proj_head:   # trainable copies live in the parameter tree, not in the prepared (frozen) matrices
             v4 = self.proj.vis._modules["4"]
             x = ops.linear(x, v4.weight.view(v4.weight.shape[0], -1), v4.bias)
