@@ -70,7 +70,7 @@ def test_folded_text_gate_and_position_constants(tiny):
     assert torch.allclose(w.pos2d(cfg.vis_dim, 6, 6), OC.pos2d(cfg.vis_dim, 6, 6))
     assert torch.allclose(w.pos1d(cfg.transformer_width, 11), OC.pos1d(cfg.transformer_width, 11))
     co = w.coords(2, 3, 4)
-    assert co.shape == (24, 4) and co[:, 2:].abs().max() == 0 and co[0, 0] == -1 and co[3, 0] == 1 and co[11, 1] == 1
+    assert co.shape == (24, 32) and co[:, 2:].abs().max() == 0 and co[0, 0] == -1 and co[3, 0] == 1 and co[11, 1] == 1
 
 
 def test_constructor_surface_and_errors():

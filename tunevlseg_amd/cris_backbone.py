@@ -9,6 +9,8 @@ convs as plain matrices (+ transposes), attention projections packed per use.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Any, Mapping
 
@@ -35,6 +37,8 @@ def _pad_cols(m: torch.Tensor, mult: int = 4) -> torch.Tensor:
     out[:, :k] = m
     return out
 
+
+COORD_PAD = int(os.environ.get("TVL_CRIS_COORD_PAD", "30"))   # zero channels behind CoordConv's (x, y): vis_dim + 2 + 30 is a multiple of 32 for vis_dim % 32 == 0
 
 TRAINABLE_HEAD = ("proj.txt.weight", "proj.txt.bias", "proj.vis.4.weight", "proj.vis.4.bias")   # no_freeze_last_layer
 
@@ -228,8 +232,9 @@ class CRISWeights(_Node):
             "f3_v_proj": conv_layer("neck.f3_v_proj", 3, False), "f3_cat": conv_layer("neck.f3_cat", 1, True),
             "f4_proj5": conv_layer("neck.f4_proj5", 3, True), "f4_proj4": conv_layer("neck.f4_proj4", 3, True),
             "f4_proj3": conv_layer("neck.f4_proj3", 3, True), "aggr": conv_layer("neck.aggr", 1, True),
-            # CoordConv: the two coordinate channels ride along as real channels (+2 zero channels for 16-byte rows)
-            "coord0": conv_layer("neck.coordconv.0.conv1", 3, True, pad_cin=2), "coord1": conv_layer("neck.coordconv.1", 3, True),
+            # CoordConv: the two coordinate channels ride along as real channels, + zero channels up to a multiple of 32 (514 -> 544) so
+            # that the conv and its data gradient (N = 544) take the two-fp16-piece implicit GEMM (hip.conv3x3_takes_h2)
+            "coord0": conv_layer("neck.coordconv.0.conv1", 3, True, pad_cin=COORD_PAD), "coord1": conv_layer("neck.coordconv.1", 3, True),
         }
         # decoder (layers.py:278-356)
         D = cfg.vis_dim
@@ -303,12 +308,12 @@ class CRISWeights(_Node):
         return self._const[key]
 
     def coords(self, B: int, H: int, W: int) -> torch.Tensor:
-        """CoordConv channels (layers.py:52-64) as a [B*H*W, 4] matrix: (x, y, 0, 0), linspace(-1, 1)."""
+        """CoordConv channels (layers.py:52-64) as a [B*H*W, 2 + COORD_PAD] matrix: (x, y, 0, ..., 0), linspace(-1, 1)."""
         dev = self.backbone.logit_scale.device
         key = ("coords", B, H, W, dev)
         if key not in self._const:
             yy, xx = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
-            m = torch.zeros(H * W, 4)
+            m = torch.zeros(H * W, 2 + COORD_PAD)
             m[:, 0], m[:, 1] = xx.reshape(-1), yy.reshape(-1)
             self._const[key] = m.repeat(B, 1).contiguous().to(dev)
         return self._const[key]
