@@ -300,6 +300,9 @@ int tvl_gemm_tp3(const tvlGemmTp3Args* args, tvlStream_t stream);
 int64_t tvl_h2_bytes(int64_t rows, int32_t K);
 int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, float* inv_scale, float* row_norm /* [rows] or null */,
                 int32_t per_row, void* work, tvlStream_t stream);
+/* tvl_h2_pack of x * (mask > 0): a ReLU layer's data gradient gated while it is packed (mask = the layer's output) */
+int tvl_h2_pack_masked(const float* x, int64_t ldx, const float* mask, int64_t ldm, int64_t rows, int32_t K, void* out, float* inv_scale,
+                       float* row_norm /* [rows] or null */, int32_t per_row, void* work, tvlStream_t stream);
 int tvl_h2_absmax(const float* x, int64_t ldx, int64_t rows, int32_t K, void* bits /* 4 bytes: max |x| as float bits */, tvlStream_t stream);
 int tvl_gemm_h2(const tvlGemmTp3Args* args, const float* a_row_scale, tvlStream_t stream);
 /* ... with the result written as an h2 image (the next GEMM's A operand).  Its row scales come from the bound

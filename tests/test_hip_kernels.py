@@ -585,6 +585,21 @@ def test_h2_pack_round_trip_and_scales(hip, rows, cols):
         assert (err <= bound).all(), (err / bound).max()
 
 
+@pytest.mark.parametrize("rows,cols", [(70, 64), (2049, 512)])
+def test_h2_pack_with_relu_gate(hip, rows, cols):
+    """tvl_h2_pack_masked: x * (mask > 0) packed in one go; scales and row norms are those of the GATED matrix; a strided mask."""
+    x = rnd(rows, cols, seed=8) * torch.logspace(-3, 1, rows)[:, None]
+    wide = rnd(rows, cols + 16, seed=9)
+    mask = dev(wide)[:, 8:8 + cols]   # row stride cols + 16
+    gated = torch.where(wide[:, 8:8 + cols] > 0, x, torch.zeros_like(x))   # (x * False would leave -0.0 behind)
+    for per_row in (True, False):
+        t = hip.h2_pack(dev(x), per_row, want_norm=per_row, relu_mask=mask)
+        ref = hip.h2_pack(dev(gated), per_row, want_norm=per_row)
+        assert torch.equal(t.inv_scale, ref.inv_scale) and torch.equal(t.buf, ref.buf)   # bit-identical to packing the gated matrix
+        if per_row:
+            assert torch.allclose(t.row_norm, ref.row_norm, rtol=1e-6, atol=0)   # (the two instantiations contract their FMAs differently)
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (495, 512, 3072), (33, 256, 64)])
 def test_gemm_h2_matches_fp64(hip, M, N, K):
     """tvl_gemm_h2: three fp16-piece products per k-step, row scales of A and the tensor scale of B undone in the epilogue."""

@@ -68,9 +68,8 @@ class FLinearFn(Fn):
         (y,) = ctx.saved_tensors
         fl = ctx.fl
         dy2d = _c(dy).view(-1, fl.W.shape[0])
-        if ctx.act == hip.ACT_RELU:
-            dy2d = hip.dact_mul(dy2d, y, hip.ACT_RELU)  # relu'(pre) == (y > 0)
-        return hip.linear_dgrad(dy2d, fl.W, Wt=fl.Wt).view(ctx.shape), None, None
+        # relu'(pre) == (y > 0): the gate is applied while dy is packed for the GEMM (or in a pass of its own where the GEMM reads fp32)
+        return hip.linear_dgrad(dy2d, fl.W, Wt=fl.Wt, relu_mask=y if ctx.act == hip.ACT_RELU else None).view(ctx.shape), None, None
 
 
 def flinear_g(x, fl: FrozenLinear, act: int = hip.ACT_NONE):
@@ -91,10 +90,7 @@ class FConv3Fn(Fn):
         (y,) = ctx.saved_tensors
         fc = ctx.fc
         B, H, W = ctx.geom
-        dy2d = _c(dy)
-        if ctx.act == hip.ACT_RELU:
-            dy2d = hip.dact_mul(dy2d, y, hip.ACT_RELU)
-        return hip.conv3x3(dy2d, B, H, W, fc.Wd), None, None, None, None, None
+        return hip.conv3x3(_c(dy), B, H, W, fc.Wd, x_relu_mask=y if ctx.act == hip.ACT_RELU else None), None, None, None, None, None
 
 
 def fconv3_g(x2d, fc: FrozenConv3, B: int, H: int, W: int, act: int = hip.ACT_RELU):
@@ -122,10 +118,7 @@ class UpConv3Fn(Fn):
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
         B, H, W, s = ctx.geom
-        dy2d = _c(dy)
-        if ctx.act == hip.ACT_RELU:
-            dy2d = hip.dact_mul(dy2d, y, hip.ACT_RELU)
-        dup = hip.conv3x3(dy2d, B, H * s, W * s, ctx.fc.Wd)
+        dup = hip.conv3x3(_c(dy), B, H * s, W * s, ctx.fc.Wd, x_relu_mask=y if ctx.act == hip.ACT_RELU else None)
         return hip.bilinear_up_bwd(dup, B, H, W, s), None, None, None, None, None, None
 
 

@@ -22,24 +22,36 @@ __device__ __forceinline__ float pow2_scale_inv(float amax) { return h2::inv_sca
 __device__ __forceinline__ float amax4(float m, const float4 v) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
-__global__ __launch_bounds__(256) void h2_absmax_kernel(const float* __restrict__ x, long ldx, long rows, int K, unsigned* __restrict__ bits) {
+// MASK kernels pack x * (mask > 0): the ReLU gate of a data gradient applied on the way into the image (mask = the layer's output)
+__device__ __forceinline__ float4 gate4(const float4 v, const float4 g) {
+    return make_float4(g.x > 0.f ? v.x : 0.f, g.y > 0.f ? v.y : 0.f, g.z > 0.f ? v.z : 0.f, g.w > 0.f ? v.w : 0.f);
+}
+template <bool MASK>
+__device__ __forceinline__ float4 ld4(const float* __restrict__ x, const float* __restrict__ mask, long off, long moff) {
+    const float4 v = *reinterpret_cast<const float4*>(x + off);
+    if constexpr (MASK) return gate4(v, *reinterpret_cast<const float4*>(mask + moff));
+    return v;
+}
+template <bool MASK>
+__global__ __launch_bounds__(256) void h2_absmax_kernel(const float* __restrict__ x, long ldx, long rows, int K, unsigned* __restrict__ bits,
+                                                        const float* __restrict__ mask, long ldm) {
     float m = 0.f;
     const long total = rows * (K >> 2);
     const long stride = (long)gridDim.x * 256;
     long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (ldx == K) {
-        const float4* x4 = reinterpret_cast<const float4*>(x);
+    if (ldx == K && (!MASK || ldm == K)) {
         for (; t + 3 * stride < total; t += 4 * stride) {
-            const float4 a = x4[t], b = x4[t + stride], c = x4[t + 2 * stride], d = x4[t + 3 * stride];
+            const float4 a = ld4<MASK>(x, mask, 4 * t, 4 * t), b = ld4<MASK>(x, mask, 4 * (t + stride), 4 * (t + stride)),
+                         c = ld4<MASK>(x, mask, 4 * (t + 2 * stride), 4 * (t + 2 * stride)), d = ld4<MASK>(x, mask, 4 * (t + 3 * stride), 4 * (t + 3 * stride));
             m = amax4(amax4(amax4(amax4(m, a), b), c), d);
         }
-        for (; t < total; t += stride) m = amax4(m, x4[t]);
+        for (; t < total; t += stride) m = amax4(m, ld4<MASK>(x, mask, 4 * t, 4 * t));
     } else {
         const unsigned k4 = (unsigned)(K >> 2);
         for (; t < total; t += stride) {
             const unsigned r = (unsigned)t / k4;   // total < 2^32 (host check)
             const unsigned c = ((unsigned)t - r * k4) * 4;
-            m = amax4(m, *reinterpret_cast<const float4*>(x + (long)r * ldx + c));
+            m = amax4(m, ld4<MASK>(x, mask, (long)r * ldx + c, (long)r * ldm + c));
         }
     }
 #pragma unroll
@@ -55,8 +67,9 @@ __global__ __launch_bounds__(256) void h2_absmax_kernel(const float* __restrict_
     }
 }
 // one thread = 8 consecutive k of one row -> one 16-byte store per piece (same mapping as tp3_pack_kernel)
-__device__ __forceinline__ void h2_pack8(const float* __restrict__ xr, float s, unsigned char* __restrict__ o) {
-    const float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
+template <bool MASK = false>
+__device__ __forceinline__ void h2_pack8(const float* __restrict__ xr, float s, unsigned char* __restrict__ o, const float* __restrict__ mr = nullptr) {
+    const float4 a = ld4<MASK>(xr, mr, 0, 0), b = ld4<MASK>(xr, mr, 4, 4);
     const float v[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
     uint4 pl[2];
     h2::split8(v, pl);
@@ -64,8 +77,10 @@ __device__ __forceinline__ void h2_pack8(const float* __restrict__ xr, float s, 
     *reinterpret_cast<uint4*>(o + PIECE) = pl[1];
 }
 // (tensor mode: `bits` = the maximum found by h2_absmax_kernel; the first thread publishes the inverse scale)
+template <bool MASK>
 __global__ __launch_bounds__(256) void h2_pack_kernel(const float* __restrict__ x, long ldx, long rows, int K, const unsigned* __restrict__ bits,
-                                                      float* __restrict__ inv_scale, unsigned char* __restrict__ out, long rows_padded) {
+                                                      float* __restrict__ inv_scale, unsigned char* __restrict__ out, long rows_padded,
+                                                      const float* __restrict__ mask, long ldm) {
     const unsigned KB = (unsigned)(K >> 4);
     const long total = rows_padded * (K >> 3);   // blocks * 64 < 2^31 * 64 (host check on the block count)
     const float inv_all = pow2_scale_inv(__builtin_bit_cast(float, bits[0]));
@@ -80,7 +95,7 @@ __global__ __launch_bounds__(256) void h2_pack_kernel(const float* __restrict__ 
         const long row = (long)rb * 32 + r;
         unsigned char* o = out + (long)blk * BLK2 + lane * 16;
         if (row < rows) {
-            h2_pack8(x + row * ldx + kb * 16 + h * 8, s_all, o);
+            h2_pack8<MASK>(x + row * ldx + kb * 16 + h * 8, s_all, o, MASK ? mask + row * ldm + kb * 16 + h * 8 : nullptr);
         } else {
             *reinterpret_cast<uint4*>(o) = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4*>(o + PIECE) = make_uint4(0, 0, 0, 0);
@@ -90,8 +105,10 @@ __global__ __launch_bounds__(256) void h2_pack_kernel(const float* __restrict__ 
 
 // per-row mode in one pass over HBM: a workgroup owns one 32-row block; its four waves first reduce eight rows each (maximum -> scale,
 // L2 norm), then all 256 threads pack the block, whose second read comes from L2
+template <bool MASK>
 __global__ __launch_bounds__(256) void h2_rowpack_kernel(const float* __restrict__ x, long ldx, long rows, int K, float* __restrict__ inv_scale,
-                                                         float* __restrict__ row_norm, unsigned char* __restrict__ out) {
+                                                         float* __restrict__ row_norm, unsigned char* __restrict__ out, const float* __restrict__ mask,
+                                                         long ldm) {
     __shared__ float s_mul[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rb = blockIdx.x;
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(256) void h2_rowpack_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const long row = row0 + i < rows ? row0 + i : rows - 1;
-            v[i] = *reinterpret_cast<const float4*>(x + row * ldx + c);
+            v[i] = ld4<MASK>(x, mask, row * ldx + c, row * ldm + c);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(256) void h2_rowpack_kernel(const float* __restrict
     for (int kb = wave; kb < KB; kb += 4) {
         unsigned char* o = out + (rb * KB + kb) * (long)BLK2 + lane * 16;
         if (row < rows) {
-            h2_pack8(x + row * ldx + kb * 16 + h * 8, s_mul[r], o);
+            h2_pack8<MASK>(x + row * ldx + kb * 16 + h * 8, s_mul[r], o, MASK ? mask + row * ldm + kb * 16 + h * 8 : nullptr);
         } else {
             *reinterpret_cast<uint4*>(o) = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4*>(o + PIECE) = make_uint4(0, 0, 0, 0);
@@ -186,32 +203,48 @@ extern "C" int64_t tvl_h2_bytes(int64_t rows, int32_t K) {
     return ((rows + 31) / 32) * (int64_t)(K / 16) * BLK2;
 }
 
-// fp32 [rows, K] -> h2 image + inverse scale(s): per_row != 0 -> inv_scale[rows] (activations: A operand), else inv_scale[1]
-// (a frozen weight: B operand, its factor goes into alpha).  `work` = 4 bytes of device scratch (per-tensor mode only).
-extern "C" int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, float* inv_scale, float* row_norm, int32_t per_row,
-                           void* work, tvlStream_t stream) {
+static int h2_pack_impl(const float* x, int64_t ldx, const float* mask, int64_t ldm, int64_t rows, int32_t K, void* out, float* inv_scale,
+                        float* row_norm, int32_t per_row, void* work, tvlStream_t stream) {
     TVL_REQUIRE(x && out && inv_scale && (per_row || work), "tvl_h2_pack: null pointer");
     TVL_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ldx >= K && ldx % 4 == 0, "tvl_h2_pack: need K %% 16 == 0, ldx >= K, ldx %% 4 == 0");
     TVL_REQUIRE(tvl_aligned16(out) && tvl_aligned16(x), "tvl_h2_pack: operands must be 16-byte aligned");
+    TVL_REQUIRE(!mask || (ldm >= K && ldm % 4 == 0 && tvl_aligned16(mask)), "tvl_h2_pack_masked: mask needs ldm >= K, ldm %% 4 == 0, 16-byte alignment");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long rp = (rows + 31) / 32 * 32;
     TVL_REQUIRE(rp / 32 * (K / 16) < (1ll << 31) && rows * (K / 4) < (1ll << 32), "tvl_h2_pack: image too large (%ld blocks)", rp / 32 * (K / 16));
+    unsigned char* o = reinterpret_cast<unsigned char*>(out);
     if (per_row) {
-        hipLaunchKernelGGL(h2_rowpack_kernel, dim3((unsigned)(rp / 32)), dim3(256), 0, s, x, (long)ldx, (long)rows, K, inv_scale, row_norm,
-                           reinterpret_cast<unsigned char*>(out));
+        if (mask) hipLaunchKernelGGL(h2_rowpack_kernel<true>, dim3((unsigned)(rp / 32)), dim3(256), 0, s, x, (long)ldx, (long)rows, K, inv_scale, row_norm, o, mask, (long)ldm);
+        else hipLaunchKernelGGL(h2_rowpack_kernel<false>, dim3((unsigned)(rp / 32)), dim3(256), 0, s, x, (long)ldx, (long)rows, K, inv_scale, row_norm, o, mask, (long)ldm);
     } else {
         hipError_t e = hipMemsetAsync(work, 0, 4, s);
         TVL_REQUIRE(e == hipSuccess, "tvl_h2_pack: memset failed: %s", hipGetErrorString(e));
         long nb = (rows * (K / 4) + 1023) / 1024;
         nb = nb > 4096 ? 4096 : nb;
-        hipLaunchKernelGGL(h2_absmax_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, reinterpret_cast<unsigned*>(work));
+        unsigned* bits = reinterpret_cast<unsigned*>(work);
+        if (mask) hipLaunchKernelGGL(h2_absmax_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, bits, mask, (long)ldm);
+        else hipLaunchKernelGGL(h2_absmax_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, bits, mask, (long)ldm);
         nb = (rp * (K / 8) + 255) / 256;
         nb = nb > 1048576 ? 1048576 : nb;
-        hipLaunchKernelGGL(h2_pack_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, reinterpret_cast<const unsigned*>(work),
-                           inv_scale, reinterpret_cast<unsigned char*>(out), rp);
+        if (mask) hipLaunchKernelGGL(h2_pack_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, (const unsigned*)bits, inv_scale, o, rp, mask, (long)ldm);
+        else hipLaunchKernelGGL(h2_pack_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, (const unsigned*)bits, inv_scale, o, rp, mask, (long)ldm);
     }
     TVL_LAUNCH_CHECK("tvl_h2_pack");
     return 0;
+}
+
+// fp32 [rows, K] -> h2 image + inverse scale(s): per_row != 0 -> inv_scale[rows] (activations: A operand), else inv_scale[1]
+// (a frozen weight or a conv's pixel matrix).  `work` = 4 bytes of device scratch (per-tensor mode only).
+extern "C" int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out, float* inv_scale, float* row_norm, int32_t per_row,
+                           void* work, tvlStream_t stream) {
+    return h2_pack_impl(x, ldx, nullptr, 0, rows, K, out, inv_scale, row_norm, per_row, work, stream);
+}
+// ... of x * (mask > 0): the ReLU gate of a data gradient (mask = the layer's output y, reference F.relu backward) applied while packing, so
+// the gated gradient never exists in fp32
+extern "C" int tvl_h2_pack_masked(const float* x, int64_t ldx, const float* mask, int64_t ldm, int64_t rows, int32_t K, void* out, float* inv_scale,
+                                  float* row_norm, int32_t per_row, void* work, tvlStream_t stream) {
+    TVL_REQUIRE(mask != nullptr, "tvl_h2_pack_masked: null mask");
+    return h2_pack_impl(x, ldx, mask, ldm, rows, K, out, inv_scale, row_norm, per_row, work, stream);
 }
 
 // max |x| over [rows, K] as the bit pattern of a non-negative float in bits[0] (4 bytes, zeroed here): the first half of the per-tensor
@@ -224,7 +257,7 @@ extern "C" int tvl_h2_absmax(const float* x, int64_t ldx, int64_t rows, int32_t 
     TVL_REQUIRE(e == hipSuccess, "tvl_h2_absmax: memset failed: %s", hipGetErrorString(e));
     long nb = (rows * (K / 4) + 1023) / 1024;
     nb = nb > 4096 ? 4096 : nb;
-    hipLaunchKernelGGL(h2_absmax_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, reinterpret_cast<unsigned*>(bits));
+    hipLaunchKernelGGL(h2_absmax_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, reinterpret_cast<unsigned*>(bits), (const float*)nullptr, 0L);
     TVL_LAUNCH_CHECK("tvl_h2_absmax");
     return 0;
 }

@@ -148,6 +148,7 @@ _SIGS = {
     "tvl_tp3_unpack": [_P, _L, _I, _P, _L],
     "tvl_gemm_tp3": [C.POINTER(GemmTp3Args)],
     "tvl_h2_pack": [_P, _L, _L, _I, _P, _P, _P, _I, _P],
+    "tvl_h2_pack_masked": [_P, _L, _P, _L, _L, _I, _P, _P, _P, _I, _P],
     "tvl_gemm_h2_out": [C.POINTER(GemmTp3Args), _P, _P, _P, _F, _F, _P, _I],
     "tvl_attn_h2_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _F],
     "tvl_attn_h2_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _F],
@@ -511,15 +512,22 @@ class H2:
         return self._alpha
 
 
-def h2_pack(x2d: torch.Tensor, per_row: bool, want_norm: bool = False, zero_tail: bool = False) -> H2:
-    """fp32 [rows, cols] -> H2 (per_row: activations, the A operand; per tensor: frozen weights, the B operand)."""
+def h2_pack(x2d: torch.Tensor, per_row: bool, want_norm: bool = False, zero_tail: bool = False, relu_mask: torch.Tensor | None = None) -> H2:
+    """fp32 [rows, cols] -> H2 (per_row: activations, the A operand; per tensor: frozen weights, the B operand, and conv inputs).
+    ``relu_mask``: pack ``x * (relu_mask > 0)`` -- a ReLU layer's data gradient gated on the way into the image."""
     rows, cols = x2d.shape
     out = H2(rows, cols, x2d.device, per_row, zero_tail)
-    work = None if per_row else torch.zeros(1, device=x2d.device, dtype=torch.int32)
+    work = None if per_row else torch.empty(1, device=x2d.device, dtype=torch.int32)
     if per_row and want_norm:
         out.row_norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
-    _call("tvl_h2_pack", _ps(x2d), x2d.stride(0), rows, cols, out.buf.data_ptr(), _p(out.inv_scale), _p(out.row_norm), 1 if per_row else 0,
-          None if work is None else work.data_ptr())
+    if relu_mask is not None:
+        if relu_mask.shape != x2d.shape:
+            raise RuntimeError(f"h2_pack: mask {tuple(relu_mask.shape)} vs matrix {tuple(x2d.shape)}")
+        _call("tvl_h2_pack_masked", _ps(x2d), x2d.stride(0), _ps(relu_mask), relu_mask.stride(0), rows, cols, out.buf.data_ptr(), _p(out.inv_scale),
+              _p(out.row_norm), 1 if per_row else 0, None if work is None else work.data_ptr())
+    else:
+        _call("tvl_h2_pack", _ps(x2d), x2d.stride(0), rows, cols, out.buf.data_ptr(), _p(out.inv_scale), _p(out.row_norm), 1 if per_row else 0,
+              None if work is None else work.data_ptr())
     return out
 
 
@@ -614,23 +622,30 @@ def tp3_tile(M: int, N: int) -> int:
     return bm
 
 
+def _gemm_takes_h2(layout, M, N, K, A, lda, B, ldb, Cout, ldc, residual, ldr, pre_out, dact_aux, ld_aux, alpha, a_map, c_map) -> bool:
+    """Large NT problems over a FROZEN weight (mark_frozen): both operands as two-piece fp16 images -- the weight's image is cached on the
+    tensor, the activation is packed on the way in (one pass for its exact row scales: 8 B/element of extra traffic, repaid by 3 MFMAs
+    per product on the DMA-ring kernel instead of 6 on the in-kernel-split one wherever the GEMM is not HBM-bound: N, K >= 256)."""
+    return bool(layout == NT and GEMM_MODE == "bf16x6" and GEMM_H2 and PACK_H2 and getattr(B, "_tvl_frozen", False) and a_map is None and c_map is None
+                and alpha == 1.0 and M >= 2048 and N >= PACK_H2_MIN_N and N % 16 == 0 and K % 32 == 0 and K >= PACK_H2_MIN_K and 2.0 * M * N * K >= 3e9
+                and A.dim() == 2 and A.stride(1) == 1 and A.stride(0) == lda and lda % 4 == 0 and B.dim() == 2 and B.is_contiguous() and ldb == K
+                and Cout.dim() == 2 and Cout.stride(1) == 1 and Cout.stride(0) == ldc and ldc % 4 == 0
+                and (residual is None or (residual.dim() == 2 and residual.stride(1) == 1 and residual.stride(0) == ldr))
+                and (pre_out is None or (pre_out.dim() == 2 and pre_out.stride(0) == ldc))
+                and (dact_aux is None or (dact_aux.dim() == 2 and dact_aux.stride(0) == ld_aux)))
+
+
 def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias=None, residual=None, ldr=0, act=ACT_NONE,
-         pre_out=None, dact_aux=None, ld_aux=0, dact=ACT_NONE, alpha=1.0, a_map=None, c_map=None):
+         pre_out=None, dact_aux=None, ld_aux=0, dact=ACT_NONE, alpha=1.0, a_map=None, c_map=None, a_relu_mask=None):
+    takes_h2 = _gemm_takes_h2(layout, M, N, K, A, lda, B, ldb, Cout, ldc, residual, ldr, pre_out, dact_aux, ld_aux, alpha, a_map, c_map)
+    if a_relu_mask is not None and not takes_h2:   # A := A * (mask > 0): fused into the packing where the GEMM packs, a pass of its own elsewhere
+        A = dact_mul(A, a_relu_mask, ACT_RELU)
     args = GemmArgs(layout, M, N, K, _ps(A) if A.dim() == 2 else _p(A), lda, _p(B), ldb, _ps(Cout) if Cout.dim() == 2 else _p(Cout), ldc,
                     _p(bias), _ps(residual) if (residual is not None and residual.dim() == 2) else _p(residual), ldr, act, _p(pre_out),
                     _p(dact_aux), ld_aux, dact, alpha, a_map or _ident(), c_map or _ident())
-    # Large NT problems over a FROZEN weight (mark_frozen): both operands as two-piece fp16 images -- the weight's image is cached on the
-    # tensor, the activation is packed on the way in (two passes for its exact row scales: 8 B/element of extra traffic, repaid several
-    # times over by 3 MFMAs per product on the DMA-ring kernel instead of 6 on the in-kernel-split one)
-    if (layout == NT and GEMM_MODE == "bf16x6" and GEMM_H2 and PACK_H2 and getattr(B, "_tvl_frozen", False) and a_map is None and c_map is None
-            and alpha == 1.0 and M >= 2048 and N >= PACK_H2_MIN_N and N % 16 == 0 and K % 32 == 0 and K >= PACK_H2_MIN_K and 2.0 * M * N * K >= 3e9
-            and A.dim() == 2 and A.stride(1) == 1 and A.stride(0) == lda and lda % 4 == 0 and B.dim() == 2 and B.is_contiguous() and ldb == K
-            and Cout.dim() == 2 and Cout.stride(1) == 1 and Cout.stride(0) == ldc and ldc % 4 == 0
-            and (residual is None or (residual.dim() == 2 and residual.stride(1) == 1 and residual.stride(0) == ldr))
-            and (pre_out is None or (pre_out.dim() == 2 and pre_out.stride(0) == ldc))
-            and (dact_aux is None or (dact_aux.dim() == 2 and dact_aux.stride(0) == ld_aux))):
-        gemm_h2(h2_pack(A[:M], per_row=True), weight_h2_cached(B), out=Cout[:M], bias=bias, residual=None if residual is None else residual[:M],
-                act=act, pre_out=None if pre_out is None else pre_out[:M], dact_aux=None if dact_aux is None else dact_aux[:M], dact=dact)
+    if takes_h2:
+        gemm_h2(h2_pack(A[:M], per_row=True, relu_mask=None if a_relu_mask is None else a_relu_mask[:M]), weight_h2_cached(B), out=Cout[:M], bias=bias,
+                residual=None if residual is None else residual[:M], act=act, pre_out=None if pre_out is None else pre_out[:M], dact_aux=None if dact_aux is None else dact_aux[:M], dact=dact)
         return Cout
     split = _NSPLIT.get(GEMM_MODE, 0) if (layout == NT and M >= 256) else 0
     # skinny and deep (text-tower GEMMs: a few dozen 64x64 tiles, 48-64 k-slabs each): split K over more workgroups
@@ -674,7 +689,7 @@ def linear_fwd(x2d: torch.Tensor, W: torch.Tensor, b=None, *, act=ACT_NONE, resi
 
 
 def linear_dgrad(dy2d: torch.Tensor, W: torch.Tensor, *, dact=ACT_NONE, dact_aux=None, residual=None, out=None, c_map=None,
-                 out_rows=None, M=None, Wt: torch.Tensor | None = None):
+                 out_rows=None, M=None, Wt: torch.Tensor | None = None, relu_mask: torch.Tensor | None = None):
     """dx = (dy W) * act'(aux) + residual ; dy2d [M,N], W [N,K] -> [M,K].  ``Wt`` = W^T [K,N] (kept for frozen weights)
     turns the data gradient into an NT GEMM, which is what the split-bf16 kernel runs."""
     Mx = dy2d.shape[0] if M is None else M
@@ -682,9 +697,9 @@ def linear_dgrad(dy2d: torch.Tensor, W: torch.Tensor, *, dact=ACT_NONE, dact_aux
     rows = Mx if out_rows is None else out_rows
     dx = out if out is not None else torch.empty((rows, K), device=dy2d.device, dtype=torch.float32)
     if Wt is not None and GEMM_MODE != "f32":
-        gemm(NT, Mx, K, N, dy2d, N, Wt, N, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map)
+        gemm(NT, Mx, K, N, dy2d, N, Wt, N, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map, a_relu_mask=relu_mask)
     else:
-        gemm(NN, Mx, K, N, dy2d, N, W, K, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map)
+        gemm(NN, Mx, K, N, dy2d, N, W, K, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map, a_relu_mask=relu_mask)
     return dx
 
 
@@ -1112,6 +1127,8 @@ def colsum(x2d, out=None, accumulate=False):
 
 
 def dact_mul(dy2d, pre, act: int):
+    if dy2d.shape != pre.shape or not dy2d.is_contiguous() or not pre.is_contiguous():
+        raise RuntimeError(f"dact_mul: needs two contiguous tensors of one shape, got {tuple(dy2d.shape)} / {tuple(pre.shape)}")
     out = torch.empty_like(dy2d)
     _call("tvl_dact_mul", _p(dy2d), _p(pre), _p(out), dy2d.numel(), act)
     return out
@@ -1300,7 +1317,7 @@ def conv3x3_takes_h2(M: int, Cc: int, Wm: torch.Tensor, stride: int = 1) -> bool
 
 
 def conv3x3(x2d: torch.Tensor | None, B: int, H: int, W: int, Wm: torch.Tensor, bias=None, act: int = ACT_NONE, stride: int = 1, out=None,
-            packed: "H2 | None" = None):
+            packed: "H2 | None" = None, x_relu_mask: torch.Tensor | None = None):
     """3x3 / pad 1 conv of an NHWC pixel matrix with GEMM-ordered weights ``Wm`` [Cout, >=9C] (+ bias, activation).
 
     Split-bf16 modes run it as an implicit GEMM (no im2col matrix); the exact-fp32 mode and shapes the implicit kernel does
@@ -1314,7 +1331,7 @@ def conv3x3(x2d: torch.Tensor | None, B: int, H: int, W: int, Wm: torch.Tensor, 
     split = _NSPLIT.get(GEMM_MODE, 0)
     if packed is not None or (conv3x3_takes_h2(M, Cc, Wm, stride) and x2d.stride(0) % 4 == 0 and y.stride(0) % 4 == 0):
         # two fp16 pieces: the map packed with one scale (+ a zero block for the padding taps), the taps gathered by the GEMM's LDS-DMA
-        xa = packed if packed is not None else h2_pack(x2d, per_row=False, zero_tail=True)
+        xa = packed if packed is not None else h2_pack(x2d, per_row=False, zero_tail=True, relu_mask=x_relu_mask)
         wb = conv_weight_h2_cached(Wm, Cc)
         args = GemmTp3Args(M, N, 9 * Cc, xa.buf.data_ptr(), M, wb.buf.data_ptr(), wb.rows, _ps(y), y.stride(0), None, _p(bias), None, 0, act, None, None, 0,
                            ACT_NONE, wb.alpha(), 0, 0)
@@ -1327,6 +1344,8 @@ def conv3x3(x2d: torch.Tensor | None, B: int, H: int, W: int, Wm: torch.Tensor, 
             e1.record()
             _gemm_prof.append((conv_h2_kernel_name(M, N, bias is not None, act), 2.0 * M * N * 9 * Cc, e0, e1))
         return y
+    if x_relu_mask is not None:   # the paths below read fp32 rows: gate them in a pass of their own
+        x2d = dact_mul(x2d, x_relu_mask, ACT_RELU)
     if split == 3 and Cc % 4 == 0 and M >= 256 and x2d.stride(0) % 4 == 0:
         args = GemmArgs(NT, M, N, 9 * Cc, _ps(x2d), x2d.stride(0), _p(Wm), Wm.shape[1], _ps(y), y.stride(0), _p(bias), None, 0, act,
                         None, None, 0, ACT_NONE, 1.0, _ident(), _ident())
