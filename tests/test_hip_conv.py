@@ -255,3 +255,30 @@ def test_bilinear_upsample_written_as_conv_operand(hip, B, C, H, W, s, Cout):
         close(y, y_ref, 1e-5, "conv over the packed upsample")
         ref = F.relu(F.conv2d(F.interpolate(nchw(x.cpu(), B, H, W).double(), scale_factor=s, mode="bilinear"), w.double(), b.double(), padding=1))
         close(nchw(y, B, Ho, Wo), ref, 2e-5, "upsample + conv vs float64")
+
+
+def test_conv3x3_two_piece_full_size_properties(hip):
+    """BASELINE configs[2]'s largest conv (projector vis3: B = 32, 104 x 104, 512 -> 256; M = 346 112 rows, K = 4608) through properties that
+    need no reference: (1) scaling the map by a power of two scales the result EXACTLY (the image's pieces are identical, only its
+    power-of-two scale moves); (2) permuting the samples permutes the result bit for bit (a row's k-loop does not depend on its tile);
+    (3) an input that is zero outside one sample leaves the other samples' outputs exactly zero (no tap crosses a sample boundary)."""
+    B, C, H, W, Cout = 32, 512, 104, 104, 256
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(B * H * W, C, device="cuda", generator=g)
+    wm = hip.mark_frozen(torch.randn(Cout, 9 * C, device="cuda", generator=g) * (9 * C) ** -0.5)
+    assert hip.conv3x3_takes_h2(B * H * W, C, wm)
+    y = hip.conv3x3(x, B, H, W, wm)
+    y4 = hip.conv3x3(x * 4.0, B, H, W, wm)
+    assert torch.equal(y4, y * 4.0)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+    xp = x.view(B, H * W, C)[perm].reshape(B * H * W, C).contiguous()
+    yp = hip.conv3x3(xp, B, H, W, wm)
+    assert torch.equal(yp.view(B, H * W, Cout), y.view(B, H * W, Cout)[perm])
+    del y4, yp, xp
+    xs = torch.zeros_like(x)
+    xs.view(B, H * W, C)[5] = x.view(B, H * W, C)[5]
+    ys = hip.conv3x3(xs, B, H, W, wm).view(B, H * W, Cout)
+    assert ys[:5].abs().max().item() == 0 and ys[6:].abs().max().item() == 0
+    # (the scale of xs is that of sample 5 alone, which may differ from the full map's: compare to rounding, not to the bit)
+    ref5 = y.view(B, H * W, Cout)[5]
+    assert (ys[5] - ref5).abs().max().item() <= 2e-6 * ref5.abs().max().item()
