@@ -27,7 +27,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from tunevlseg_amd import hip  # noqa: E402
 
 hip.load()
-for M, N, K in [(384, 512, 32), (384, 512, 64), (384, 512, 512), (384, 512, 2048), (64, 64, 512), (384, 1536, 512)]:
+SHAPES = [(384, 512, 32), (384, 512, 64), (384, 512, 512), (384, 512, 2048), (64, 64, 512), (384, 1536, 512)]
+if "--sweep" in sys.argv:   # duration against the number of workgroups at (almost) no work per workgroup, and at K = 512
+    SHAPES = [(384, n, k) for k in (64, 512) for n in (64, 512, 1536, 4096, 8192)] + [(64, 64, 64), (3072, 512, 64)]
+for M, N, K in SHAPES:
     A, B, C = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda"), torch.empty(M, N, device="cuda")
     for _ in range(30):
         hip.gemm(hip.NT, M, N, K, A, K, B, K, C, N)
