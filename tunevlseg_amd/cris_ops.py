@@ -216,6 +216,60 @@ class SelfAttnQKFn(Fn):
         return dqk, dv, None, None, None, None
 
 
+class SelfAttnBlockFn(Fn):
+    """One decoder self-attention block, ``out_proj(attn(q = k = Wqk xq, v = Wv xv))`` (reference layers.py:322-328 with nn.MultiheadAttention's
+    packed in-projection), on two fp16 pieces end to end: both projections write ONE [B*T, 3D] matrix, which is packed once with one scale;
+    attention reads that image and writes O as an image sharing its scale; the out-projection consumes O's image directly.  The backward
+    mirrors it: dO packed once, dQ | dK | dV from the attention kernels as one image, unpacked for the two projection data gradients."""
+
+    @staticmethod
+    def takes(M: int, dh: int, *fls: FrozenLinear) -> bool:
+        return bool(hip.GEMM_MODE == "bf16x6" and hip.GEMM_H2 and hip.ATTN_H2 and SELF_ATTN_H2 and dh == 64 and M >= 2048
+                    and all(getattr(f.W, "_tvl_frozen", False) and f.W.shape[1] % 32 == 0 for f in fls))
+
+    @staticmethod
+    def forward(ctx, xq, xv, fqk: FrozenLinear, fv: FrozenLinear, fo: FrozenLinear, B, T, H, dh):
+        D = H * dh
+        xq2, xv2 = _c(xq).view(B * T, -1), _c(xv).view(B * T, -1)
+        buf = torch.empty((B * T, 3 * D), device=xq2.device, dtype=torch.float32)
+        flinear(xq2, fqk, out=buf[:, :2 * D])
+        flinear(xv2, fv, out=buf[:, 2 * D:])
+        qkv_h = hip.h2_pack(buf, per_row=False)
+        del buf
+        o_h, lse = hip.attn_h2_fwd(qkv_h, B, T, H, dh**-0.5, o_as_h2=True)
+        out, _ = hip.gemm_h2(o_h, hip.weight_h2_cached(fo.W), bias=fo.b)
+        ctx.save_for_backward(qkv_h.buf, qkv_h.inv_scale, o_h.buf, lse)
+        ctx.mods, ctx.geom, ctx.in_shapes = (fqk, fv, fo), (B, T, H, dh), (xq.shape, xv.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        qkv_buf, qkv_inv, o_buf, lse = ctx.saved_tensors
+        fqk, fv, fo = ctx.mods
+        B, T, H, dh = ctx.geom
+        D, M = H * dh, B * T
+        qkv_h = hip.H2.wrap(M, 3 * D, qkv_buf, qkv_inv, per_row=False)
+        o_h = hip.H2.wrap(M, D, o_buf, qkv_inv, per_row=False)
+        do_h = hip.h2_pack(hip.linear_dgrad(_c(d_out).view(M, D), fo.W, Wt=fo.Wt), per_row=False)
+        g = hip.attn_h2_bwd(qkv_h, o_h, do_h, lse, B, T, H, dh**-0.5).float()   # dQ | dK | dV [M, 3D]
+        dxq = hip.linear_dgrad(g[:, :2 * D], fqk.W, Wt=fqk.Wt)
+        dxv = hip.linear_dgrad(g[:, 2 * D:], fv.W, Wt=fv.Wt)
+        return dxq.view(ctx.in_shapes[0]), dxv.view(ctx.in_shapes[1]), None, None, None, None, None, None, None
+
+
+SELF_ATTN_H2 = __import__("os").environ.get("TVL_CRIS_SELF_ATTN_H2", "1") != "0"   # A/B switch of the fused decoder self-attention block
+
+
+def self_attn_block(xq, xv, fqk: FrozenLinear, fv: FrozenLinear, fo: FrozenLinear, B: int, T: int, H: int, dh: int):
+    """[B*T, D] output of the decoder's self-attention sub-block (before its LayerNorm)."""
+    if SelfAttnBlockFn.takes(B * T, dh, fqk, fv, fo):
+        return SelfAttnBlockFn.apply(xq, xv, fqk, fv, fo, B, T, H, dh)
+    D = H * dh
+    qk = flinear_g(xq, fqk).view(B * T, 2 * D)
+    v = flinear_g(xv, fv).view(B * T, D)
+    return flinear_g(SelfAttnQKFn.apply(qk, v, B, T, H, dh), fo)
+
+
 class CrossAttnFn(Fn):
     """T visual queries x Tk word keys with a key-padding mask (layers.py:341-349)."""
 

@@ -696,10 +696,11 @@ def linear_dgrad(dy2d: torch.Tensor, W: torch.Tensor, *, dact=ACT_NONE, dact_aux
     N, K = W.shape
     rows = Mx if out_rows is None else out_rows
     dx = out if out is not None else torch.empty((rows, K), device=dy2d.device, dtype=torch.float32)
+    lda = dy2d.stride(0)   # dy may be a column range of a wider matrix (a packed gradient)
     if Wt is not None and GEMM_MODE != "f32":
-        gemm(NT, Mx, K, N, dy2d, N, Wt, N, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map, a_relu_mask=relu_mask)
+        gemm(NT, Mx, K, N, dy2d, lda, Wt, N, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map, a_relu_mask=relu_mask)
     else:
-        gemm(NN, Mx, K, N, dy2d, N, W, K, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map, a_relu_mask=relu_mask)
+        gemm(NN, Mx, K, N, dy2d, lda, W, K, dx, K, residual=residual, ldr=K, dact_aux=dact_aux, ld_aux=K, dact=dact, c_map=c_map, a_relu_mask=relu_mask)
     return dx
 
 

@@ -215,9 +215,7 @@ class COOPCRIS(nn.Module):
         kin = C.BcastAddFn.apply(words, txt_pos, B)  # key input = words + 1-D code, shared by the layers
         for lw in prep["decoder_layers"]:
             v2 = ops.layer_norm(vis, *lw["norm1"], LN_EPS)
-            qk = C.flinear_g(C.BcastAddFn.apply(v2, vis_pos, B), lw["sa_qk"]).view(B * T, 2 * D)
-            v = C.flinear_g(v2, lw["sa_v"]).view(B * T, D)
-            o = C.flinear_g(C.SelfAttnQKFn.apply(qk, v, B, T, heads, dh), lw["sa_o"]).view(B, T, D)
+            o = C.self_attn_block(C.BcastAddFn.apply(v2, vis_pos, B), v2, lw["sa_qk"], lw["sa_v"], lw["sa_o"], B, T, heads, dh).view(B, T, D)
             vis = ops.add(vis, ops.layer_norm(o, *lw["self_attn_norm"], LN_EPS))
             v2 = ops.layer_norm(vis, *lw["norm2"], LN_EPS)
             q = C.flinear_g(C.BcastAddFn.apply(v2, vis_pos, B), lw["ca_q"]).view(B * T, D)
