@@ -222,7 +222,7 @@ def test_conv3x3_two_piece_fp16(hip, B, C, H, W, Cout, bias_relu):
         torch.cuda.synchronize()
     finally:
         hip._gemm_prof = old
-    assert prof and prof[0][0] == conv_h2_kernel_name(B * H * W, Cout, bias_relu, bias_relu), prof   # the h2 kernel ran, not the bf16 one
+    assert prof and prof[0][0] == conv_h2_kernel_name(B * H * W, Cout, bias_relu, hip.ACT_RELU if bias_relu else hip.ACT_NONE), prof   # the h2 kernel ran, not the bf16 one
     close(nchw(y, B, H, W), ref, 2e-5, "conv3x3 h2")
     # against the three-bf16-piece implicit GEMM on the same input: both are fp32-equivalent
     hip.CONV_H2 = False

@@ -170,6 +170,9 @@ int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
             case E_BIAS | E_QGELU | E_PRE | E_RSCALE | E_H2OUT: return launch<256, 256, 2, E_BIAS | E_QGELU | E_PRE | E_RSCALE | E_H2OUT, 2>(p, s);   // fc1 -> h2
             case E_BIAS | E_QGELU | E_RSCALE | E_H2OUT: return launch<256, 256, 2, E_BIAS | E_QGELU | E_RSCALE | E_H2OUT, 2>(p, s);
             case E_DQGELU | E_RSCALE | E_H2OUT: return launch<256, 256, 2, E_DQGELU | E_RSCALE | E_H2OUT, 2>(p, s);                 // dz -> h2
+            case E_BIAS | E_F32 | E_RSCALE: return launch<256, 256, 2, E_BIAS | E_F32 | E_RSCALE, 2>(p, s);                       // frozen Linear / 1x1 conv
+            case E_BIAS | E_RELU | E_F32 | E_RSCALE: return launch<256, 256, 2, E_BIAS | E_RELU | E_F32 | E_RSCALE, 2>(p, s);     // ... + ReLU (folded BN)
+            case E_F32 | E_RSCALE: return launch<256, 256, 2, E_F32 | E_RSCALE, 2>(p, s);                                         // its data gradient
             default: return launch<256, 256, 2, -1, 2>(p, s);
         }
     }
@@ -181,6 +184,7 @@ int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
         case E_BIAS | E_F32 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_F32 | E_RSCALE, 2>(p, s);
         case E_F32 | E_RSCALE: return launch<192, 256, 3, E_F32 | E_RSCALE, 2>(p, s);
         case E_BIAS | E_RES | E_F32 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_RES | E_F32 | E_RSCALE, 2>(p, s);   // out_proj, fc2
+        case E_BIAS | E_RELU | E_F32 | E_RSCALE: return launch<192, 256, 3, E_BIAS | E_RELU | E_F32 | E_RSCALE, 2>(p, s);  // frozen Linear / 1x1 conv + ReLU
         default: return launch<192, 256, 3, -1, 2>(p, s);
     }
 }
@@ -188,11 +192,14 @@ int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
 // 3x3 conv as an implicit GEMM (the A fragments are gathered tap by tap from the pixel matrix' image): generic epilogue (bias + ReLU of the
 // folded eval BatchNorm) and the plain one of the data gradient
 int launch_h2_conv(const Tp3Params& p, int bm, int epi, hipStream_t s) {
+    constexpr int CONV_FWD = E_BIAS | E_RELU | E_F32 | E_RSCALE;   // conv + folded BN + ReLU
     if (bm == 256) {
         if (epi == (E_F32 | E_RSCALE)) return launch<256, 256, 2, E_F32 | E_RSCALE, 2, false, true>(p, s);
+        if (epi == CONV_FWD) return launch<256, 256, 2, CONV_FWD, 2, false, true>(p, s);
         return launch<256, 256, 2, -1, 2, false, true>(p, s);
     }
     if (epi == (E_F32 | E_RSCALE)) return launch<192, 256, 3, E_F32 | E_RSCALE, 2, false, true>(p, s);
+    if (epi == CONV_FWD) return launch<192, 256, 3, CONV_FWD, 2, false, true>(p, s);
     return launch<192, 256, 3, -1, 2, false, true>(p, s);
 }
 

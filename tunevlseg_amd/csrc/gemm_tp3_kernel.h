@@ -104,7 +104,7 @@ __device__ __forceinline__ long tp3_off(long row, int col, int kblocks) { return
 // bit set of the options below, resolved at compile time -- the epilogue is cold, straight-line code executed once per tile, and
 // with all options live it was ~5 KB per 4-column group, 24 groups per wave: the write-out of a tile then ran at the
 // instruction-fetch rate (20 us per 192x256 tile; stamps in profiles/r2_gemm_experiments.md), not at the store rate.
-enum { E_BIAS = 1, E_RES = 2, E_QGELU = 4, E_DQGELU = 8, E_PRE = 16, E_F32 = 32, E_TP3 = 64, E_RSCALE = 128, E_H2OUT = 256 };
+enum { E_BIAS = 1, E_RES = 2, E_QGELU = 4, E_DQGELU = 8, E_PRE = 16, E_F32 = 32, E_TP3 = 64, E_RSCALE = 128, E_H2OUT = 256, E_RELU = 512 };
 
 // h2_sc: the row's power-of-two scale of an h2 output (computed once per row by epilogue(), not once per four columns)
 template <int EPI, bool NOSTORE = false>
@@ -133,8 +133,8 @@ __device__ __forceinline__ void emit4(const Tp3Params& p, long row, int col, flo
         const float4 r4 = *reinterpret_cast<const float4*>(p.residual + row * p.ldr + col);
         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
     }
-    if (G || (EPI & E_QGELU)) {
-        const int act = G ? (p.act & 0xff) : (int)TVL_ACT_QUICK_GELU;
+    if (G || (EPI & (E_QGELU | E_RELU))) {
+        const int act = G ? (p.act & 0xff) : ((EPI & E_RELU) ? (int)TVL_ACT_RELU : (int)TVL_ACT_QUICK_GELU);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], act);
     }
@@ -519,8 +519,8 @@ int launch_epi(const Tp3Params& p, int epi, hipStream_t s) {
 inline int epi_code(const Tp3Params& p) {
     if ((p.alpha != 1.0f && !p.a_scale && !p.a_kscale) || (p.act & TVL_ACT_POST_RESIDUAL)) return -1;
     const int act = p.act & 0xff;
-    if ((act != TVL_ACT_NONE && act != TVL_ACT_QUICK_GELU) || (p.dact != TVL_ACT_NONE && p.dact != TVL_ACT_QUICK_GELU)) return -1;
-    return (p.bias ? E_BIAS : 0) | (p.residual ? E_RES : 0) | (act ? E_QGELU : 0) | (p.dact ? E_DQGELU : 0) | (p.pre_out ? E_PRE : 0) |
+    if ((act != TVL_ACT_NONE && act != TVL_ACT_QUICK_GELU && act != TVL_ACT_RELU) || (p.dact != TVL_ACT_NONE && p.dact != TVL_ACT_QUICK_GELU)) return -1;
+    return (p.bias ? E_BIAS : 0) | (p.residual ? E_RES : 0) | (act == TVL_ACT_QUICK_GELU ? E_QGELU : 0) | (act == TVL_ACT_RELU ? E_RELU : 0) | (p.dact ? E_DQGELU : 0) | (p.pre_out ? E_PRE : 0) |
            (p.C ? E_F32 : 0) | (p.Cp ? E_TP3 : 0) | ((p.a_scale || p.a_kscale) ? E_RSCALE : 0) | (p.Ch2 ? E_H2OUT : 0);
 }
 

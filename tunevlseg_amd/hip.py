@@ -579,7 +579,7 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
     return Cf, (Ch if Ch is not None else Ct)
 
 
-_H2_EPI_BUILT = {192: {193, 161, 160, 192, 163, 385, 384}, 256: {213, 197, 200, 405, 389, 392}}   # launch_h2's compile-time epilogues per row tile (csrc/gemm_h2.hip)
+_H2_EPI_BUILT = {192: {193, 161, 160, 192, 163, 385, 384, 673}, 256: {213, 197, 200, 405, 389, 392, 161, 673, 160}}   # launch_h2's compile-time epilogues per row tile (csrc/gemm_h2.hip)
 
 
 def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_m=0, c_h2=False) -> str:
@@ -588,8 +588,10 @@ def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_
     if tile not in (192, 256):
         t256, t192 = -(-M // 256) * -(-N // 256), -(-M // 192) * -(-N // 256)
         tile = 256 if -(-t256 // 256) * 256 <= -(-t192 // 256) * 192 else 192
-    epi = (1 if bias else 0) | (2 if residual else 0) | (4 if (act & 0xFF) else 0) | (8 if dact else 0) | (16 if pre_out else 0) | \
-          (32 if c_f32 else 0) | (64 if c_tp3 else 0) | 128 | (256 if c_h2 else 0)
+    epi = (1 if bias else 0) | (2 if residual else 0) | (4 if (act & 0xFF) == ACT_QUICK_GELU else 0) | (512 if (act & 0xFF) == ACT_RELU else 0) | \
+          (8 if dact else 0) | (16 if pre_out else 0) | (32 if c_f32 else 0) | (64 if c_tp3 else 0) | 128 | (256 if c_h2 else 0)
+    if (act & 0xFF) not in (ACT_NONE, ACT_QUICK_GELU, ACT_RELU):
+        epi = -1
     if (act & ~0xFF) or epi not in _H2_EPI_BUILT[tile]:
         epi = -1
     return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2, false, false>"
@@ -605,7 +607,7 @@ def conv_h2_tile(M: int, N: int) -> int:
 def conv_h2_kernel_name(M, N, bias, act) -> str:
     """Instantiation tvl_conv3x3_h2 launches (CONV = true as the last template argument)."""
     tile = conv_h2_tile(M, N)
-    epi = -1 if (bias or act) else 160
+    epi = 673 if (bias and act == ACT_RELU) else (160 if not (bias or act) else -1)
     return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2, false, true>"
 
 
