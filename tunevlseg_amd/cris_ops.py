@@ -270,6 +270,44 @@ def self_attn_block(xq, xv, fqk: FrozenLinear, fv: FrozenLinear, fo: FrozenLinea
     return flinear_g(SelfAttnQKFn.apply(qk, v, B, T, H, dh), fo)
 
 
+class FFNBlockFn(Fn):
+    """``x + W4 LN_f(relu(W0 LN_3(x) + b0)) + b4`` -- the decoder layer's feed-forward sub-block (reference layers.py:296-300,351-355, eval-mode
+    dropout) with both LayerNorms writing the next GEMM's two-piece operand image directly (csrc/layernorm.hip) and the residual added in the
+    second GEMM's epilogue: neither normalised tensor exists in fp32.  Backward: plain fp32 LayerNorm gradients, the ReLU gate applied while
+    the [M, 2048] gradient is packed."""
+
+    @staticmethod
+    def takes(M: int, D: int, F_: int, f0: FrozenLinear, f4: FrozenLinear) -> bool:
+        return bool(hip.GEMM_MODE == "bf16x6" and hip.GEMM_H2 and FFN_H2 and M >= 2048 and D % 32 == 0 and F_ % 32 == 0 and max(D, F_) <= 2048
+                    and getattr(f0.W, "_tvl_frozen", False) and getattr(f4.W, "_tvl_frozen", False))
+
+    @staticmethod
+    def forward(ctx, x, g3, b3, f0: FrozenLinear, gf, bf, f4: FrozenLinear, eps):
+        shape = x.shape
+        x2d = _c(x).view(-1, shape[-1])
+        xh, mean3, rstd3 = hip.layernorm_fwd_h2(x2d, g3, b3, eps)
+        h, _ = hip.gemm_h2(xh, hip.weight_h2_cached(f0.W), bias=f0.b, act=hip.ACT_RELU)
+        hh, meanf, rstdf = hip.layernorm_fwd_h2(h, gf, bf, eps)
+        out, _ = hip.gemm_h2(hh, hip.weight_h2_cached(f4.W), bias=f4.b, residual=x2d)
+        ctx.save_for_backward(x2d, g3, mean3, rstd3, h, gf, meanf, rstdf)
+        ctx.mods, ctx.shape = (f0, f4), shape
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x2d, g3, mean3, rstd3, h, gf, meanf, rstdf = ctx.saved_tensors
+        f0, f4 = ctx.mods
+        d2d = _c(d_out).view(x2d.shape)
+        dn = hip.linear_dgrad(d2d, f4.W, Wt=f4.Wt)                         # d LN_f output  [M, F]
+        dh = hip.layernorm_bwd(dn, h, gf, meanf, rstdf)                    # d relu output
+        dx3 = hip.linear_dgrad(dh, f0.W, Wt=f0.Wt, relu_mask=h)            # gate by (h > 0) while packing; d LN_3 output  [M, D]
+        dx = hip.layernorm_bwd(dx3, x2d, g3, mean3, rstd3, dres=d2d)       # + the residual branch
+        return dx.view(ctx.shape), None, None, None, None, None, None, None
+
+
+FFN_H2 = __import__("os").environ.get("TVL_CRIS_FFN_H2", "1") != "0"   # A/B switch of the fused decoder feed-forward block
+
+
 class CrossAttnFn(Fn):
     """T visual queries x Tk word keys with a key-padding mask (layers.py:341-349)."""
 

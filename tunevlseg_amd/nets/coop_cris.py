@@ -223,9 +223,12 @@ class COOPCRIS(nn.Module):
             vv = C.flinear_g(words, lw["ca_v"]).view(B * L, D)
             o = C.flinear_g(C.CrossAttnFn.apply(q, k, vv, key_mask, B, T, L, heads, dh), lw["ca_o"]).view(B, T, D)
             vis = ops.add(vis, ops.layer_norm(o, *lw["cross_attn_norm"], LN_EPS))
-            v2 = ops.layer_norm(vis, *lw["norm3"], LN_EPS)
-            v2 = ops.layer_norm(C.flinear_g(v2, lw["ffn0"], RELU), *lw["ffn_norm"], LN_EPS)
-            vis = ops.add(vis, C.flinear_g(v2, lw["ffn4"]))
+            if C.FFNBlockFn.takes(B * T, D, lw["ffn0"].W.shape[0], lw["ffn0"], lw["ffn4"]):
+                vis = C.FFNBlockFn.apply(vis, *lw["norm3"], lw["ffn0"], *lw["ffn_norm"], lw["ffn4"], LN_EPS)
+            else:
+                v2 = ops.layer_norm(vis, *lw["norm3"], LN_EPS)
+                v2 = ops.layer_norm(C.flinear_g(v2, lw["ffn0"], RELU), *lw["ffn_norm"], LN_EPS)
+                vis = ops.add(vis, C.flinear_g(v2, lw["ffn4"]))
         return ops.layer_norm(vis, *prep["decoder_norm"], LN_EPS).view(B * T, D)
 
     # ------------------------------------------------------------------ projector (layers.py:96-119)
