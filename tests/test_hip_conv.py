@@ -282,3 +282,50 @@ def test_conv3x3_two_piece_full_size_properties(hip):
     # (the scale of xs is that of sample 5 alone, which may differ from the full map's: compare to rounding, not to the bit)
     ref5 = y.view(B, H * W, Cout)[5]
     assert (ys[5] - ref5).abs().max().item() <= 2e-6 * ref5.abs().max().item()
+
+
+def _frozen_linear(hip, n, k, seed, bias=True):
+    from tunevlseg_amd.cris_ops import FrozenLinear
+
+    w = dev(rnd(n, k, seed=seed) * k ** -0.5)
+    return FrozenLinear(hip.mark_frozen(w), dev(rnd(n, seed=seed + 1) * 0.1) if bias else None, hip.mark_frozen(w.t().contiguous()))
+
+
+def test_cris_decoder_blocks_on_two_pieces_match_the_unfused_path(hip):
+    """SelfAttnBlockFn / FFNBlockFn (QK | V projections -> one packed image -> attention -> out-projection; LayerNorm -> GEMM -> ReLU ->
+    LayerNorm -> GEMM + residual, all operands as two fp16 pieces) against the op-by-op path on fp32 tensors: outputs and input gradients."""
+    from tunevlseg_amd import cris_ops as CO
+    from tunevlseg_amd import ops
+
+    B, T, H, dh, F_ = 4, 676, 8, 64, 2048
+    D = H * dh
+    fqk, fv, fo = _frozen_linear(hip, 2 * D, D, 61), _frozen_linear(hip, D, D, 63), _frozen_linear(hip, D, D, 65)
+    assert CO.SelfAttnBlockFn.takes(B * T, dh, fqk, fv, fo)
+    xq0, xv0, dy = dev(rnd(B, T, D, seed=67)), dev(rnd(B, T, D, seed=68)), dev(rnd(B * T, D, seed=69))
+    res = {}
+    for fused in (True, False):
+        CO.SELF_ATTN_H2 = fused
+        try:
+            xq, xv = xq0.clone().requires_grad_(True), xv0.clone().requires_grad_(True)
+            out = CO.self_attn_block(xq, xv, fqk, fv, fo, B, T, H, dh)
+            out.backward(dy)
+            res[fused] = (out.detach(), xq.grad, xv.grad)
+        finally:
+            CO.SELF_ATTN_H2 = True
+    for a, b, what in zip(res[True], res[False], ("out", "d xq", "d xv")):
+        close(a.reshape(b.shape), b, 2e-5, f"self-attention block {what}")
+
+    f0, f4 = _frozen_linear(hip, F_, D, 71), _frozen_linear(hip, D, F_, 73)
+    g3, b3, gf, bf = dev(1 + 0.1 * rnd(D, seed=75)), dev(0.1 * rnd(D, seed=76)), dev(1 + 0.1 * rnd(F_, seed=77)), dev(0.1 * rnd(F_, seed=78))
+    assert CO.FFNBlockFn.takes(B * T, D, F_, f0, f4)
+    x0, dy3 = dev(rnd(B, T, D, seed=79)), dev(rnd(B, T, D, seed=80))
+    x = x0.clone().requires_grad_(True)
+    y = CO.FFNBlockFn.apply(x, g3, b3, f0, gf, bf, f4, 1e-5)
+    y.backward(dy3)
+    xr = x0.clone().requires_grad_(True)
+    v2 = ops.layer_norm(xr, g3, b3, 1e-5)
+    v2 = ops.layer_norm(CO.flinear_g(v2, f0, hip.ACT_RELU), gf, bf, 1e-5)
+    yr = ops.add(xr, CO.flinear_g(v2, f4))
+    yr.backward(dy3)
+    close(y, yr, 2e-5, "ffn block out")
+    close(x.grad, xr.grad, 2e-5, "ffn block d x")
