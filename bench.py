@@ -120,7 +120,29 @@ def build_module(device, num_context: int = 10, prompt_depth: int = 1, seed: int
     return module, opt
 
 
-def cpu_baseline(steps32: int = 2, steps4: int = 3) -> dict:
+PEAK_HBM_TBS = 8.0   # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+
+
+def rocprof_avg_us(workload: str, kernel: str):
+    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of the same command (profiles/), or None."""
+    import csv
+
+    f = ROOT / "profiles" / {"cris": "r3_cris_kernel_stats.csv", "maple": "r3_maple_kernel_stats.csv", "vit640": "r3_vit640_kernel_stats.csv"}.get(workload, "r3_kernel_stats.csv")
+    if not f.exists():
+        return None, None
+    want = kernel.replace(" ", "")
+    with open(f, newline="") as fh:
+        for row in csv.DictReader(fh):
+            name = (row.get("Name") or row.get("KernelName") or "").replace(" ", "")
+            if want in name:
+                try:
+                    return round(float(row.get("AverageNs") or row.get("Average") or 0.0) / 1e3, 1), str(f.relative_to(ROOT))
+                except ValueError:
+                    return None, None
+    return None, None
+
+
+def cpu_baseline(steps32: int = 2, steps4: int = 10) -> dict:
     """The reference's trainer=cpu path on the host cores of this box: the CPU oracle -- a port pinned by the
     golden fixtures; the reference's own Python cannot travel -- runs the identical train step (forward, DiceCE, backward, AdamW),
     fp32, ``set_float32_matmul_precision("medium")`` (reference src/models/__init__.py:6), all host threads.
@@ -159,7 +181,7 @@ def cpu_baseline(steps32: int = 2, steps4: int = 3) -> dict:
         O.dice_ce_loss(logits, b32["mask"]).backward()
         vopt.step()
 
-    t32 = timed(vpt_step, 0, steps32)  # ~40-80 s per step on the host cores: no separate warm-up, every step reported
+    t32 = timed(vpt_step, 1, steps32)  # ~27 s per step on the host cores: 1 warm-up, every timed step reported
     # C1: CoOp-4 (4 context tokens, depth 1), bs 4, seed 0
     cctx = (torch.randn(1, 4, 512, generator=torch.Generator().manual_seed(0)) * 0.02).requires_grad_(True)
     copt = torch.optim.AdamW([cctx], lr=2e-4)
@@ -171,14 +193,14 @@ def cpu_baseline(steps32: int = 2, steps4: int = 3) -> dict:
         O.dice_ce_loss(logits, b4["mask"]).backward()
         copt.step()
 
-    t4 = timed(coop_step, 1, steps4)
+    t4 = timed(coop_step, 3, steps4)   # 3 warm-up + 10 timed steps, median
     torch.set_float32_matmul_precision("highest")
     return {"value": round(32 / median(t32), 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"median of {steps32} train steps (no warm-up; each step's seconds listed) of the headline workload's own shape -- VPT-10 shallow, 352x352, bs 32 -- "
+            "sample": f"median of {steps32} train steps (1 warm-up; each timed step's seconds listed) of the headline workload's own shape -- VPT-10 shallow, 352x352, bs 32 -- "
                       "on the fp32 torch CPU oracle",
             "step_seconds_bs32": [round(t, 2) for t in t32],
             "c1_coop4_bs4": {"value": round(4 / median(t4), 3), "unit": "images/s",
-                             "sample": f"median of {steps4} train steps (1 warm-up), CLIPSeg + CoOp-4, 352x352, bs 4 (BASELINE configs[0])"}}
+                             "sample": f"median of {steps4} train steps (3 warm-up), CLIPSeg + CoOp-4, 352x352, bs 4 (BASELINE configs[0])"}}
 
 
 def main():
@@ -192,10 +214,11 @@ def main():
                     help="vpt only: keep the frozen text tower's conditional embeddings per distinct token row (skips work: NOT the headline number; "
                          "the line is marked cond_cache=true)")
     ap.add_argument("--cpu-steps32", type=int, default=2, help="timed CPU-oracle steps at the headline shape (bs 32)")
-    ap.add_argument("--cpu-steps4", type=int, default=3, help="timed CPU-oracle steps of config C1 (CoOp-4, bs 4)")
-    ap.add_argument("--workload", choices=("vpt", "cris", "maple"), default="vpt",
+    ap.add_argument("--cpu-steps4", type=int, default=10, help="timed CPU-oracle steps of config C1 (CoOp-4, bs 4)")
+    ap.add_argument("--workload", choices=("vpt", "cris", "maple", "vit640"), default="vpt",
                     help="vpt = BASELINE configs[1] (the headline line); cris = configs[2] (CRIS + CoCoOp, 416x416) and maple = configs[3] "
-                         "(MaPLe depth 9) are reported for DESIGN.md")
+                         "(MaPLe depth 9) are reported for DESIGN.md; vit640 = the ViT-B/16 encoder leg of configs[4] (640x640, bs 16: "
+                         "forward + data gradient of the 12 layers; the DenseCLIP FPN / context decoder / head are not built)")
     args = ap.parse_args()
 
     from tunevlseg_amd import dist as tdist
@@ -210,17 +233,45 @@ def main():
     device = torch.device("cuda", local_rank)
     hip.load()
 
-    cris, maple = args.workload == "cris", args.workload == "maple"
-    module, opt = build_cris_module(device) if cris else (build_maple_module(device) if maple else build_module(device, cond_cache=args.cond_cache))
-    batch = make_batch(args.batch, 416 if cris else 352, 100 + rank, device, pad_id=0 if cris else 1)
-    gflop_per_image = 212.8 if cris else (167.8 if maple else GFLOP_PER_IMAGE_TRAIN)  # SURVEY.md §8d (FlopCounterMode on the reference)
+    cris, maple, vit640 = args.workload == "cris", args.workload == "maple", args.workload == "vit640"
+    if vit640:
+        # configs[4]'s encoder leg (reference src/models/components/denseclip/models.py:530-714: 12 ResidualAttentionBlocks of width 768 over
+        # 1 + 40^2 tokens): forward + data gradient through the frozen layers -- what a prompt-tuned DenseCLIP step would spend in the tower
+        from tunevlseg_amd import ops
+        from tunevlseg_amd.backbone import CLIPSegBackbone
 
-    def step():
-        opt.zero_grad()
-        loss = module.training_step(batch, 0)
-        loss.backward()
-        opt.step()
-        return loss
+        if "--batch" not in sys.argv:
+            args.batch = 16
+        T640, D640 = 1 + (640 // 16) ** 2, 768
+        layers = CLIPSegBackbone.from_spec("random:rd64:seed=0").to(device).prepared()["vision_layers"]
+        spec = ops.AttnSpec(heads=12, act=hip.ACT_QUICK_GELU, eps=1e-5)
+        g = torch.Generator().manual_seed(100 + rank)
+        x640 = torch.randn(args.batch, T640, D640, generator=g).to(device).requires_grad_(True)
+        w640 = (torch.randn(args.batch, T640, D640, generator=g) * 1e-3).to(device)
+        per_layer_fwd = 24.0 * T640 * D640 * D640 + 4.0 * T640 * T640 * D640          # 8 T D^2 of QKV/out-proj + 16 T D^2 of the MLP, QK^T + PV
+        per_layer_bwd = 24.0 * T640 * D640 * D640 + 10.0 * T640 * T640 * D640         # data gradients only; attention backward = 5 products
+        gflop_per_image = len(layers) * (per_layer_fwd + per_layer_bwd) / 1e9
+        module = opt = batch = None
+
+        def step():
+            x640.grad = None
+            y = x640
+            for lw in layers:
+                y = ops.encoder_layer(y, lw, spec)
+            loss = (y * w640).sum()
+            loss.backward()
+            return loss
+    else:
+        module, opt = build_cris_module(device) if cris else (build_maple_module(device) if maple else build_module(device, cond_cache=args.cond_cache))
+        batch = make_batch(args.batch, 416 if cris else 352, 100 + rank, device, pad_id=0 if cris else 1)
+        gflop_per_image = 212.8 if cris else (167.8 if maple else GFLOP_PER_IMAGE_TRAIN)  # SURVEY.md §8d (FlopCounterMode on the reference)
+
+        def step():
+            opt.zero_grad()
+            loss = module.training_step(batch, 0)
+            loss.backward()
+            opt.step()
+            return loss
 
     def barrier():
         if world > 1:
@@ -240,7 +291,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    metrics = module.epoch_metrics("train")
+    metrics = module.epoch_metrics("train") if module is not None else None
 
     # ---- roofline of the dominant kernel: HIP events (on torch's current stream = the launch stream) around every GEMM launch of
     # 2 extra, untimed steps.  achieved = algorithmic FLOPs (2*M*N*K per launch) / summed launch time.
@@ -263,7 +314,8 @@ def main():
         # doubled per the gfx950 note of MI355X_MICROARCH.md §HBM) and committed under profiles/.  It is a RECORDED number: reported
         # only when the record names the same kernel instantiation, and always with the file and commit it came from.
         traffic, traffic_source = None, None
-        tf = ROOT / "profiles" / {"cris": "r2_cris_hbm_traffic.json", "maple": "r2_maple_hbm_traffic.json"}.get(args.workload, "r2_hbm_traffic.json")
+        stem = {"cris": "cris_hbm_traffic.json", "maple": "maple_hbm_traffic.json"}.get(args.workload, "hbm_traffic.json")
+        tf = next((f for f in (ROOT / "profiles" / f"r3_{stem}", ROOT / "profiles" / f"r2_{stem}") if f.exists()), ROOT / "profiles" / f"r3_{stem}")
         if tf.exists():
             rec_all = json.loads(tf.read_text())
             rec = rec_all.get("kernels", rec_all).get(name.replace(", ", ","))
@@ -276,22 +328,39 @@ def main():
                                   "algorithmic fp32 FLOP/s ceiling = dense bf16 MFMA peak (2.5 PFLOP/s) / 6 MFMAs per fp32 product") if split
                     else "dense f32-input MFMA peak",
                     "launches_per_step": d["launches"] // 2, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1),
-                    "event_pair_overhead_us": round(1e3 * hip.last_empty_pair_ms, 1),   # an empty event pair's reading, already taken off every launch
+                    # the uncorrected event reading, the empty pair's reading that `avg_launch_us` has taken off, and the same kernel's
+                    # average in the committed rocprofv3 --kernel-trace --stats summary (profiles/): the three should agree
+                    "avg_launch_us_raw_events": round(1e3 * d["raw_ms"] / d["launches"], 1),
+                    "event_pair_overhead_us": round(1e3 * hip.last_empty_pair_ms, 1),
+                    "rocprof_avg_launch_us": rocprof_avg_us(args.workload, name)[0], "rocprof_source": rocprof_avg_us(args.workload, name)[1],
                     "flops_per_launch": round(d["flops"] / d["launches"]), "all_gemm_ms_per_step": round(gemm_ms, 2),
                     # every GEMM instantiation of the step (one instantiation serves several shapes: the average mixes them)
                     "gemm_kernels": [{"kernel": k.replace("gemm_bf16s_kernel", "bf16s").replace("gemm_f32_kernel", "f32").replace("gemm_tp3_kernel", "tp3"),
                                       "ms_per_step": round(v["ms"] / 2, 2), "launches_per_step": v["launches"] // 2,
                                       "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                      for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:5]],
-                    "all_gemm_tflops": round(sum(v["flops"] for v in prof.values()) / 2 / (gemm_ms * 1e-3) / 1e12, 2)}
+                    "all_gemm_tflops": round(sum(v["flops"] for v in prof.values()) / 2 / (gemm_ms * 1e-3) / 1e12, 2),
+                    # the non-GEMM kernels of a vision layer, each against its own roofline: attention on the same MFMA ceiling (its
+                    # products are 3 MFMAs on two fp16 pieces), LayerNorm on HBM (algorithmic bytes)
+                    "other_kernels": [
+                        ({"kernel": k, "bound": "mfma", "ms_per_step": round(v["ms"] / 2, 3), "launches_per_step": v["launches"] // 2,
+                          "avg_us": round(1e3 * v["ms"] / v["launches"], 1), "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
+                          "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4),
+                          "hbm_GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if v["flops"] else
+                         {"kernel": k, "bound": "hbm", "ms_per_step": round(v["ms"] / 2, 3), "launches_per_step": v["launches"] // 2,
+                          "avg_us": round(1e3 * v["ms"] / v["launches"], 1), "achieved": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "unit": "GB/s",
+                          "peak": PEAK_HBM_TBS * 1e3, "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)})
+                        for k, v in sorted(hip.last_aux_profile.items(), key=lambda kv: -kv[1]["ms"])]}
 
+    step_ceiling = PEAK_BF16_MFMA_TFLOPS / 3 if (hip.GEMM_MODE == "bf16x6" and hip.GEMM_H2) else MODE_PEAK[hip.GEMM_MODE]
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = world * args.batch * args.steps / elapsed
         out = {
             "metric": ("images/sec, train step (fwd + DiceCE + bwd + AdamW on prompts), " +
                        ("CRIS (CLIP-RN50) + CoCoOp, 416x416" if cris else "CLIPSeg ViT-B/16 + MaPLe depth 9, 352x352" if maple
-                        else "CLIPSeg ViT-B/16 + VPT-10 shallow, 352x352")),
+                        else "CLIPSeg ViT-B/16 + VPT-10 shallow, 352x352")) if not vit640 else
+                      "images/sec, forward + data gradient of the 12 ViT-B/16 encoder layers at 640x640 (the encoder leg of DenseCLIP ViT-B FPN; no head, no optimizer)",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": (("f32 (fp32-equivalent: operands split into 2 fp16 pieces with exact power-of-two scales [3x3 convs with C_in % 32 == 0 and C_out >= 128, "
@@ -303,19 +372,22 @@ def main():
             "data": "synthetic", "per_gpu": round(value / world, 2),
             "config": {"workload": ("CRIS (CLIP-RN50 + cross-attn decoder) + CoCoOp meta-net, 416x416, bs=32/GPU (BASELINE configs[2])" if cris else
                                     "CLIPSeg ViT-B/16 + MaPLe (coupled V+L prompts, depth=9), 352x352, bs=32/GPU (BASELINE configs[3])" if maple else
+                                    "ViT-B/16 encoder leg of DenseCLIP ViT-B FPN 640x640, bs=16/GPU (BASELINE configs[4]: encoder layers only, parity unpinned)" if vit640 else
                                     "CLIPSeg ViT-B/16 + VPT-shallow (10 visual prompts), 352x352, bs=32/GPU (BASELINE configs[1])"),
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
                        "weights": "seeded random init (RN50 CRIS geometry)" if cris else "seeded random init (rd64 geometry)",
                        "use_new_last_layer": cris or maple},
             "step_tflops": round(value * gflop_per_image / 1e3, 2),
-            "step_frac_of_ceiling": round(value / world * gflop_per_image / 1e3 / MODE_PEAK[hip.GEMM_MODE], 4),
-            "loss": round(float(loss.item()), 6), "train_dice": round(metrics["train_dice"], 6), "train_iou": round(metrics["train_iou"], 6),
+            # whole-step algorithmic TFLOP/s per GPU against the ceiling of the arithmetic the step's FLOPs actually run on: two fp16
+            # pieces (3 MFMAs per fp32 product, 833 TFLOP/s) for the layer GEMMs, the attention and the large convs when GEMM_H2 is on
+            "step_frac_of_ceiling": round(value / world * gflop_per_image / 1e3 / step_ceiling, 4), "step_ceiling_tflops": round(step_ceiling, 1),
+            "loss": round(float(loss.item()), 6), "train_dice": round(metrics["train_dice"], 6) if metrics else None, "train_iou": round(metrics["train_iou"], 6) if metrics else None,
             "roofline": roofline,
         }
         if args.cond_cache and not cris and not maple:
             out["cond_cache"] = True
             out["config"]["workload"] += " -- WITH the conditional-embedding cache (text tower skipped after the first step: not the headline)"
-        if not args.no_cpu_baseline and world == 1 and not cris and not maple:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "vpt":
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps32, args.cpu_steps4)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -26,6 +26,10 @@ extern "C" {
 
 typedef void* tvlStream_t; /* hipStream_t */
 
+/* Bumped on every incompatible change of a signature or struct below.  3: tvl_dicece_stats gained `work`, tvl_split_planes /
+ * tvl_gemm_planes removed (round 2).  The Python binding refuses a library whose tvl_abi_version() differs. */
+#define TVL_ABI_VERSION 3
+
 const char* tvl_last_error(void);
 int tvl_abi_version(void);
 

@@ -160,7 +160,7 @@ def compact_outputs(logits, mask):
 
 
 def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, learner_kw: dict, net_kw: dict,
-             B: int, H: int, L: int, iseed: int, M, compact: bool = False, with_f64: bool = False):
+             B: int, H: int, L: int, iseed: int, M, compact: bool = False, with_f64: bool = False, tails: int = 0):
     from src.models.components.hf_clipseg_wrapper import HFCLIPSegWrapper
     from src.models.core_models import coop as R
     from src.models.core_models.coop import context_learner as CL
@@ -169,7 +169,7 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
     from oracle.clipseg_oracle import dice_ce_loss
 
     cfg = CLIPSegConfig.tiny(eos_token_id=eos) if preset == "tiny" else CLIPSegConfig.rd64(eos_token_id=eos)
-    sd = init_clipseg_state_dict(cfg, wseed)
+    sd = init_clipseg_state_dict(cfg, wseed, tails=tails)
     HFCLIPSegWrapper.get_pretrained_model = staticmethod(lambda *a, **k: hf_model_from_state(cfg, sd))
 
     if ONLY and not any(name.startswith(o) for o in ONLY):
@@ -241,9 +241,11 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
         for k, p_ in net64.named_parameters():
             if p_.requires_grad and p_.grad is not None:
                 arrays["grad64." + k] = p_.grad.float().numpy()
+        if tails:
+            arrays["out.logits64"] = logits64.detach().float().numpy()
         print(f"   f64: logits fp32-vs-fp64 {float((logits.detach().double() - logits64.detach()).abs().max()):.2e}; worst fp32 gradient "
               f"deviation {max(float((params[k].grad.double() - p_.grad).abs().max() / p_.grad.abs().max()) for k, p_ in net64.named_parameters() if p_.requires_grad and p_.grad is not None):.2e}")
-    meta = {"name": name, "compact": compact, "preset": preset, "eos_token_id": eos, "weight_seed": wseed, "net": net_kind,
+    meta = {"name": name, "compact": compact, "preset": preset, "eos_token_id": eos, "weight_seed": wseed, "tails": tails, "net": net_kind,
             "learner_kw": {k: v for k, v in learner_kw.items()}, "net_kw": net_kw, "B": B, "H": H, "L": L,
             "input_seed": iseed, "weights_checksum": state_checksum(sd), "grads_none": grads_none,
             "torch": torch.__version__}
@@ -427,6 +429,26 @@ def main():
     # every 11th logit.  This is the case whose M = 15 840 rows select the large GEMM tiles of the benchmarked step.
     FB = dict(preset="rd64", B=32, H=352, L=8, M=M, compact=True)
     run_case("rd64_vpt_n10_d1_b32", eos=2, wseed=21, net_kind="vpt", iseed=1,
+             learner_kw=dict(prompt_depth=1, num_context=10, vector_std=0.02), net_kw=base_old, **FB)
+
+    # --- BASELINE configs[3], the per-GPU step of the 8-GPU config: MaPLe depth 9, 4 context tokens, new last layer, B = 32 (compact)
+    run_case("rd64_maple_n4_d9_newlast_b32", eos=2, wseed=21, net_kind="maple", iseed=100,
+             learner_kw=dict(prompt_depth=9, num_context=4, vector_std=0.02, use_unified_projection=False,
+                             intermediate_dim=64, use_proj_norm=True, use_lora_proj=False), net_kw=base_new, **FB)
+    # --- heavy-tailed stress fixtures (weights.heavy_tails: outlier LayerNorm gains, out_proj / fc2 rows, q / k bias outliers),
+    # run through the same reference classes: the regime of trained checkpoints that loosens the scale bounds of the two-piece
+    # fp16 operand format.  The B = 1 ones also carry the float64 run (the reference's own fp32 noise grows with the tails);
+    # level 2 (`*_tails2`) is the regime where the reference's fp32 run is itself 0.14 away from float64 in the logits.
+    run_case("tiny_vpt_n4_d2_tails", eos=2, wseed=11, net_kind="vpt", iseed=16, tails=1,
+             learner_kw=dict(prompt_depth=2, num_context=4, vector_std=0.02), net_kw=base_old, with_f64=True, **T)
+    run_case("rd64_vpt_n10_d1_tails", eos=2, wseed=21, net_kind="vpt", iseed=27, tails=1,
+             learner_kw=dict(prompt_depth=1, num_context=10, vector_std=0.02), net_kw=base_old, with_f64=True, **F_)
+    run_case("rd64_maple_n4_d9_newlast_tails", eos=2, wseed=21, net_kind="maple", iseed=28, tails=1,
+             learner_kw=dict(prompt_depth=9, num_context=4, vector_std=0.02, use_unified_projection=False,
+                             intermediate_dim=64, use_proj_norm=True, use_lora_proj=False), net_kw=base_new, with_f64=True, **F_)
+    run_case("rd64_vpt_n10_d1_tails2", eos=2, wseed=21, net_kind="vpt", iseed=27, tails=2,
+             learner_kw=dict(prompt_depth=1, num_context=10, vector_std=0.02), net_kw=base_old, with_f64=True, **F_)
+    run_case("rd64_vpt_n10_d1_b32_tails", eos=2, wseed=21, net_kind="vpt", iseed=3, tails=1,
              learner_kw=dict(prompt_depth=1, num_context=10, vector_std=0.02), net_kw=base_old, **FB)
 
     # --- CRIS (BASELINE configs[2]; reference coop_cris.py) ---------------------------------------------------------

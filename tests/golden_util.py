@@ -32,7 +32,7 @@ def config_of(fx) -> CLIPSegConfig:
 
 
 def state_of(fx) -> dict[str, torch.Tensor]:
-    sd = init_clipseg_state_dict(config_of(fx), fx["meta"]["weight_seed"])
+    sd = init_clipseg_state_dict(config_of(fx), fx["meta"]["weight_seed"], tails=fx["meta"].get("tails", 0))
     chk = float(sum(v.double().abs().sum() for v in sd.values()))
     assert abs(chk - fx["meta"]["weights_checksum"]) <= 1e-6 * abs(chk), "seeded weight draw drifted from the fixture"
     return sd

@@ -44,7 +44,7 @@ def build_net(fx, device="cuda"):
                "shared_separate": nets.SharedSeparateCLIPSeg, "shared_attn": nets.SharedAttnCLIPSeg}[kind]
     learner_cls = {"vpt": CL.VPTContextLearner, "coop": CL.CoOpContextLearner, "cocoop": CL.CoCoOpContextLearner,
                    "maple": CL.MapleContextLearner, "shared_separate": CL.SharedSeparateLearner, "shared_attn": CL.SharedAttnLearner}[kind]
-    spec = f"random:{m['preset']}:seed={m['weight_seed']}:eos={m['eos_token_id']}"
+    spec = f"random:{m['preset']}:seed={m['weight_seed']}:eos={m['eos_token_id']}:tails={m.get('tails', 0)}"
     net = net_cls(context_learner=partial(learner_cls, **lkw),
                   model_cfg={"pretrained_model_name_or_path": spec, "freeze_encoder": False, "freeze_decoder": False}, **m["net_kw"])
     params = trainable_of(fx, requires_grad=False)
@@ -133,12 +133,15 @@ def test_hip_net_matches_reference_tiny(name):
     run_case(name)
 
 
-@pytest.mark.parametrize("name", [n for n in golden_names("rd64_") if not n.endswith("_b32")])
+FULL_B1 = [n for n in golden_names("rd64_") if "_b32" not in n and not n.endswith("_tails2")]
+
+
+@pytest.mark.parametrize("name", FULL_B1)
 def test_hip_net_matches_reference_full_size(name):
     run_case(name)
 
 
-@pytest.mark.parametrize("name", [n for n in golden_names("rd64_") if not n.endswith("_b32")])
+@pytest.mark.parametrize("name", FULL_B1)
 def test_hip_net_matches_reference_full_size_tp3(name, monkeypatch):
     """The same B = 1 fixtures forced onto the tp3 kernels (LDS-DMA GEMM ring, tp3-writing LayerNorm / attention) that the
     benchmarked batch size selects by itself."""
@@ -198,6 +201,51 @@ def test_hip_net_matches_reference_headline_batch():
     prof = run_compact_case("rd64_vpt_n10_d1_b32")
     big = [k for k in prof if k.startswith("gemm_tp3_kernel<192") or "gemm_bf16s_kernel<192" in k]
     assert big, sorted(prof)
+
+
+def test_hip_net_matches_reference_maple_per_gpu_batch():
+    """BASELINE configs[3]'s per-GPU step (MaPLe depth 9, 4 context tokens, new last layer, B = 32): both towers train, the deep-prompt
+    overwrites and the coupling MLPs run at the batch the 8-GPU config gives every rank."""
+    prof = run_compact_case("rd64_maple_n4_d9_newlast_b32")
+    assert any(k.startswith("gemm_tp3_kernel<") and ", 2, " in k for k in prof), sorted(prof)
+
+
+def test_hip_net_matches_reference_headline_batch_heavy_tails():
+    """The headline batch with the outlier-channel weight preset (weights.heavy_tails level 1): the h2 operand images' scale bounds
+    (Cauchy-Schwarz row bounds, one scale per tensor for QKV / dO) under rows that span decades."""
+    run_compact_case("rd64_vpt_n10_d1_b32_tails")
+
+
+@pytest.mark.parametrize("force_tp3", [False, True])
+def test_hip_net_in_the_chaotic_tail_regime_is_no_further_from_float64_than_the_reference(force_tp3, monkeypatch):
+    """weights.heavy_tails level 2 (LayerNorm gains 30-100, out_proj / fc2 rows x20, q / k bias +-8): attention saturates and the
+    REFERENCE's own fp32 logits are 0.14 away from its float64 logits, so "within 1e-3 of the reference" has no meaning here.  The
+    fixture carries the float64 run of the reference classes; the HIP path must be no further from it than a small multiple of the
+    reference's own fp32 deviation -- a format whose scale bounds broke under the outliers would be orders of magnitude off."""
+    from tunevlseg_amd import hip, ops
+
+    if force_tp3:
+        monkeypatch.setattr(hip, "TP3_MIN_ROWS", 1)
+    fx = load_golden("rd64_vpt_n10_d1_tails2")
+    net = build_net(fx)
+    pix, ids, am, mask = (t.cuda() for t in inputs_of(fx))
+    logits = net(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix)
+    l64, l32 = torch.from_numpy(fx["out.logits64"]), torch.from_numpy(fx["out.logits"])
+    ref_dev = (l32 - l64).abs().max().item()
+    own_dev = (logits.detach().cpu() - l64).abs().max().item()
+    loss, _ = ops.DiceCELossFn.apply(logits, mask, 1.0, 0.2, 0.5)
+    loss.backward()
+    k = "context_learner.context_vectors"
+    g64, g32 = torch.from_numpy(fx["grad64." + k]).double(), torch.from_numpy(fx["grad." + k]).double()
+    g = dict(net.named_parameters())[k].grad.cpu().double()
+    ref_g = ((g32 - g64).norm() / g64.norm()).item()
+    own_g = ((g - g64).norm() / g64.norm()).item()
+    print(f"PARITY(tails2, forced_tp3={force_tp3}) logits vs fp64: HIP {own_dev:.3e}, reference fp32 {ref_dev:.3e}; gradient rel-L2 vs fp64: HIP {own_g:.3e}, reference fp32 {ref_g:.3e}")
+    assert own_dev <= max(LOGIT_TOL, 3.0 * ref_dev)
+    assert own_g <= max(GRAD_RTOL, 3.0 * ref_g)
+    # labels: bit-equal to the float64 run wherever its logit is further from the threshold than the reference's own fp32 deviation
+    lab, lab64 = torch.sigmoid(logits.detach().cpu()) > 0.5, l64 > 0
+    assert ((lab != lab64) & (l64.abs() > 3.0 * ref_dev)).sum().item() == 0
 
 
 def test_vpt_conditional_embedding_cache_skips_the_text_tower_and_keeps_the_logits(monkeypatch):

@@ -25,6 +25,11 @@ echo "pmc FETCH_SIZE done"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline $EXTRA \
     > "$OUT/bench_under_pmc_write.json" 2> "$OUT/pmc_write.err"
 echo "pmc WRITE_SIZE done"
+# matrix-pipe occupancy and clock: SQ_VALU_MFMA_BUSY_CYCLES (cycles an MFMA is executing, per SIMD summed) and GRBM_GUI_ACTIVE (busy cycles
+# summed over the 8 XCDs: / 8 / kernel wall time = effective clock, MI355X_MICROARCH.md "DVFS give-back"); SQ_BUSY_CYCLES for the ratio
+timeout -k 10 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline $EXTRA \
+    > "$OUT/bench_under_pmc_mfma.json" 2> "$OUT/pmc_mfma.err" || echo "pmc MFMA pass failed (see pmc_mfma.err)"
+echo "pmc MFMA_BUSY done"
 # keep what travels back small: the per-dispatch CSVs are what the tools read
 find "$OUT" -name "*.csv" -size +20M -delete || true
 du -sh "$OUT"

@@ -42,11 +42,11 @@ class _Embedding(_Node):
 
 
 class CLIPSegBackbone(_Node):
-    def __init__(self, config: CLIPSegConfig, state_dict: Mapping[str, torch.Tensor] | None = None, seed: int = 0):
+    def __init__(self, config: CLIPSegConfig, state_dict: Mapping[str, torch.Tensor] | None = None, seed: int = 0, tails: int = 0):
         super().__init__()
         self.config = config
         self.extract_layers = tuple(config.extract_layers)
-        sd = state_dict if state_dict is not None else init_clipseg_state_dict(config, seed)
+        sd = state_dict if state_dict is not None else init_clipseg_state_dict(config, seed, tails=tails)
         for name, shape, _, _ in clipseg_param_specs(config):
             parts = name.split(".")
             node: nn.Module = self
@@ -75,18 +75,19 @@ class CLIPSegBackbone(_Node):
     # ------------------------------------------------------------------ construction helpers
     @classmethod
     def from_spec(cls, spec: Any) -> "CLIPSegBackbone":
-        """``spec``: a backbone, a mapping {preset|config, seed, eos_token_id}, ``"random:<preset>[:seed=N][:eos=N]"``,
+        """``spec``: a backbone, a mapping {preset|config, seed, eos_token_id}, ``"random:<preset>[:seed=N][:eos=N][:tails=1]"``
+        (``tails``: the outlier-channel preset of ``weights.heavy_tails``),
         or a local HF checkpoint directory (``CLIPSegForImageSegmentation.from_pretrained`` layout)."""
         if isinstance(spec, CLIPSegBackbone):
             return spec
         if isinstance(spec, Mapping):
             cfg = _config_from_mapping(spec)
-            return cls(cfg, spec.get("state_dict"), seed=int(spec.get("seed", 0)))
+            return cls(cfg, spec.get("state_dict"), seed=int(spec.get("seed", 0)), tails=int(spec.get("tails", 0)))
         if isinstance(spec, str) and spec.startswith("random:"):
             parts = spec.split(":")[1:]
             opts = dict(p.split("=") for p in parts[1:])
             cfg = _config_from_mapping({"preset": parts[0], "eos_token_id": int(opts.get("eos", 2))})
-            return cls(cfg, None, seed=int(opts.get("seed", 0)))
+            return cls(cfg, None, seed=int(opts.get("seed", 0)), tails=int(opts.get("tails", 0)))
         return cls._from_hf(spec)
 
     @classmethod

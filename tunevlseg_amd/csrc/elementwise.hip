@@ -14,7 +14,7 @@ void tvl_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* tvl_last_error(void) { return g_err; }
-extern "C" int tvl_abi_version(void) { return 2; }
+extern "C" int tvl_abi_version(void) { return TVL_ABI_VERSION; }
 
 namespace {
 

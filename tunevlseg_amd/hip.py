@@ -173,6 +173,7 @@ _SIGS = {
 EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_h2_bytes", "tvl_dicece_work_doubles", *_SIGS]
 
 _lib = None
+ABI_VERSION = 3   # include/tvl_hip.h TVL_ABI_VERSION
 
 
 def load():
@@ -188,6 +189,9 @@ def load():
     lib = C.CDLL(str(LIB_PATH))
     lib.tvl_last_error.restype = C.c_char_p
     lib.tvl_abi_version.restype = C.c_int
+    if lib.tvl_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has C-ABI version {lib.tvl_abi_version()}, this package binds version {ABI_VERSION}: rebuild it "
+                           f"(`make -C {LIB_PATH.parent}`)")
     lib.tvl_dynconv_bwd_work_floats.argtypes = [_I, _I, _I, _I]
     lib.tvl_dynconv_bwd_work_floats.restype = C.c_int64
     lib.tvl_dicece_work_doubles.argtypes = [_I, _L]
@@ -271,17 +275,40 @@ def set_gemm_mode(mode: str) -> None:
 
 
 _gemm_prof: list | None = None  # bench.py: (kernel key, flops, start event, stop event) per launch
+_aux_prof: list | None = None   # the same for the non-GEMM kernels of a vision layer: (key, flops, algorithmic bytes, e0, e1)
+
+
+class _aux_span:
+    """HIP-event bracket (torch's current stream = the launch stream) around one non-GEMM entry point while bench.py profiles."""
+
+    __slots__ = ("key", "flops", "nbytes", "e0")
+
+    def __init__(self, key: str, flops: float, nbytes: float):
+        self.key, self.flops, self.nbytes, self.e0 = key, flops, nbytes, None
+
+    def __enter__(self):
+        if _aux_prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.e0 is not None and _aux_prof is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _aux_prof.append((self.key, self.flops, self.nbytes, self.e0, e1))
+        return False
 
 
 def gemm_profile_start():
-    global _gemm_prof
-    _gemm_prof = []
+    global _gemm_prof, _aux_prof
+    _gemm_prof, _aux_prof = [], []
 
 
 def gemm_profile_stop() -> dict:
     """Per kernel instantiation: launches, algorithmic FLOPs (2*M*N*K) and summed device time (ms, HIP events)."""
-    global _gemm_prof
+    global _gemm_prof, _aux_prof, last_aux_profile
     rec, _gemm_prof = _gemm_prof or [], None
+    aux, _aux_prof = _aux_prof or [], None
     # what an event pair reads around a kernel that does (almost) nothing -- the markers' own cost, ~20-30 us on this stack, which would
     # otherwise be booked on every launch and turn a 27 us kernel into a 60 us one: median over 32 one-element fills, taken off each launch
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(32)] if rec else []
@@ -299,12 +326,23 @@ def gemm_profile_stop() -> dict:
         d["flops"] += flops
         t = e0.elapsed_time(e1)
         d["ms"] += max(t - empty, 0.25 * t)
+        d["raw_ms"] = d.get("raw_ms", 0.0) + t
+    last_aux_profile = {}
+    for key, flops, nbytes, e0, e1 in aux:
+        d = last_aux_profile.setdefault(key, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0, "raw_ms": 0.0})
+        t = e0.elapsed_time(e1)
+        d["launches"] += 1
+        d["flops"] += flops
+        d["bytes"] += nbytes
+        d["ms"] += max(t - empty, 0.25 * t)
+        d["raw_ms"] += t
     global last_empty_pair_ms
     last_empty_pair_ms = empty
     return out
 
 
 last_empty_pair_ms = 0.0
+last_aux_profile: dict = {}   # filled by gemm_profile_stop(): attention / LayerNorm spans of the profiled steps
 
 
 def _bf16s_tile(M: int, N: int, K: int) -> tuple[int, int, int]:
@@ -423,7 +461,14 @@ def mark_frozen(t: torch.Tensor) -> torch.Tensor:
 
 
 GEMM_TP3_TILE = int(os.environ.get("TVL_TP3_TILE", "0"))      # 0 = automatic; 128 / 192 / 256 rows per workgroup
-GEMM_TP3_VARIANT = int(os.environ.get("TVL_TP3_VARIANT", "0"))  # 0 = production; others: diagnostic builds (csrc/gemm_tp3.hip)
+# 0 = production.  Diagnostic variants (ablations with wrong results, stamps) exist only in a `make DIAG=1` library and are selected
+# by the tools through set_tp3_variant(); the training path never reads an environment variable for this.
+GEMM_TP3_VARIANT = 0
+
+
+def set_tp3_variant(v: int) -> None:
+    global GEMM_TP3_VARIANT
+    GEMM_TP3_VARIANT = int(v)
 
 
 def gemm_tp3(A: Tp3, B: Tp3, *, M: int | None = None, out: torch.Tensor | None = None, out_tp3: Tp3 | None = None, want_f32=True,
@@ -751,7 +796,8 @@ def layernorm_fwd_h2(x2d, gamma, beta, eps: float, want_stats=True):
     y.row_norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
     mean = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
-    _call("tvl_layernorm_fwd_h2", _p(x2d), _p(gamma), _p(beta), y.buf.data_ptr(), _p(y.inv_scale), _p(y.row_norm), _p(mean), _p(rstd), rows, cols, float(eps))
+    with _aux_span("ln_fwd_h2", 0.0, 8.0 * rows * cols):   # read x fp32, write the two fp16 pieces
+        _call("tvl_layernorm_fwd_h2", _p(x2d), _p(gamma), _p(beta), y.buf.data_ptr(), _p(y.inv_scale), _p(y.row_norm), _p(mean), _p(rstd), rows, cols, float(eps))
     return y, mean, rstd
 
 
@@ -761,8 +807,9 @@ def layernorm_bwd_h2(dy2d, x2d, gamma, mean, rstd, dres=None):
     dx = torch.empty_like(x2d)
     dxt = H2(rows, cols, x2d.device, per_row=True)
     dxt.row_norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
-    _call("tvl_layernorm_bwd_h2", _p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), dxt.buf.data_ptr(), _p(dxt.inv_scale),
-          _p(dxt.row_norm), rows, cols)
+    with _aux_span("ln_bwd_h2", 0.0, (20.0 if dres is not None else 16.0) * rows * cols):   # read dy, x [, dres]; write dx fp32 + image
+        _call("tvl_layernorm_bwd_h2", _p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), dxt.buf.data_ptr(), _p(dxt.inv_scale),
+              _p(dxt.row_norm), rows, cols)
     return dx, dxt
 
 
@@ -790,7 +837,7 @@ def tp3_path_ok(M: int, D: int, F: int, dh: int, causal: bool, key_mask) -> bool
     """Can an encoder layer run on the tp3 kernels (GEMM ring + LayerNorm / attention that write tp3)?  d_h = 64 without masks,
     widths that are multiples of 32, enough rows to fill the chip, fp32-equivalent arithmetic selected."""
     return (GEMM_MODE == "bf16x6" and os.environ.get("TVL_ATTN_MODE", "")[:1] != "f" and os.environ.get("TVL_TP3", "1") != "0"
-            and dh == 64 and not causal and key_mask is None and D % 32 == 0 and F % 32 == 0 and D >= 64 and M >= TP3_MIN_ROWS)
+            and dh == 64 and not causal and key_mask is None and D % 32 == 0 and F % 32 == 0 and 64 <= D <= 2048 and M >= TP3_MIN_ROWS)   # tvl_layernorm_*_tp3 / _h2: cols <= 2048
 
 
 # --------------------------------------------------------------------------------------
@@ -843,7 +890,8 @@ def attn_h2_fwd(qkv_h: H2, B: int, T: int, H: int, scale: float, want_lse=True, 
     else:
         o = Tp3(B * T, D, qkv_h.buf.device)
     lse = torch.empty((B, H, T), device=qkv_h.buf.device, dtype=torch.float32) if want_lse else None
-    _call("tvl_attn_h2_fwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o.buf.data_ptr(), 1 if o_as_h2 else 0, _p(lse), B, H, T, float(scale))
+    with _aux_span("attn_h2_fwd", 4.0 * B * H * T * T * 64, 4.0 * B * T * D * (3 + (1 if o_as_h2 else 1.5))):   # QKV image in, O image out
+        _call("tvl_attn_h2_fwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o.buf.data_ptr(), 1 if o_as_h2 else 0, _p(lse), B, H, T, float(scale))
     return o, lse
 
 
@@ -894,9 +942,12 @@ def attn_h2_bwd(qkv_h: H2, o_t, do_h: H2, lse, B: int, T: int, H: int, scale: fl
     g = H2K(B * T, 3 * D, dev) if out_h2 else Tp3(B * T, 3 * D, dev)
     delta = torch.empty((B, H, T), device=dev, dtype=torch.float32)
     dn = torch.empty(B * H, device=dev, dtype=torch.int32)
-    _call("tvl_attn_h2_bwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o_t.buf.data_ptr(), 1 if isinstance(o_t, H2) else 0, do_h.buf.data_ptr(),
-          _p(do_h.inv_scale), _p(lse),
-          _p(delta), dn.data_ptr(), g.buf.data_ptr(), 1 if out_h2 else 0, _p(g.kscale) if out_h2 else None, B, H, T, float(scale))
+    # 10 T^2 d_h FLOP per (b, h) (five products; the recomputed S of the second kernel is not counted); bytes: both kernels read QKV + dO,
+    # the dQ one also O, together they write dQ | dK | dV
+    with _aux_span("attn_h2_bwd", 10.0 * B * H * T * T * 64, 4.0 * B * T * D * (2 * 4 + 1 + 3)):
+        _call("tvl_attn_h2_bwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o_t.buf.data_ptr(), 1 if isinstance(o_t, H2) else 0, do_h.buf.data_ptr(),
+              _p(do_h.inv_scale), _p(lse),
+              _p(delta), dn.data_ptr(), g.buf.data_ptr(), 1 if out_h2 else 0, _p(g.kscale) if out_h2 else None, B, H, T, float(scale))
     return g
 
 

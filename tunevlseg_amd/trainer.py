@@ -154,7 +154,7 @@ class Trainer:
             stop = False
             if val_loader is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
                 metrics.update(self._run_eval(module, val_loader, "val"))
-                if isinstance(sched, ReduceLROnPlateau) or hasattr(sched, "step"):
+                if isinstance(sched, ReduceLROnPlateau):   # Lightning hands the monitored value to ReduceLROnPlateau only
                     sched.step(metrics["val_loss"])
                 score = metrics.get(self.monitor)
                 improved = score is not None and (self.best_score is None or (
@@ -171,6 +171,8 @@ class Trainer:
                 else:
                     self.wait_count += 1
                     stop = self.patience is not None and self.wait_count >= self.patience
+            if sched is not None and not isinstance(sched, ReduceLROnPlateau) and hasattr(sched, "step"):
+                sched.step()   # every other scheduler: once per epoch, no argument (Lightning's interval="epoch" default)
             self.callback_metrics = metrics
             self.save(module, opt, epoch, "last", sched)
             self.log(f"epoch {epoch}: " + " ".join(f"{k}={v:.5f}" for k, v in sorted(metrics.items())))
