@@ -307,8 +307,8 @@ def main():
         name, d = max(long_ones.items(), key=lambda kv: kv[1]["ms"])
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         gemm_ms = sum(v["ms"] for v in prof.values()) / 2
-        split = "bf16s" in name or "tp3" in name
-        two_piece = re.search(r", 2, (true|false), (true|false)>", name) is not None   # the h2 format: two fp16 pieces, 3 MFMAs per fp32 product
+        split = "bf16s" in name or "tp3" in name or "h2m" in name
+        two_piece = "gemm_h2m_kernel" in name or re.search(r", 2, (true|false), (true|false)>", name) is not None   # the h2 format: two fp16 pieces, 3 MFMAs per fp32 product
         peak = (PEAK_BF16_MFMA_TFLOPS / 3 if two_piece else MODE_PEAK[hip.GEMM_MODE]) if split else PEAK_F32_MFMA_TFLOPS
         # HBM bytes per launch of that kernel: recorded by two separate rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE; FETCH_SIZE
         # doubled per the gfx950 note of MI355X_MICROARCH.md §HBM) and committed under profiles/.  It is a RECORDED number: reported
@@ -335,7 +335,7 @@ def main():
                     "rocprof_avg_launch_us": rocprof_avg_us(args.workload, name)[0], "rocprof_source": rocprof_avg_us(args.workload, name)[1],
                     "flops_per_launch": round(d["flops"] / d["launches"]), "all_gemm_ms_per_step": round(gemm_ms, 2),
                     # every GEMM instantiation of the step (one instantiation serves several shapes: the average mixes them)
-                    "gemm_kernels": [{"kernel": k.replace("gemm_bf16s_kernel", "bf16s").replace("gemm_f32_kernel", "f32").replace("gemm_tp3_kernel", "tp3"),
+                    "gemm_kernels": [{"kernel": k.replace("gemm_bf16s_kernel", "bf16s").replace("gemm_f32_kernel", "f32").replace("gemm_tp3_kernel", "tp3").replace("gemm_h2m_kernel", "h2m"),
                                       "ms_per_step": round(v["ms"] / 2, 2), "launches_per_step": v["launches"] // 2,
                                       "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                      for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:5]],

@@ -600,22 +600,27 @@ def test_h2_pack_with_relu_gate(hip, rows, cols):
             assert torch.allclose(t.row_norm, ref.row_norm, rtol=1e-6, atol=0)   # (the two instantiations contract their FMAs differently)
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (495, 512, 3072), (33, 256, 64)])
-def test_gemm_h2_matches_fp64(hip, M, N, K):
-    """tvl_gemm_h2: three fp16-piece products per k-step, row scales of A and the tensor scale of B undone in the epilogue."""
+@pytest.mark.parametrize("tile", [0, 1926, 2566, 1920, 2560])
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (495, 512, 3072), (33, 256, 64), (257, 512, 96), (700, 272, 128)])
+def test_gemm_h2_matches_fp64(hip, M, N, K, tile):
+    """tvl_gemm_h2: three fp16-piece products per k-step, row scales of A and the tensor scale of B undone in the epilogue.  Both kernel
+    generations and both row tiles: 1926 / 2566 = the v_mfma_f32_16x16x32_f16 ring (csrc/gemm_h2m_kernel.h; K = 96 is its shortest k-loop,
+    K = 64 falls back), 1920 / 2560 = the 32x32x16 one; 0 = the library's own choice."""
+    _gemm = hip.gemm_h2
+    hip_gemm_h2 = lambda *a, **k: _gemm(*a, tile_m=tile, **k)  # noqa: E731
     a = rnd(M, K, seed=5) * torch.logspace(-5, 1, M)[:, None]
     b = rnd(N, K, seed=6) * 0.03
     bias = rnd(N, seed=7)
     ref = a.double() @ b.double().T + bias.double()
     den = a.abs().double() @ b.abs().double().T + bias.abs().double()
     A, B = hip.h2_pack(dev(a), True), hip.h2_pack(dev(b), False)
-    c, _ = hip.gemm_h2(A, B, bias=dev(bias))
+    c, _ = hip_gemm_h2(A, B, bias=dev(bias))
     assert ((c.cpu().double() - ref).abs() / den).max().item() < 2e-6
     c3, _ = hip.gemm_tp3(hip.tp3_pack(dev(a)), hip.tp3_pack(dev(b)), bias=dev(bias))
     e2, e3 = ((c.cpu().double() - ref) / den).pow(2).mean().sqrt().item(), ((c3.cpu().double() - ref) / den).pow(2).mean().sqrt().item()
     assert e2 < 3 * e3 + 1e-9, (e2, e3)   # as accurate as the six-product bf16 scheme
     # tp3 output of the same call (what the attention / fc2 consume)
-    _, ct = hip.gemm_h2(A, B, bias=dev(bias), want_f32=False, want_tp3=True)
+    _, ct = hip_gemm_h2(A, B, bias=dev(bias), want_f32=False, want_tp3=True)
     assert torch.equal(ct.float(), c)
 
 

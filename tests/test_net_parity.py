@@ -78,7 +78,13 @@ def run_case(name):
 
     exact_mode = _hip.GEMM_MODE in ("f32", "bf16x6")  # fp32-equivalent arithmetic: label map must be bit-exact
     flips = (lab != lab_ref).sum().item()
-    if exact_mode:
+    # heavy-tailed fixtures carry the reference's float64 logits: where the reference's OWN fp32 logit is within its fp32-vs-float64
+    # deviation of the threshold, its label is a coin flip of that rounding noise and is not held against this path
+    noise = (ref - torch.from_numpy(fx["out.logits64"])).abs().max().item() if "out.logits64" in fx else 0.0
+    if exact_mode and noise:
+        assert ((lab != lab_ref) & (ref.abs() > 3.0 * noise)).sum().item() == 0, f"{name}: label pixels differ away from the threshold"
+        exact_mode = flips == 0   # the count comparison against the reference below presumes identical label maps
+    elif exact_mode:
         assert flips == 0, f"{name}: {flips} label pixels differ"
     else:  # reduced-precision modes: only pixels whose reference logit is within the logit tolerance may flip
         assert ((lab != lab_ref) & (ref.abs() > LOGIT_TOL)).sum().item() == 0
@@ -151,7 +157,7 @@ def test_hip_net_matches_reference_full_size_tp3(name, monkeypatch):
     hip.gemm_profile_start()
     run_case(name)
     prof = hip.gemm_profile_stop()
-    assert any(k.startswith("gemm_tp3_kernel") for k in prof), sorted(prof)
+    assert any(k.startswith(("gemm_tp3_kernel", "gemm_h2m_kernel")) for k in prof), sorted(prof)
 
 
 def run_compact_case(name):
@@ -199,7 +205,7 @@ def test_hip_net_matches_reference_headline_batch():
     """BASELINE configs[1] exactly (VPT-10 shallow, 352x352, B = 32): the configuration bench.py times.  Its M = 15 840 rows must
     have gone through the large-tile GEMM (the 192-row tp3 ring), which no B = 1 fixture reaches by itself."""
     prof = run_compact_case("rd64_vpt_n10_d1_b32")
-    big = [k for k in prof if k.startswith("gemm_tp3_kernel<192") or "gemm_bf16s_kernel<192" in k]
+    big = [k for k in prof if k.startswith(("gemm_tp3_kernel<192", "gemm_h2m_kernel<192")) or "gemm_bf16s_kernel<192" in k]
     assert big, sorted(prof)
 
 
@@ -207,7 +213,7 @@ def test_hip_net_matches_reference_maple_per_gpu_batch():
     """BASELINE configs[3]'s per-GPU step (MaPLe depth 9, 4 context tokens, new last layer, B = 32): both towers train, the deep-prompt
     overwrites and the coupling MLPs run at the batch the 8-GPU config gives every rank."""
     prof = run_compact_case("rd64_maple_n4_d9_newlast_b32")
-    assert any(k.startswith("gemm_tp3_kernel<") and ", 2, " in k for k in prof), sorted(prof)
+    assert any(k.startswith("gemm_h2m_kernel<") or (k.startswith("gemm_tp3_kernel<") and ", 2, " in k) for k in prof), sorted(prof)
 
 
 def test_hip_net_matches_reference_headline_batch_heavy_tails():

@@ -9,7 +9,7 @@
 // epilogue undoes the scales: per-row factors of A (a_scale[m] = 1 / s_m) and alpha (= 1 / s of the B tensor), both exact.
 //
 // Image layout = tp3's with two pieces: block (rb, kb) at ((rb * K/16 + kb) * 2 + piece) * 1024, same lane order inside a piece.
-#include "gemm_tp3_kernel.h"
+#include "gemm_h2m_kernel.h"
 
 namespace {
 
@@ -160,7 +160,20 @@ __global__ __launch_bounds__(256) void h2_rowpack_kernel(const float* __restrict
     }
 }
 
+// TVL_GEMM_M16=0: the first-generation ring on v_mfma_f32_32x32x16_f16 (A/B switch; default = the 16x16x32 kernels, gemm_h2m_kernel.h)
+bool use_m16() {
+    static const bool on = !(getenv("TVL_GEMM_M16") && getenv("TVL_GEMM_M16")[0] == '0');
+    return on;
+}
+
 int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
+    if (bm == 128) return tvl_gemm_h2_w4(&p, bm, epi, s);
+    if ((bm == 2566 || (bm == 256 && use_m16())) && p.K >= 96) return tvl_gemm_h2m_t256(&p, epi, s);
+    if ((bm == 1926 || (bm == 192 && use_m16())) && p.K >= 96) return tvl_gemm_h2m_t192(&p, epi, s);
+    if (bm == 2566 || bm == 1926) bm = bm / 10;
+    if (bm == 2560 || bm == 1920) bm = bm / 10;   // explicit first-generation tiles (tools/bench_layer_gemms.py)
+    if (bm == 2564 || bm == 1924) return tvl_gemm_h2_ns4(&p, bm / 10, epi, s);
+    if (bm == 2565 || bm == 1925) return tvl_gemm_h2_ns5(&p, bm / 10, epi, s);
     // the epilogues the vision tower's forward needs (QKV -> tp3, fc1 -> QuickGELU -> tp3 + z) + the plain ones; others: generic
     if (bm == 256) {
         switch (epi) {
@@ -192,6 +205,7 @@ int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
 // 3x3 conv as an implicit GEMM (the A fragments are gathered tap by tap from the pixel matrix' image): generic epilogue (bias + ReLU of the
 // folded eval BatchNorm) and the plain one of the data gradient
 int launch_h2_conv(const Tp3Params& p, int bm, int epi, hipStream_t s) {
+    if (use_m16() && p.K >= 96) return bm == 256 ? tvl_gemm_h2m_conv_t256(&p, epi, s) : tvl_gemm_h2m_conv_t192(&p, epi, s);
     constexpr int CONV_FWD = E_BIAS | E_RELU | E_F32 | E_RSCALE;   // conv + folded BN + ReLU
     if (bm == 256) {
         if (epi == (E_F32 | E_RSCALE)) return launch<256, 256, 2, E_F32 | E_RSCALE, 2, false, true>(p, s);
@@ -296,7 +310,10 @@ static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void*
     p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha; p.a_scale = a_row_scale; p.a_sstride = conv ? 0 : 1;
     p.Ch2 = reinterpret_cast<unsigned char*>(c_h2); p.out_norm = out_row_norm; p.out_mul = out_mul; p.out_add = out_add; p.out_inv = out_inv_scale; p.out_stride = out_per_tensor ? 0 : 1;
     int bm = a->tile_m;
-    if (bm != 256 && bm != 192) {
+    if (bm == 128 && !conv) {
+        static const int stagger_us = getenv("TVL_GEMM_STAGGER_US") ? atoi(getenv("TVL_GEMM_STAGGER_US")) : 0;   // experiment knob
+        p.stagger_ticks = stagger_us * 100;
+    } else if (bm != 256 && bm != 192 && bm != 2564 && bm != 2565 && bm != 1924 && bm != 1925 && bm != 2566 && bm != 1926 && bm != 2560 && bm != 1920) {
         const long t256 = ((long)(a->M + 255) / 256) * ((a->N + 255) / 256), t192 = ((long)(a->M + 191) / 192) * ((a->N + 255) / 256);
         bm = ((t256 + 255) / 256) * 256 <= ((t192 + 255) / 256) * 192 ? 256 : 192;   // rounds x rows per tile; ties go to the larger tile
     }
@@ -304,6 +321,33 @@ static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void*
         p.cH = conv->H; p.cW = conv->W; p.cC16 = conv->C / 16;
         p.a_rb = (int)((a->a_rows + 31) / 32);   // = the index of the appended zero block row
     }
+#ifdef TVL_DIAGNOSTIC_KERNELS   // `make DIAG=1`: timing-only ablations of the plain fp32-output GEMM (WRONG results: bit 2 no DMA in the loop,
+                               // bit 3 every DMA re-reads slab 0 -- L2-resident operands --, bit 4 no stores); tools/bench_gemm_ablate.py
+    if (!conv && a->variant >= 32) p.pre_out = nullptr;   // (the stamp buffer travels in a->pre_out)
+    if (!conv && a->variant && epi_code(p) == (E_F32 | E_RSCALE)) {
+        if (a->variant >= 32) p.pre_out = a->pre_out;
+        hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+        int drc = 1;
+        if (bm == 256) {
+            if (a->variant == 4) drc = launch<256, 256, 2 | 4, E_F32 | E_RSCALE, 2>(p, hs);
+            else if (a->variant == 8) drc = launch<256, 256, 2 | 8, E_F32 | E_RSCALE, 2>(p, hs);
+            else if (a->variant == 16) drc = launch<256, 256, 2 | 16, E_F32 | E_RSCALE, 2>(p, hs);
+            else if (a->variant == 24) drc = launch<256, 256, 2 | 8 | 16, E_F32 | E_RSCALE, 2>(p, hs);
+            else if (a->variant == 32) drc = launch<256, 256, 2 | 32, E_F32 | E_RSCALE, 2>(p, hs);   // in-kernel stamps into pre_out (12 uint64 per workgroup)
+            else if (a->variant == 36) drc = launch<256, 256, 2 | 32 | 4, E_F32 | E_RSCALE, 2>(p, hs);
+        } else {
+            if (a->variant == 4) drc = launch<192, 256, 3 | 4, E_F32 | E_RSCALE, 2>(p, hs);
+            else if (a->variant == 8) drc = launch<192, 256, 3 | 8, E_F32 | E_RSCALE, 2>(p, hs);
+            else if (a->variant == 16) drc = launch<192, 256, 3 | 16, E_F32 | E_RSCALE, 2>(p, hs);
+            else if (a->variant == 24) drc = launch<192, 256, 3 | 8 | 16, E_F32 | E_RSCALE, 2>(p, hs);
+            else if (a->variant == 32) drc = launch<192, 256, 3 | 32, E_F32 | E_RSCALE, 2>(p, hs);
+            else if (a->variant == 36) drc = launch<192, 256, 3 | 32 | 4, E_F32 | E_RSCALE, 2>(p, hs);
+        }
+        TVL_REQUIRE(drc == 0, "tvl_gemm_h2: unknown diagnostic variant %d", a->variant);
+        TVL_LAUNCH_CHECK("tvl_gemm_h2(diag)");
+        return 0;
+    }
+#endif
     const int rc = conv ? launch_h2_conv(p, bm, epi_code(p), reinterpret_cast<hipStream_t>(stream))
                         : launch_h2(p, bm, epi_code(p), reinterpret_cast<hipStream_t>(stream));
     TVL_REQUIRE(rc == 0, "tvl_gemm_h2: launch failed (dynamic LDS opt-in?)");
@@ -356,7 +400,8 @@ extern "C" int tvl_gemm_h2_ks(const tvlGemmTp3Args* a, const float* a_kscale, tv
     p.A = reinterpret_cast<const unsigned char*>(a->A); p.a_rb = (int)((a->a_rows + 31) / 32);
     p.B = reinterpret_cast<const unsigned char*>(a->B); p.b_rb = (int)((a->b_rows + 31) / 32);
     p.C = a->C; p.ldc = a->ldc; p.alpha = a->alpha; p.a_kscale = a_kscale; p.k_chunks = a->K / 64; p.a_sstride = 1;
-    const int rc = launch<192, 256, 3, E_F32 | E_RSCALE, 2, true>(p, reinterpret_cast<hipStream_t>(stream));
+    const int rc = (use_m16() && p.K >= 96) ? tvl_gemm_h2m_ks_t192(&p, reinterpret_cast<hipStream_t>(stream))
+                                            : launch<192, 256, 3, E_F32 | E_RSCALE, 2, true>(p, reinterpret_cast<hipStream_t>(stream));
     TVL_REQUIRE(rc == 0, "tvl_gemm_h2_ks: launch failed (dynamic LDS opt-in?)");
     TVL_LAUNCH_CHECK("tvl_gemm_h2_ks");
     return 0;

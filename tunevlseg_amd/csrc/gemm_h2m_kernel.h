@@ -1,0 +1,358 @@
+// Two-piece fp16 ("h2") ring GEMM on v_mfma_f32_16x16x32_f16 -- the second generation of gemm_tp3_kernel.h<NP = 2>.
+//
+// Why another kernel.  Stamps inside the 32x32x16 ring (profiles/r3_gemm_experiments.md) show its k-loop already issues 83-86 % of
+// its cycles as MFMAs -- and runs at 1.33-1.9 GHz: a dense MFMA loop is POWER-limited on this chip, cycles saved come back as a lower
+// clock.  What raises throughput at a fixed power is fewer joules per FLOP, and the 16x16x32 shape delivers the same FLOPs per cycle at
+// a clock the chip can hold ~10 % higher (MI355X_MICROARCH.md "DVFS give-back" item 7; our own probe in the ring's regime -- every
+// operand re-read from LDS, one barrier per block, 256 workgroups: 589 vs 515 TFLOP/s fp32-equivalent, tools/mfma_shape_probe.hip).
+//
+// Same operand images as gemm_tp3_kernel.h (block (rb, kb) = 32 rows x 16 k, two 1-KiB pieces, lane-linear), same LDS-DMA fill, same
+// epilogue contract.  What changes:
+//   * a 16x16x32 operand = rows 16 m .. 16 m + 15 of TWO consecutive k blocks: lane (r = l & 15, q = l >> 4) reads its 16 bytes
+//     (k = 8 q .. 8 q + 7) at block(kb + (q >> 1)) + ((q & 1) * 32 + 16 (m & 1) + r) * 16 -- sixteen-lane groups on distinct slots,
+//     conflict-free.  A k-step is therefore 32 deep: slabs (2t, 2t + 1) sit in the LDS stage PAIR t & 1 (four 16-deep stages);
+//   * ALL fragments of a 32-deep step live in registers (A: WM/16 x 2 pieces, B: 4 x 2 pieces; 96 VGPRs + 128 accumulators for the
+//     256-row tile), so there is ONE raw barrier per 32-deep step (B_t): before it a wave waits for its own DMA pieces of the next
+//     pair and for its LDS reads of the current one; after it the current pair is free -> the DMA of step t + 2 goes out, spread over
+//     the first MFMAs -- and the next pair is visible -> the fragments of step t + 1 are fetched into each register as soon as its
+//     last MFMA of step t has issued (A row by row; B in the last row's column sweep), so no LDS latency is exposed at a boundary;
+//   * accumulators are TMo x 4 tiles of 16 x 16 (4 registers each: column = lane & 15, rows 4 (lane >> 4) .. + 3).  The product is
+//     transposed as before (mfma(b, a)): a lane's 4 registers are 4 consecutive columns of C.
+#pragma once
+#include "gemm_tp3_kernel.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <bool DMA, bool NEXT, bool FIRST>
+struct StepKind {};
+
+template <int TMo, int EPI>
+__device__ __forceinline__ void epilogue16(const Tp3Params& p, f32x4 (&acc)[TMo][4], int row_base, int col_base, int lane, float* scratch) {
+    constexpr int LDS_ROW = 36;
+    constexpr int ROWS = TMo * 16;
+    const int m = lane & 15, q = lane >> 4;
+    const int rr = lane >> 3, cc = (lane & 7) * 4;
+    constexpr bool H2O = EPI < 0 || (EPI & E_H2OUT) != 0;
+    float* rowsc = scratch + ROWS * LDS_ROW;
+    const bool h2o = H2O && (EPI >= 0 || p.Ch2 != nullptr);
+    if (h2o) {
+        for (int rl = lane; rl < ROWS; rl += 64) {
+            const int row = row_base + rl;
+            float inv = 1.0f;
+            if (row < p.M) {
+                inv = h2::inv_scale_of(p.out_norm[(long)row * p.out_stride] * p.out_mul + p.out_add);
+                if (col_base == 0 && (p.out_stride || row == 0)) p.out_inv[(long)row * p.out_stride] = inv;
+            }
+            rowsc[rl] = 1.0f / inv;   // a power of two: exact
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {   // two 32-column strips of the wave's 64 columns
+#pragma unroll
+        for (int i = 0; i < TMo; ++i)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                *reinterpret_cast<float4*>(&scratch[(i * 16 + m) * LDS_ROW + n * 16 + 4 * q]) =
+                    make_float4(acc[i][2 * j + n][0], acc[i][2 * j + n][1], acc[i][2 * j + n][2], acc[i][2 * j + n][3]);
+        const int col = col_base + j * 32 + cc;
+        if (col + 3 < p.N) {
+#pragma unroll 1
+            for (int rl = rr; rl < ROWS; rl += 8) {
+                const float4 v = *reinterpret_cast<const float4*>(&scratch[rl * LDS_ROW + cc]);
+                const int row = row_base + rl;
+                if (row < p.M) emit4<EPI, false>(p, row, col, v, h2o ? rowsc[rl] : 1.0f);
+            }
+        }
+    }
+}
+
+template <int BM, int EPI, bool KS = false, bool CONV = false>
+__global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
+    constexpr int NW = 8, BN = 256, NP = 2;
+    constexpr int WM = BM / 2;
+    constexpr int TMo = WM / 16;                    // 16-row A operands per wave (8 or 6)
+    constexpr int BLKP = NP * PIECE;
+    constexpr int PA = NP * BM / 32, PB = NP * BN / 32, PT = PA + PB;   // 1-KiB pieces per 16-deep slab
+    constexpr int PW = (PT + NW - 1) / NW;
+    constexpr int STAGE = PT * PIECE, PAIR = 2 * STAGE;
+    constexpr int NM = 3 * TMo * 4;                 // MFMAs per 32-deep step and wave
+    static_assert(WM % 32 == 0 && (BM == 256 || BM == 192), "tile");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int gsize_full = GROUP_M * p.tiles_n;
+    const int group = bid / gsize_full;
+    const int gm0 = group * GROUP_M;
+    const int gm = p.tiles_m - gm0 < GROUP_M ? p.tiles_m - gm0 : GROUP_M;
+    const int in_group = bid - group * gsize_full;
+    const int tile_m = gm0 + in_group % gm, tile_n = in_group / gm;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int KB = p.K >> 4;
+    const int nt = KB >> 1;                          // 32-deep steps (K % 32 == 0, K >= 96: nt >= 3)
+
+    // this wave's DMA sources (slab 0): wave-uniform bases + one lane offset
+    const unsigned char* src[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int pc = wave + NW * i;
+        if (pc < PA) {
+            int rb = tile_m * (BM / 32) + pc / NP;
+            rb = rb < p.a_rb ? rb : p.a_rb - 1;
+            src[i] = p.A + ((long)rb * KB) * BLKP + (pc % NP) * PIECE;
+        } else {
+            const int q = pc < PT ? pc - PA : 0;
+            int rb = tile_n * (BN / 32) + q / NP;
+            rb = rb < p.b_rb ? rb : p.b_rb - 1;
+            src[i] = p.B + ((long)rb * KB) * BLKP + (q % NP) * PIECE;
+        }
+    }
+    const unsigned lane16 = lane * 16;
+    static_assert(!CONV || PA <= 2 * NW, "conv: at most two A pieces per wave");
+    int cv_row[2] = {-1, -1}, cv_yx[2] = {0, 0};
+    int cv_dy = -1, cv_dx = -1, cv_cb = 0;
+    if constexpr (CONV) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pc = wave + NW * i;
+            if (pc < PA) {
+                const int r = tile_m * BM + (pc / NP) * 32 + (lane & 31);
+                const int hw = p.cH * p.cW;
+                const int rem = r % hw, oy = rem / p.cW;
+                cv_row[i] = r < p.M ? r : -1;
+                cv_yx[i] = (oy << 16) | (rem - oy * p.cW);
+            }
+        }
+    }
+    auto conv_advance = [&]() {
+        if constexpr (CONV) {
+            if (++cv_dx == 2) {
+                cv_dx = -1;
+                if (++cv_dy == 2) { cv_dy = -1; ++cv_cb; }
+            }
+        }
+    };
+    // request piece i of this wave for 16-deep slab `slab` (into LDS stage slab & 3)
+    auto issue_piece = [&](auto idx, int slab) {
+        constexpr int i = decltype(idx)::value;
+        const int pc = wave + NW * i;
+        const unsigned dst = lds0 + (slab & 3) * STAGE + pc * PIECE;
+        if constexpr (CONV && i < 2) {
+            if (pc < PA) {   // wave-uniform
+                const int iy = (cv_yx[i] >> 16) + cv_dy, ix = (cv_yx[i] & 0xffff) + cv_dx;
+                const bool ok = cv_row[i] >= 0 && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
+                const int rin = ok ? cv_row[i] + cv_dy * p.cW + cv_dx : p.a_rb * 32;
+                const unsigned long off = ((unsigned long)((rin >> 5) * p.cC16 + cv_cb)) * BLKP + (unsigned)((pc % NP) * PIECE + (((lane >> 5) * 32 + (rin & 31)) * 16));
+                glds16(p.A + off, dst);
+                return;
+            }
+        }
+        if ((i + 1) * NW <= PT || pc < PT) {
+            // keep the 64-bit base in SGPRs (saddr + 32-bit lane offset form of global_load_lds): left to itself hipcc strength-reduces
+            // the slab offset into a VGPR pair per piece, and the 256-row tile has no registers to spare
+            const unsigned long sb = (unsigned long)(src[i] + (long)slab * BLKP);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb), hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+            glds16(reinterpret_cast<const unsigned char*>(((unsigned long)hi << 32) | lo) + lane16, dst);
+        }
+    };
+    auto issue_slab = [&](int slab) {
+        [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(std::integral_constant<int, I>{}, slab), ...); }(std::make_integer_sequence<int, PW>{});
+        conv_advance();
+    };
+
+    f32x4 acc[TMo][4];
+#pragma unroll
+    for (int i = 0; i < TMo; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses inside pair 0: lane (r, q) -> k block (q >> 1), slot (q & 1) * 32 + r
+    const unsigned lane_off = (unsigned)(((lane >> 5) & 1) * STAGE + ((((lane >> 4) & 1) * 32) + (lane & 15)) * 16);
+    const unsigned a_frag = lds0 + lane_off + wm * ((WM / 32) * BLKP);
+    const unsigned b_frag = lds0 + lane_off + PA * PIECE + wn * (2 * BLKP);
+    bf16x8 a[TMo][2], b[4][2];
+    auto read_a = [&](auto mi, unsigned base) {
+        constexpr int m = decltype(mi)::value;
+        a[m][0] = lds_frag<(m >> 1) * BLKP + (m & 1) * 256>(base);
+        a[m][1] = lds_frag<(m >> 1) * BLKP + (m & 1) * 256 + PIECE>(base);
+    };
+    auto read_b = [&](auto ni, unsigned base) {
+        constexpr int n = decltype(ni)::value;
+        b[n][0] = lds_frag<(n >> 1) * BLKP + (n & 1) * 256>(base);
+        b[n][1] = lds_frag<(n >> 1) * BLKP + (n & 1) * 256 + PIECE>(base);
+    };
+
+    // KS: ratio table R[row][c] = inv[row][c-1] / inv[row][c] (c >= 1) behind the four stages, before any LDS-DMA is in flight
+    const unsigned ktab = lds0 + 4 * STAGE;
+    float kratio[TMo];
+    auto kratio_request = [&](int c) {
+        if constexpr (KS) {
+#pragma unroll
+            for (int i = 0; i < TMo; ++i)
+                asm volatile("ds_read_b32 %0, %1" : "=v"(kratio[i]) : "v"(ktab + (unsigned)(((wm * WM + i * 16 + (lane & 15)) * p.k_chunks + c) * 4)));
+        }
+    };
+    if constexpr (KS) {
+        float* tab = reinterpret_cast<float*>(smem + 4 * STAGE);
+        const int nch = p.k_chunks;
+        for (int e = threadIdx.x; e < BM * nch; e += 512) {
+            const int rl = e / nch, c = e - rl * nch;
+            long row = (long)tile_m * BM + rl;
+            row = row < p.M ? row : p.M - 1;
+            tab[e] = c ? p.a_kscale[row * nch + c - 1] / p.a_kscale[row * nch + c] : 1.0f;
+        }
+        __syncthreads();
+    }
+
+    // prologue: all four stages requested, wait for the first pair, fetch its fragments
+    issue_slab(0);
+    issue_slab(1);
+    issue_slab(2);
+    issue_slab(3);
+    wait_groups_ct<PT, NW, 2>(wave < PT % NW);
+    __builtin_amdgcn_s_barrier();
+    [&]<int... I>(std::integer_sequence<int, I...>) { (read_a(std::integral_constant<int, I>{}, a_frag), ...); }(std::make_integer_sequence<int, TMo>{});
+    [&]<int... I>(std::integer_sequence<int, I...>) { (read_b(std::integral_constant<int, I>{}, b_frag), ...); }(std::make_integer_sequence<int, 4>{});
+    if constexpr (KS) kratio_request(1);
+
+    // One 32-deep step.  MFMA q = (i * 4 + j) * 3 + product; rows i ascending, columns j ascending.
+    //   after MFMA 8 (row 0, columns 0-2 done)        the step's only synchronisation B_t (unless this is the last step)
+    //   DMA && after MFMA 9 + 3 d                     piece d of the 2 PW pieces of slabs 2t + 4, 2t + 5 (into the pair this step reads)
+    //   NEXT && one MFMA into row i + 1               A operand i of step t + 1 (from the other pair); in the last row, B operand j
+    //                                                 one MFMA after its own three
+    //   !FIRST && after MFMA 0                        the last A operand and the last B operand of THIS step (their registers were in use
+    //                                                 until the previous step's last MFMA); first needed by MFMA 9, behind B_t's lgkmcnt(0)
+    constexpr int SYNC_AT = 8;
+    auto step = [&]<bool DMA, bool NEXT, bool FIRST>(StepKind<DMA, NEXT, FIRST>, int t) {
+        const unsigned nxt_a = a_frag + ((t + 1) & 1) * PAIR, nxt_b = b_frag + ((t + 1) & 1) * PAIR;
+        if constexpr (KS) {
+            if ((t & 1) == 0 && t) {   // this step opens chunk t / 2 (64 columns of K): bring the accumulators to its scale
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < TMo; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] *= kratio[i];
+                const int cn = (t >> 1) + 1;
+                kratio_request(cn < p.k_chunks ? cn : p.k_chunks - 1);
+            }
+        }
+        // every fragment fetched so far has arrived (the inline-asm reads are invisible to hipcc's own waitcnt insertion): the prologue's
+        // reads in the first step, the previous step's last refetches (B operands 1 and 2, issued 3-6 MFMAs ago) in the others
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        auto body = [&](auto idx) {
+            constexpr int q = decltype(idx)::value;
+            constexpr int prod = q % 3, ij = q / 3, i = ij / 4, j = ij % 4;
+            // smallest piece products first: h0 h1, h1 h0, then h0 h0
+            constexpr int pa = prod == 1 ? 1 : 0, pb = prod == 0 ? 1 : 0;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[j][pb]), __builtin_bit_cast(f16x8, a[i][pa]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!FIRST && q == 0) {
+                read_a(std::integral_constant<int, TMo - 1>{}, a_frag + (t & 1) * PAIR);
+                read_b(std::integral_constant<int, 3>{}, b_frag + (t & 1) * PAIR);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (q == SYNC_AT && !NEXT && !FIRST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (last step: only those two reads)
+            if constexpr (NEXT && q == SYNC_AT) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next pair have landed (nothing younger is in flight)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // ... and its reads of the current pair are complete
+                __builtin_amdgcn_s_barrier();                         // B_t: next pair visible to all, current pair free
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (DMA && q > SYNC_AT && (q - SYNC_AT - 1) % 3 == 0 && (q - SYNC_AT - 1) / 3 < 2 * PW) {
+                constexpr int d = (q - SYNC_AT - 1) / 3;
+                issue_piece(std::integral_constant<int, d % PW>{}, 2 * t + 4 + d / PW);
+                if constexpr (d % PW == PW - 1) conv_advance();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (NEXT) {
+                // A operand i - 1 is dead once row i has started: refetch it one MFMA into the row
+                if constexpr (i >= 1 && j == 0 && prod == 1) { read_a(std::integral_constant<int, i - 1>{}, nxt_a); __builtin_amdgcn_sched_barrier(0); }
+                // last row: B operand j - 1 is dead after its three MFMAs; refetch it one MFMA later
+                if constexpr (i == TMo - 1 && j >= 1 && prod == 1) { read_b(std::integral_constant<int, j - 1>{}, nxt_b); __builtin_amdgcn_sched_barrier(0); }
+            }
+        };
+        [&]<int... Q>(std::integer_sequence<int, Q...>) { (body(std::integral_constant<int, Q>{}), ...); }(std::make_integer_sequence<int, NM>{});
+    };
+
+    // nt >= 3 (the host sends K < 96 to the 32x32x16 kernel): first step, steady steps, the step with nothing left to request, the last
+    step(StepKind<true, true, true>{}, 0);
+#pragma unroll 1
+    for (int t = 1; t < nt - 2; ++t) step(StepKind<true, true, false>{}, t);
+    step(StepKind<false, true, false>{}, nt - 2);
+    step(StepKind<false, false, false>{}, nt - 1);
+
+    __syncthreads();  // every wave is past its last LDS read: the stages become epilogue scratch
+    float* scratch = reinterpret_cast<float*>(smem) + wave * (TMo * 16 * 37);
+    epilogue16<TMo, EPI>(p, acc, tile_m * BM + wm * WM, tile_n * BN + wn * 64, lane, scratch);
+}
+
+template <int BM, int EPI, bool KS = false, bool CONV = false>
+int launch_m(const Tp3Params& p0, hipStream_t s) {
+    Tp3Params p = p0;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + 255) / 256;
+    constexpr size_t stage_bytes = (size_t)4 * (2 * (BM + 256) / 32) * PIECE;
+    constexpr size_t epi_bytes = (size_t)8 * (BM / 2) * 37 * sizeof(float);
+    constexpr size_t ks_bytes = KS ? (size_t)BM * 64 * sizeof(float) : 0;
+    constexpr size_t smem = (stage_bytes + ks_bytes) > epi_bytes ? (stage_bytes + ks_bytes) : epi_bytes;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    auto kern = gemm_h2m_kernel<BM, EPI, KS, CONV>;
+    static int attr_dev_mask = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    if (!(attr_dev_mask & (1 << dev))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 1;
+        attr_dev_mask |= 1 << dev;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)p.tiles_m * p.tiles_n)), dim3(512), smem, s, p);
+    return 0;
+}
+
+template <int BM>
+int launch_m_layer_epi(const Tp3Params& p, int epi, hipStream_t s) {
+    switch (epi) {
+        case E_BIAS | E_RSCALE | E_H2OUT: return launch_m<BM, E_BIAS | E_RSCALE | E_H2OUT>(p, s);                                       // qkv -> h2
+        case E_RSCALE | E_H2OUT: return launch_m<BM, E_RSCALE | E_H2OUT>(p, s);                                                         // dO -> h2
+        case E_BIAS | E_RES | E_F32 | E_RSCALE: return launch_m<BM, E_BIAS | E_RES | E_F32 | E_RSCALE>(p, s);                           // out_proj, fc2
+        case E_F32 | E_RSCALE: return launch_m<BM, E_F32 | E_RSCALE>(p, s);                                                             // data gradients
+        case E_BIAS | E_QGELU | E_PRE | E_RSCALE | E_H2OUT: return launch_m<BM, E_BIAS | E_QGELU | E_PRE | E_RSCALE | E_H2OUT>(p, s);   // fc1 -> h2 + z
+        case E_BIAS | E_QGELU | E_RSCALE | E_H2OUT: return launch_m<BM, E_BIAS | E_QGELU | E_RSCALE | E_H2OUT>(p, s);                   // fc1, no tape
+        case E_DQGELU | E_RSCALE | E_H2OUT: return launch_m<BM, E_DQGELU | E_RSCALE | E_H2OUT>(p, s);                                   // dz -> h2
+        case E_BIAS | E_F32 | E_RSCALE: return launch_m<BM, E_BIAS | E_F32 | E_RSCALE>(p, s);                                           // frozen Linear / 1x1 conv
+        case E_BIAS | E_RELU | E_F32 | E_RSCALE: return launch_m<BM, E_BIAS | E_RELU | E_F32 | E_RSCALE>(p, s);                         // ... + ReLU
+        default: return launch_m<BM, -1>(p, s);
+    }
+}
+
+// 3x3 conv as an implicit GEMM (A pieces gathered tap by tap): conv + folded BN + ReLU, the plain data gradient, anything else
+template <int BM>
+int launch_m_conv_epi(const Tp3Params& p, int epi, hipStream_t s) {
+    constexpr int CONV_FWD = E_BIAS | E_RELU | E_F32 | E_RSCALE;
+    if (epi == (E_F32 | E_RSCALE)) return launch_m<BM, E_F32 | E_RSCALE, false, true>(p, s);
+    if (epi == CONV_FWD) return launch_m<BM, CONV_FWD, false, true>(p, s);
+    return launch_m<BM, -1, false, true>(p, s);
+}
+
+}  // namespace
+
+int tvl_gemm_h2m_t256(const void* params, int epi, hipStream_t s);   // gemm_h2m_t256.hip / gemm_h2m_t192.hip
+int tvl_gemm_h2m_t192(const void* params, int epi, hipStream_t s);
+int tvl_gemm_h2m_conv_t256(const void* params, int epi, hipStream_t s);
+int tvl_gemm_h2m_conv_t192(const void* params, int epi, hipStream_t s);
+int tvl_gemm_h2m_ks_t192(const void* params, hipStream_t s);         // A scaled per (row, 64-column chunk of K): the QKV data gradient

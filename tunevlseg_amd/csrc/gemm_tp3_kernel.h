@@ -38,8 +38,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int NTH = 512;
+constexpr int NTH = 512;     // the 8-wave workgroup (2 x 4 waves, one workgroup per CU)
 constexpr int NWAVE = 8;
+// NW = 4: a 4-wave workgroup (1 x 4 waves, tile BM x 256 with BM <= 128, LDS <= 80 KB) of which TWO fit a CU -- one wave of each per SIMD.
+// The two are independent (own barriers, own DMA ring): whatever one of them waits for (its slab barrier, a counted vmcnt, the
+// HBM burst of its epilogue, its launch prologue) the other one's MFMAs fill, which a single 8-wave workgroup in lockstep cannot do.
 using tp3::PIECE;
 using tp3::BLK;
 
@@ -69,6 +72,7 @@ struct Tp3Params {
     // row m of the GEMM gathers its nine taps from it (3x3, pad 1, stride 1; K = 9 * 16 * cC16 ordered (c / 16, ky, kx, c % 16))
     int cH, cW, cC16;
     int tiles_m, tiles_n;
+    int stagger_ticks;   // NW = 4 kernels: start delay (10 ns ticks of s_memrealtime) of the second workgroup of each CU, 0 = none
 };
 
 __device__ __forceinline__ void glds16(const void* g, unsigned lds_byte) {
@@ -88,13 +92,19 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// wait until at most `groups` of this wave's DMA groups (one group = its pieces of one slab) are still in flight
-template <int PT>
-__device__ __forceinline__ void wait_groups(int groups, bool extra) {
-    constexpr int n0 = PT / NWAVE;
-    if (groups <= 0) wait_vm<0>();
-    else if (groups == 1) { if (extra) wait_vm<n0 + 1>(); else wait_vm<n0>(); }
-    else { if (extra) wait_vm<2 * (n0 + 1)>(); else wait_vm<2 * n0>(); }
+// wait until at most G of this wave's DMA groups (one group = its pieces of one slab) are still in flight
+template <int PT, int NW, int G>
+__device__ __forceinline__ void wait_groups_ct(bool extra) {
+    constexpr int n0 = PT / NW;
+    static_assert(G >= 0 && G * (n0 + 1) <= 63, "vmcnt is a 6-bit count");
+    if constexpr (G == 0) wait_vm<0>();
+    else if constexpr (PT % NW == 0) wait_vm<G * n0>();
+    else { if (extra) wait_vm<G * (n0 + 1)>(); else wait_vm<G * n0>(); }
+}
+template <int PT, int NW, int GMAX>
+__device__ __forceinline__ void wait_groups_rt(int groups, bool extra) {   // prologue only: the count depends on K
+    if constexpr (GMAX <= 0) wait_groups_ct<PT, NW, 0>(extra);
+    else { if (groups >= GMAX) wait_groups_ct<PT, NW, GMAX>(extra); else wait_groups_rt<PT, NW, GMAX - 1>(groups, extra); }
 }
 
 using tp3::split4;
@@ -229,12 +239,18 @@ __device__ __forceinline__ void read_all(Frags<TM, TN, NP>& f, unsigned a_addr, 
 // KS: A carries one power-of-two scale per (row, 64-column chunk of K) (a_kscale).  The accumulators hold the sum scaled by the CURRENT
 // chunk's scale; at a chunk boundary (every four 16-deep slabs) each lane multiplies its rows' accumulators by s_next / s_cur -- a power of
 // two, exact -- and the epilogue undoes the last chunk's scale.  The ratios sit in LDS behind the three stages (BM x k_chunks floats).
-template <int BM, int BN, int VARIANT, int EPI, int NP = 3, bool KS = false, bool CONV = false>
-__global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
+// NS = LDS stages of the DMA ring (NS - 1 slabs requested ahead of the one being multiplied).  The ring is what hides the operand
+// stream's latency: bytes in flight per CU / latency = fill rate, and with two fp16 pieces a slab is multiplied in half the time
+// three bf16 pieces took, so the same two slabs in flight cover half the time (profiles/r3_gemm_experiments.md)
+template <int BM, int BN, int VARIANT, int EPI, int NP = 3, bool KS = false, bool CONV = false, int NW = NWAVE, int NS = 3>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_tp3_kernel(Tp3Params p_in) {
     Tp3Params p = p_in;
     float* const stamp_buf = p_in.pre_out;
     if constexpr ((VARIANT & 32) != 0) p.pre_out = nullptr;
-    constexpr int WGM = 2, WGN = 4;
+    constexpr int NWAVE = NW, NTH = NW * 64;   // (shadow the 8-wave constants of the namespace)
+    constexpr int WGN = 4, WGM = NW / WGN;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(NS >= 3 && NS <= 6, "ring stages");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int BLKP = NP * PIECE;                                      // one 32 x 16 block of an operand image
@@ -302,6 +318,15 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     // CONV: the output pixel behind this lane's row of the wave's A pieces (only pieces 0 and 1 of a wave can be A pieces), and the
     // (tap, channel block) of the NEXT slab to be requested -- slabs are requested in order, conv_advance() after each
     static_assert(!CONV || PA <= 2 * NWAVE, "conv: at most two A pieces per wave");
+    // first-round stagger (speed only, never correctness): the workgroups that the dispatcher is observed to place SECOND on each CU
+    // (ids 256 .. 511 of the first wave of dispatches) start half a tile late, so that the two workgroups of a CU reach their
+    // epilogues at different times from then on
+    if constexpr (NW == 4) {
+        if (p.stagger_ticks > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(64);
+        }
+    }
     int cv_row[2] = {-1, -1}, cv_yx[2] = {0, 0};
     int cv_dy = -1, cv_dx = -1, cv_cb = 0;
     if constexpr (CONV) {
@@ -359,9 +384,9 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     const unsigned b_frag = lds0 + lane * 16 + PA * PIECE + wn * (TN * BLKP);
 
     // KS: ratio table R[row][c] = inv[row][c-1] / inv[row][c] (c >= 1) behind the stages, before any LDS-DMA is in flight
-    const unsigned ktab = lds0 + 3 * STAGE;
+    const unsigned ktab = lds0 + NS * STAGE;
     if constexpr (KS) {
-        float* tab = reinterpret_cast<float*>(smem + 3 * STAGE);
+        float* tab = reinterpret_cast<float*>(smem + NS * STAGE);
         const int nch = p.k_chunks;
         for (int e = threadIdx.x; e < BM * nch; e += NTH) {
             const int rl = e / nch, c = e - rl * nch;
@@ -371,11 +396,10 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
         }
         __syncthreads();
     }
-    // prologue: three slabs in flight, wait for the first
-    issue_next(0, 0);
-    if (nk > 1) issue_next(1, 1);
-    if (nk > 2) issue_next(2, 2);
-    wait_groups<PT>((nk < 3 ? nk : 3) - 1, extra);
+    // prologue: NS slabs in flight (the host guarantees nk > NS), wait for the first
+#pragma unroll
+    for (int i = 0; i < NS; ++i) issue_next(i, i);
+    wait_groups_ct<PT, NW, NS - 1>(extra);
     __builtin_amdgcn_s_barrier();
     stamp(1);
     Frags<TM, TN, NP> f0, f1;
@@ -398,7 +422,7 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     if constexpr (KS) kratio_request(1);
     auto step = [&]<int INFLIGHT, bool ISSUE, bool LAST>(StepMode<INFLIGHT, ISSUE, LAST>, int kt, int st_cur, Frags<TM, TN, NP>& cur,
                                                          Frags<TM, TN, NP>& nxt) {
-        if constexpr (!LAST && !ABL_NODMA) wait_groups<PT>(INFLIGHT, extra);   // this wave's pieces of slab kt+1 have landed
+        if constexpr (!LAST && !ABL_NODMA) wait_groups_ct<PT, NW, INFLIGHT>(extra);   // this wave's pieces of slab kt+1 have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // `cur` is complete and this wave no longer reads stage st_cur
         if constexpr (KS) {
             if ((kt & 3) == 0 && kt) {   // slab kt opens chunk kt / 4: bring the accumulators to its scale, request the next boundary's ratios
@@ -414,7 +438,7 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
         }
         if constexpr (!LAST) __builtin_amdgcn_s_barrier();        // ... nor does any other wave, and their pieces landed too
         __builtin_amdgcn_sched_barrier(0);
-        const int st_nxt = st_cur == 2 ? 0 : st_cur + 1;
+        const int st_nxt = st_cur == NS - 1 ? 0 : st_cur + 1;
         const unsigned a_addr = a_frag + st_nxt * STAGE, b_addr = b_frag + st_nxt * STAGE;
         // NMFMA MFMAs of slab kt.  The memory instructions ride between them so that the matrix pipe restarts right after the
         // barrier: the first NREAD MFMAs are each preceded by one fragment read of slab kt+1, and the PW DMA requests of slab
@@ -425,7 +449,7 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
             constexpr int q = decltype(idx)::value;
             if constexpr (!LAST && q < NREAD) read_one<TM, TN, NP, q>(nxt, a_addr, b_addr);
             if constexpr (ISSUE && !ABL_NODMA && DMA_SPREAD && q % DMA_EVERY == 1 && q / DMA_EVERY < PW)
-                issue_piece(std::integral_constant<int, q / DMA_EVERY>{}, kt + 3, st_cur);
+                issue_piece(std::integral_constant<int, q / DMA_EVERY>{}, kt + NS, st_cur);
             constexpr int pair = q % NPROD, ij = q / NPROD, i = ij / TN, j = ij % TN;
             if constexpr (NP == 3) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.b[j][PB_[pair]], cur.a[i][PA_[pair]], acc[i][j], 0, 0, 0);
@@ -435,31 +459,40 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
             }
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
         };
-        if constexpr (ISSUE && !ABL_NODMA && !DMA_SPREAD) issue(kt + 3, st_cur);
+        if constexpr (ISSUE && !ABL_NODMA && !DMA_SPREAD) issue(kt + NS, st_cur);
         [&]<int... Q>(std::integer_sequence<int, Q...>) { (body(std::integral_constant<int, Q>{}), ...); }(std::make_integer_sequence<int, NMFMA>{});
         if constexpr (ISSUE) conv_advance();
     };
-    using Steady = StepMode<1, true, false>;
-    using Drain1 = StepMode<1, false, false>;
-    using Drain0 = StepMode<0, false, false>;
-    using Last = StepMode<0, false, true>;
+    using Steady = StepMode<NS - 2, true, false>;
+    auto adv = [](int st) { return st == NS - 1 ? 0 : st + 1; };
 
-    // nk is even and >= 4 (K % 32 == 0, K >= 64): two slabs per trip, the last four peeled so that every wait count and
-    // every DMA request in the loop is unconditional
+    // nk is even and > NS (K % 32 == 0; the host picks NS): two slabs per trip while there is a slab kt + NS to request, then the
+    // NS last slabs peeled (straight-line: every wait count and every DMA request is unconditional).  nk - NS steady steps: their
+    // parity is NS's, so which register set holds the first peeled slab is known at compile time.
     int kt = 0, st = 0;
-    for (; kt < nk - 4; kt += 2) {
+    for (; kt + 1 < nk - NS; kt += 2) {
         step(Steady{}, kt, st, f0, f1);
-        st = st == 2 ? 0 : st + 1;
+        st = adv(st);
         step(Steady{}, kt + 1, st, f1, f0);
-        st = st == 2 ? 0 : st + 1;
+        st = adv(st);
     }
-    step(Steady{}, kt, st, f0, f1);          // kt = nk-4: requests the last slab
-    st = st == 2 ? 0 : st + 1;
-    step(Drain1{}, kt + 1, st, f1, f0);      // nk-3: awaits slab nk-2, slab nk-1 still in flight
-    st = st == 2 ? 0 : st + 1;
-    step(Drain0{}, kt + 2, st, f0, f1);      // nk-2: awaits slab nk-1
-    st = st == 2 ? 0 : st + 1;
-    step(Last{}, kt + 3, st, f1, f0);        // nk-1
+    if constexpr (NS % 2 == 1) {   // one more steady step: requests the last slab
+        step(Steady{}, kt, st, f0, f1);
+        st = adv(st);
+        ++kt;
+    }
+    // slab nk-NS+j awaits slab nk-NS+j+1 with NS-2-j younger groups still in flight; the last one awaits nothing
+    auto tail = [&]<int J>(auto&& self, std::integral_constant<int, J>, Frags<TM, TN, NP>& cur, Frags<TM, TN, NP>& nxt) {
+        if constexpr (J == NS - 1) {
+            step(StepMode<0, false, true>{}, kt + J, st, cur, nxt);
+        } else {
+            step(StepMode<NS - 2 - J, false, false>{}, kt + J, st, cur, nxt);
+            st = adv(st);
+            self(self, std::integral_constant<int, J + 1>{}, nxt, cur);
+        }
+    };
+    if constexpr (NS % 2 == 1) tail(tail, std::integral_constant<int, 0>{}, f1, f0);
+    else tail(tail, std::integral_constant<int, 0>{}, f0, f1);
 
     stamp(2);
     __syncthreads();  // every wave is past its last LDS read: the stages become epilogue scratch
@@ -477,17 +510,18 @@ __global__ __launch_bounds__(NTH) void gemm_tp3_kernel(Tp3Params p_in) {
     }
 }
 
-template <int BM, int BN, int VARIANT, int EPI, int NP = 3, bool KS = false, bool CONV = false>
+template <int BM, int BN, int VARIANT, int EPI, int NP = 3, bool KS = false, bool CONV = false, int NW = NWAVE, int NS = 3>
 int launch(const Tp3Params& p0, hipStream_t s) {
+    if (NS > 3 && (p0.K >> 4) <= NS) return launch<BM, BN, VARIANT, EPI, NP, KS, CONV, NW, 3>(p0, s);   // a ring deeper than the k-loop: the 3-stage one
     Tp3Params p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    constexpr size_t stage_bytes = (size_t)3 * (NP * (BM + BN) / 32) * PIECE;
-    constexpr size_t epi_bytes = (size_t)NWAVE * (BM / 2) * 37 * sizeof(float);
+    constexpr size_t stage_bytes = (size_t)NS * (NP * (BM + BN) / 32) * PIECE;
+    constexpr size_t epi_bytes = (size_t)NW * (BM / (NW / 4)) * 37 * sizeof(float);
     constexpr size_t ks_bytes = KS ? (size_t)BM * 64 * sizeof(float) : 0;   // ratio table: up to 64 chunks (K <= 4096)
     constexpr size_t smem = (stage_bytes + ks_bytes) > epi_bytes ? (stage_bytes + ks_bytes) : epi_bytes;
-    static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = gemm_tp3_kernel<BM, BN, VARIANT, EPI, NP, KS, CONV>;
+    static_assert(smem <= 160 * 1024 && (NW == 8 || smem <= 80 * 1024), "LDS budget (two 4-wave workgroups per CU)");
+    auto kern = gemm_tp3_kernel<BM, BN, VARIANT, EPI, NP, KS, CONV, NW, NS>;
     static int attr_dev_mask = 0;  // per device: the opt-in for > 64 KiB of dynamic LDS is a per-device function attribute
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1;
@@ -495,7 +529,7 @@ int launch(const Tp3Params& p0, hipStream_t s) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 1;
         attr_dev_mask |= 1 << dev;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long)p.tiles_m * p.tiles_n)), dim3(NTH), smem, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)p.tiles_m * p.tiles_n)), dim3(NW * 64), smem, s, p);
     return 0;
 }
 
@@ -529,3 +563,6 @@ inline int epi_code(const Tp3Params& p) {
 // per-tile translation units (parallel make): Tp3Params is TU-local, hence the opaque pointer
 int tvl_gemm_tp3_t128(const void* params, int epi, hipStream_t s);
 int tvl_gemm_tp3_t256(const void* params, int epi, hipStream_t s);
+int tvl_gemm_h2_w4(const void* params, int bm, int epi, hipStream_t s);   // gemm_h2_w4.hip: 4-wave workgroups, two per CU
+int tvl_gemm_h2_ns4(const void* params, int bm, int epi, hipStream_t s);  // gemm_h2_ns4.hip / _ns5.hip: deeper DMA rings
+int tvl_gemm_h2_ns5(const void* params, int bm, int epi, hipStream_t s);

@@ -14,7 +14,7 @@ from pathlib import Path
 import torch
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "csrc" / "libtvl_hip.so"
+LIB_PATH = Path(os.environ["TVL_HIP_LIB"]) if os.environ.get("TVL_HIP_LIB") else _HERE / "csrc" / "libtvl_hip.so"   # (override: a `make DIAG=1` build for the tools)
 
 NT, NN, TN = 0, 1, 2
 ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -606,7 +606,7 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
     ldc = Cf.stride(0) if Cf is not None else (pre_out.stride(0) if pre_out is not None else N)
     args = GemmTp3Args(M, N, K, A.buf.data_ptr(), A.rows, B.buf.data_ptr(), B.rows, _ps(Cf), ldc, None if Ct is None else Ct.buf.data_ptr(),
                        _p(bias), _ps(residual), 0 if residual is None else residual.stride(0), act, _ps(pre_out), _ps(dact_aux),
-                       0 if dact_aux is None else dact_aux.stride(0), dact, B.alpha(), tile_m, 0)
+                       0 if dact_aux is None else dact_aux.stride(0), dact, B.alpha(), tile_m, GEMM_TP3_VARIANT)
     if _gemm_prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -620,15 +620,29 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
     if _gemm_prof is not None:
         e1.record()
         _gemm_prof.append((h2_kernel_name(M, N, bias is not None, residual is not None, act, dact, pre_out is not None, Cf is not None,
-                                          Ct is not None, tile_m, Ch is not None), 2.0 * M * N * K, e0, e1))
+                                          Ct is not None, tile_m, Ch is not None, K=K), 2.0 * M * N * K, e0, e1))
     return Cf, (Ch if Ch is not None else Ct)
 
 
 _H2_EPI_BUILT = {192: {193, 161, 160, 192, 163, 385, 384, 673}, 256: {213, 197, 200, 405, 389, 392, 161, 673, 160}}   # launch_h2's compile-time epilogues per row tile (csrc/gemm_h2.hip)
 
 
-def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_m=0, c_h2=False) -> str:
+GEMM_M16 = os.environ.get("TVL_GEMM_M16", "1") != "0"   # the h2 ring GEMMs on v_mfma_f32_16x16x32_f16 (csrc/gemm_h2m_kernel.h); 0 = the 32x32x16 generation
+_H2M_EPI_BUILT = {385, 384, 163, 160, 405, 389, 392, 161, 673}   # launch_m_layer_epi's compile-time epilogues
+
+
+def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_m=0, c_h2=False, K=None) -> str:
     """Instantiation tvl_gemm_h2 launches, spelled as rocprofv3 prints it (NP = 2 as the last template argument)."""
+    if GEMM_M16 and (K is None or K >= 96) and tile_m in (0, 192, 256, 1926, 2566):
+        tile = {1926: 192, 2566: 256}.get(tile_m, tile_m)
+        if tile not in (192, 256):
+            t256, t192 = -(-M // 256) * -(-N // 256), -(-M // 192) * -(-N // 256)
+            tile = 256 if -(-t256 // 256) * 256 <= -(-t192 // 256) * 192 else 192
+        epi = (1 if bias else 0) | (2 if residual else 0) | (4 if (act & 0xFF) == ACT_QUICK_GELU else 0) | (512 if (act & 0xFF) == ACT_RELU else 0) | \
+              (8 if dact else 0) | (16 if pre_out else 0) | (32 if c_f32 else 0) | (64 if c_tp3 else 0) | 128 | (256 if c_h2 else 0)
+        if (act & ~0xFF) or (act & 0xFF) not in (ACT_NONE, ACT_QUICK_GELU, ACT_RELU) or epi not in _H2M_EPI_BUILT:
+            epi = -1
+        return f"gemm_h2m_kernel<{tile}, {epi}, false, false>"
     tile = tile_m
     if tile not in (192, 256):
         t256, t192 = -(-M // 256) * -(-N // 256), -(-M // 192) * -(-N // 256)
@@ -653,6 +667,8 @@ def conv_h2_kernel_name(M, N, bias, act) -> str:
     """Instantiation tvl_conv3x3_h2 launches (CONV = true as the last template argument)."""
     tile = conv_h2_tile(M, N)
     epi = 673 if (bias and act == ACT_RELU) else (160 if not (bias or act) else -1)
+    if GEMM_M16:
+        return f"gemm_h2m_kernel<{tile}, {epi}, false, true>"
     return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2, false, true>"
 
 
@@ -928,7 +944,7 @@ def gemm_h2_ks(A: H2K, B: H2, out: torch.Tensor | None = None) -> torch.Tensor:
     _call("tvl_gemm_h2_ks", C.byref(args), _p(A.kscale))
     if _gemm_prof is not None:
         e1.record()
-        _gemm_prof.append(("gemm_tp3_kernel<192, 256, 3, 160, 2, true, false>", 2.0 * M * N * K, e0, e1))
+        _gemm_prof.append(("gemm_h2m_kernel<192, 160, true, false>" if (GEMM_M16 and K >= 96) else "gemm_tp3_kernel<192, 256, 3, 160, 2, true, false>", 2.0 * M * N * K, e0, e1))
     return Cf
 
 
