@@ -243,7 +243,7 @@ def main():
         if "--batch" not in sys.argv:
             args.batch = 16
         T640, D640 = 1 + (640 // 16) ** 2, 768
-        layers = CLIPSegBackbone.from_spec("random:rd64:seed=0").to(device).prepared()["vision_layers"]
+        layers = CLIPSegBackbone.from_spec("random:rd64:seed=0").requires_grad_(False).to(device).prepared()["vision_layers"]
         spec = ops.AttnSpec(heads=12, act=hip.ACT_QUICK_GELU, eps=1e-5)
         g = torch.Generator().manual_seed(100 + rank)
         x640 = torch.randn(args.batch, T640, D640, generator=g).to(device).requires_grad_(True)

@@ -241,8 +241,10 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
         for k, p_ in net64.named_parameters():
             if p_.requires_grad and p_.grad is not None:
                 arrays["grad64." + k] = p_.grad.float().numpy()
-        if tails:
+        if tails and not compact:
             arrays["out.logits64"] = logits64.detach().float().numpy()
+        elif tails:
+            arrays["out.logits64_s11"] = logits64.detach().float()[..., ::11, ::11].contiguous().numpy()
         print(f"   f64: logits fp32-vs-fp64 {float((logits.detach().double() - logits64.detach()).abs().max()):.2e}; worst fp32 gradient "
               f"deviation {max(float((params[k].grad.double() - p_.grad).abs().max() / p_.grad.abs().max()) for k, p_ in net64.named_parameters() if p_.requires_grad and p_.grad is not None):.2e}")
     meta = {"name": name, "compact": compact, "preset": preset, "eos_token_id": eos, "weight_seed": wseed, "tails": tails, "net": net_kind,
@@ -449,7 +451,7 @@ def main():
     run_case("rd64_vpt_n10_d1_tails2", eos=2, wseed=21, net_kind="vpt", iseed=27, tails=2,
              learner_kw=dict(prompt_depth=1, num_context=10, vector_std=0.02), net_kw=base_old, with_f64=True, **F_)
     run_case("rd64_vpt_n10_d1_b32_tails", eos=2, wseed=21, net_kind="vpt", iseed=3, tails=1,
-             learner_kw=dict(prompt_depth=1, num_context=10, vector_std=0.02), net_kw=base_old, **FB)
+             learner_kw=dict(prompt_depth=1, num_context=10, vector_std=0.02), net_kw=base_old, with_f64=True, **FB)
 
     # --- CRIS (BASELINE configs[2]; reference coop_cris.py) ---------------------------------------------------------
     init = dict(context_initializer="a photo of a", _init_ids=[5, 9, 7, 5])

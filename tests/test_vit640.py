@@ -23,7 +23,7 @@ def setup():
     from tunevlseg_amd.ops import AttnSpec
 
     hip.load()
-    bb = CLIPSegBackbone.from_spec("random:rd64:seed=21").cuda()
+    bb = CLIPSegBackbone.from_spec("random:rd64:seed=21").requires_grad_(False).cuda()   # frozen tower: data gradients only
     layers = bb.prepared()["vision_layers"][:LAYERS]
     spec = AttnSpec(heads=HEADS, act=hip.ACT_QUICK_GELU, eps=1e-5)
     g = torch.Generator().manual_seed(640)

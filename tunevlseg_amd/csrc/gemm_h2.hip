@@ -310,9 +310,9 @@ static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void*
     p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha; p.a_scale = a_row_scale; p.a_sstride = conv ? 0 : 1;
     p.Ch2 = reinterpret_cast<unsigned char*>(c_h2); p.out_norm = out_row_norm; p.out_mul = out_mul; p.out_add = out_add; p.out_inv = out_inv_scale; p.out_stride = out_per_tensor ? 0 : 1;
     int bm = a->tile_m;
+    static const int stagger_us = getenv("TVL_GEMM_STAGGER_US") ? atoi(getenv("TVL_GEMM_STAGGER_US")) : 0;   // experiment knob
+    p.stagger_ticks = stagger_us * 100;
     if (bm == 128 && !conv) {
-        static const int stagger_us = getenv("TVL_GEMM_STAGGER_US") ? atoi(getenv("TVL_GEMM_STAGGER_US")) : 0;   // experiment knob
-        p.stagger_ticks = stagger_us * 100;
     } else if (bm != 256 && bm != 192 && bm != 2564 && bm != 2565 && bm != 1924 && bm != 1925 && bm != 2566 && bm != 1926 && bm != 2560 && bm != 1920) {
         const long t256 = ((long)(a->M + 255) / 256) * ((a->N + 255) / 256), t192 = ((long)(a->M + 191) / 192) * ((a->N + 255) / 256);
         bm = ((t256 + 255) / 256) * 256 <= ((t192 + 255) / 256) * 192 ? 256 : 192;   // rounds x rows per tile; ties go to the larger tile

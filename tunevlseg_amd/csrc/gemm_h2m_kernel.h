@@ -96,6 +96,14 @@ __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
     const int in_group = bid - group * gsize_full;
     const int tile_m = gm0 + in_group % gm, tile_n = in_group / gm;
 
+    // De-phasing (speed only): every workgroup of the first dispatch round starts after its own pseudo-random share of `stagger_ticks`,
+    // so that CUs reach their epilogues -- 256 to 640 KB of stores each -- at different times instead of as one chip-wide HBM burst per
+    // round; later rounds inherit the offsets (a workgroup starts when a CU frees up).
+    if (p.stagger_ticks > 0 && blockIdx.x < 256) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long d = ((unsigned long long)p.stagger_ticks * ((blockIdx.x * 97u) & 255u)) >> 8;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;

@@ -21,6 +21,18 @@ from ..backbone import CLIPSegBackbone
 
 _ACT = hip.ACT_IDS
 
+import os  # noqa: E402
+
+TEXT_SIDE_STREAM = os.environ.get("TVL_TEXT_STREAM", "1") != "0"   # VPT: the gradient-free text tower on a second HIP stream
+_SIDE: dict = {}
+
+
+def side_stream(device) -> torch.cuda.Stream:
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=key)
+    return _SIDE[key]
+
 
 def patch_embeddings(model: CLIPSegBackbone, pixel_values: torch.Tensor) -> torch.Tensor:
     """16x16/s16 patch conv as im2col + GEMM (HF:195-197).  Frozen, image carries no grad -> no autograd node."""
