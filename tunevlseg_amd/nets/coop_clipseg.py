@@ -31,7 +31,18 @@ class COOPCLIPSeg(BaseCLIPSeg):
                       conditional_embeddings=None, **_unused) -> SegOutput:
         if pixel_values is None:
             raise ValueError("You have to specify pixel_values to use `CLIPSegForImageSegmentation`")
-        activations, pooled_output = self.get_vision_outputs(pixel_values)
+        from .context_learner import CoCoOpContextLearner
+
+        if conditional_embeddings is None and input_ids is not None and len(input_ids) == pixel_values.shape[0] \
+                and not isinstance(self.context_learner, CoCoOpContextLearner):
+            # plain CoOp: the text tower does not read the image features -> it runs beside the (gradient-free) vision tower
+            side = towers.SideStream(pixel_values.device)
+            with side:
+                conditional_embeddings = self.get_text_features(input_ids, attention_mask, image_features=None)
+            activations, pooled_output = self.get_vision_outputs(pixel_values)
+            side.join(conditional_embeddings)
+        else:
+            activations, pooled_output = self.get_vision_outputs(pixel_values)
         if conditional_embeddings is None:
             if input_ids is None:
                 raise ValueError("Invalid conditional, should be either provided as `input_ids` or `conditional_pixel_values`")

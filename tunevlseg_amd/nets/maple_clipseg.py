@@ -9,6 +9,11 @@ from .hf_clipseg_wrapper import SegOutput
 
 
 class BaseMultimodalCLIPSeg(BaseCLIPSeg):
+    # MaPLe's two towers read the shared prompts independently (text: ctx[idx]; vision: proj_idx(ctx[idx])): the text tower may run
+    # beside the vision tower on the side stream.  The shared-attention learners hand a cached half from the vision pass to the text
+    # pass (shared_attn_learner.py:89-90): they keep the reference's sequential order.
+    TEXT_BESIDE_VISION = False
+
     def get_vision_outputs(self, pixel_values: torch.Tensor):
         acts, _ = towers.vision_tower(self.model, pixel_values, self.context_learner)
         return acts
@@ -25,6 +30,15 @@ class BaseMultimodalCLIPSeg(BaseCLIPSeg):
         if pixel_values is None:
             raise ValueError("You have to specify pixel_values to use `CLIPSegForImageSegmentation`")
         # vision first, then text (base_multimodal_clipseg.py:577-596)
+        if conditional_embeddings is None and self.TEXT_BESIDE_VISION:
+            side = towers.SideStream(pixel_values.device)
+            with side:
+                conditional_embeddings = self.get_conditional_embeddings(pixel_values.shape[0], input_ids, attention_mask)
+            activations = self.get_vision_outputs(pixel_values)
+            side.join(conditional_embeddings)
+            out = self.decoder_forward(activations, conditional_embeddings)
+            out.conditional_embeddings = conditional_embeddings
+            return out
         activations = self.get_vision_outputs(pixel_values)
         if conditional_embeddings is None:
             conditional_embeddings = self.get_conditional_embeddings(pixel_values.shape[0], input_ids, attention_mask)
@@ -36,6 +50,8 @@ class BaseMultimodalCLIPSeg(BaseCLIPSeg):
 
 
 class MapleCLIPSeg(BaseMultimodalCLIPSeg):
+    TEXT_BESIDE_VISION = True
+
     def __init__(self, context_learner, *args, **kwargs) -> None:
         super().__init__(*args, **kwargs)
         cfg = self.model.config

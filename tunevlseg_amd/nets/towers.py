@@ -34,6 +34,40 @@ def side_stream(device) -> torch.cuda.Stream:
     return _SIDE[key]
 
 
+class SideStream:
+    """``with SideStream(device) as s: y = f(...)`` runs ``f`` on the second HIP stream of the device (after everything already enqueued
+    on the current one); ``s.join(y)`` makes the current stream wait for it and tells the allocator that ``y`` lives on.  The text tower
+    (M = B * L rows: launch-latency-bound kernels on a fraction of the CUs) and the vision tower (chip-filling kernels with bubbles at
+    every round's tail) share nothing until the decoder; autograd replays each node on its forward stream, so the backward overlaps too.
+    No-op on CPU tensors or with TVL_TEXT_STREAM=0."""
+
+    def __init__(self, device):
+        self.on = TEXT_SIDE_STREAM and torch.device(device).type == "cuda"
+        self.device = device
+        self._ctx = None
+
+    def __enter__(self):
+        if self.on:
+            self.cur = torch.cuda.current_stream(self.device)
+            self.side = side_stream(self.device)
+            self.side.wait_stream(self.cur)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.on:
+            self.cur.wait_stream(self.side)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.cur)
+
+
 def patch_embeddings(model: CLIPSegBackbone, pixel_values: torch.Tensor) -> torch.Tensor:
     """16x16/s16 patch conv as im2col + GEMM (HF:195-197).  Frozen, image carries no grad -> no autograd node."""
     prep = model.prepared()

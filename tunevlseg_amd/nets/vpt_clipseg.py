@@ -80,7 +80,7 @@ class VPTCLIPSeg(BaseCLIPSeg):
         if pixel_values is None:
             raise ValueError("You have to specify pixel_values to use `CLIPSegForImageSegmentation`")
         # step 1: conditional embeddings from the frozen text tower, no grad (HF get_conditional_embeddings, HF:972-999)
-        on_side_stream = False
+        side = None
         if conditional_embeddings is None:
             if input_ids is None:
                 raise ValueError("Invalid conditional, should be either provided as `input_ids` or `conditional_pixel_values`")
@@ -88,25 +88,18 @@ class VPTCLIPSeg(BaseCLIPSeg):
                 raise ValueError("Make sure to pass as many prompt texts as there are query images")
             if self.cache_text_features:
                 conditional_embeddings = self.cached_conditional_embeddings(input_ids, attention_mask)
-            elif pixel_values.is_cuda and towers.TEXT_SIDE_STREAM:
+            else:
                 # the frozen text tower (84 launch-latency-bound kernels at M = B * L rows, no gradient) shares nothing with the vision
                 # tower until the decoder's FiLM: it runs on a side stream, in the bubbles of the vision tower's chip-filling kernels
-                cur = torch.cuda.current_stream(pixel_values.device)
-                side = towers.side_stream(pixel_values.device)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side), torch.no_grad():
-                    conditional_embeddings = towers.text_tower(self.model, input_ids, attention_mask)
-                on_side_stream = True
-            else:
-                with torch.no_grad():
+                side = towers.SideStream(pixel_values.device)
+                with side, torch.no_grad():
                     conditional_embeddings = towers.text_tower(self.model, input_ids, attention_mask)
         elif conditional_embeddings.shape[0] != pixel_values.shape[0]:
             raise ValueError("Make sure to pass as many conditional embeddings as there are query images in the batch")
         # step 2: vision tower with the visual prompts appended
         activations = self.get_vision_outputs(pixel_values)
-        if on_side_stream:   # the decoder is the first consumer of the side stream's result
-            torch.cuda.current_stream(pixel_values.device).wait_stream(towers.side_stream(pixel_values.device))
-            conditional_embeddings.record_stream(torch.cuda.current_stream(pixel_values.device))
+        if side is not None:   # the decoder is the first consumer of the side stream's result
+            side.join(conditional_embeddings)
         # step 3: decoder
         out = self.decoder_forward(activations, conditional_embeddings)
         out.conditional_embeddings = conditional_embeddings
