@@ -211,6 +211,16 @@ int tvl_dicece_bwd(const float* logits, const float* target, const double* fsum,
  * tvl_mask_u8: mask [n] uint8 -> float / 255 (reference image_text_mask_dataset.py:66-71). */
 int tvl_normalize_u8(const uint8_t* img, float* out, int32_t B, int32_t H, int32_t W, const float* mean3, const float* std3, tvlStream_t stream);
 int tvl_mask_u8(const uint8_t* mask, float* out, int64_t n, tvlStream_t stream);
+/* tvl_resize_u8: albumentations.Resize of the WHOLE ragged batch (reference configs/experiment/coop/clipseg.yaml:80-84): image b =
+ *   hw[2b] x hw[2b+1] x C uint8 at packed + offs[b] (device arrays) -> out [B,H,W,C] uint8.  mode 2 = cv2.INTER_CUBIC (OpenCV's 8-bit
+ *   fixed-point definition), mode 0 = cv2.INTER_NEAREST (masks).
+ * tvl_augment_u8: Affine (p-gated, cubic / nearest, BORDER_REPLICATE) + RandomBrightnessContrast + Normalize + ToTensorV2
+ *   (clipseg.yaml:85-120) in one pass: img [B,H,W,3] uint8, mask [B,H,W] uint8 or null, params [B,8] = inverse affine 2x3 (dst -> src),
+ *   alpha, beta; flags [B] bit 0 warp, bit 1 brightness/contrast; host-pointer mean3 / std3 -> out_img [B,3,H,W], out_mask [B,1,H,W] (/255). */
+int tvl_resize_u8(const uint8_t* packed, const int64_t* offs, const int32_t* hw, int32_t B, int32_t C, int32_t H, int32_t W, int32_t mode,
+                  uint8_t* out, tvlStream_t stream);
+int tvl_augment_u8(const uint8_t* img, const uint8_t* mask, const float* params, const int32_t* flags, const float* mean3, const float* std3,
+                   float* out_img, float* out_mask, int32_t B, int32_t H, int32_t W, tvlStream_t stream);
 
 /* last-layer mix with the TRAINABLE residual_ratio read on the device (reference base_clipseg.py:150-155, coop_cris.py:240-242):
  * out = (1 - ratio[0]) * main + ratio[0] * extra;   y = (one_minus ? 1 - ratio[0] : ratio[0]) * x  (its gradient passes).

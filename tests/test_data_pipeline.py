@@ -148,3 +148,147 @@ def test_device_batch_prep_equals_the_host_transform(tmp_path, toy_tokenizer):
     assert out["image"].shape == (3, 3, 32, 32) and (out["image"].cpu() - ref_img).abs().max().item() <= 1e-6
     assert torch.equal(out["mask"].cpu(), (batch["mask"].float() / 255)[:, None])
     assert out["input_ids"].is_cuda and out["mask_name"] == batch["mask_name"]
+
+
+# ---- device-side transforms (reference configs/experiment/coop/clipseg.yaml:78-120) -------------------------------------------------
+def test_oracle_cubic_resize_known_answers():
+    """Hand-derived vectors of OpenCV's 8-bit INTER_CUBIC definition (A = -0.75, half-pixel centres, 11-bit weights, replicate border).
+    Doubling the width puts every output at fraction 0.25 / 0.75: weights (-216, 1800, 536, -72) / 2048 and their mirror.  Row
+    [0, 100, 200, 255] -> e.g. x = 3: taps (0, 100, 200, 255) . (-216, 1800, 536, -72) = 268840 -> 131.27 -> 131.  "Unpinned": derived from
+    the published algorithm, cv2 itself is absent."""
+    import numpy as np
+
+    from oracle import augment_oracle as A
+
+    w = A.cubic_weights(np.array([0.25, 0.75, 0.0], np.float32))
+    assert np.array_equal(np.rint(w.astype(np.float64) * 2048), [[-216, 1800, 536, -72], [-72, 536, 1800, -216], [0, 2048, 0, 0]])
+    row = np.array([[0, 100, 200, 255]], np.uint8)
+    assert A.resize_cubic_u8(row, 1, 8).tolist() == [[0, 19, 67, 131, 175, 223, 246, 255]]
+    img = np.random.default_rng(0).integers(0, 256, (9, 7, 3), dtype=np.uint8)
+    assert np.array_equal(A.resize_cubic_u8(img, 9, 7), img)                       # same size: every fraction is 0
+    assert np.array_equal(A.resize_cubic_u8(np.full((5, 6, 3), 77, np.uint8), 11, 13), np.full((11, 13, 3), 77, np.uint8))   # weights sum to 2048
+    m = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    assert A.resize_nearest_u8(m, 6, 8).tolist() == np.repeat(np.repeat(m, 2, 0), 2, 1).tolist()   # floor(d * 0.5): each pixel twice
+    assert A.resize_nearest_u8(m, 2, 3).tolist() == [[0, 1, 2], [4, 5, 6]]                          # floor(d * 1.5 / d * 1.33)
+    # brightness / contrast table: clip(v * 1.1 + 0.05 * 255) truncated
+    lut = A.brightness_contrast_u8(np.arange(256, dtype=np.uint8), 1.1, 0.05)
+    assert lut[0] == 12 and lut[100] == 122 and lut[255] == 255
+    # identity affine parameters give the identity matrix; a pure translation moves the content with replicate padding
+    assert np.allclose(A.affine_matrix(10, 20, 1, 1, 0, 0, 0), [[1, 0, 0], [0, 1, 0]])
+    M = A.affine_matrix(4, 4, 1, 1, 0, 0.25, 0)   # one pixel to the right
+    g = np.arange(16, dtype=np.uint8).reshape(4, 4) * 10
+    assert A.warp_affine_nearest_u8(g, A.invert_affine(M)).tolist() == [[0, 0, 10, 20], [40, 40, 50, 60], [80, 80, 90, 100], [120, 120, 130, 140]]
+    assert A.warp_affine_cubic_u8(g, A.invert_affine(M)).tolist() == A.warp_affine_nearest_u8(g, A.invert_affine(M)).tolist()   # integer shift: exact
+
+
+def test_shard_sampler_partitions_like_a_distributed_sampler():
+    from tunevlseg_amd.data import ShardSampler
+
+    n = 11
+    for shuffle in (False, True):
+        shards = []
+        for r in range(2):
+            s = ShardSampler(n, 2, r, shuffle, seed=5)
+            s.set_epoch(3)
+            shards.append(list(s))
+        assert len(shards[0]) == len(shards[1]) == 6                       # padded by wrap-around: same number of steps on every rank
+        assert set(shards[0]) | set(shards[1]) == set(range(n))            # together they cover the dataset
+        assert len(set(shards[0]) & set(shards[1])) <= 1                   # the only overlap is the one padding sample
+    a, b = ShardSampler(n, 2, 0, True, seed=5), ShardSampler(n, 2, 0, True, seed=5)
+    a.set_epoch(0), b.set_epoch(1)
+    assert list(a) != list(b) and sorted(list(ShardSampler(n, 1, 0, True, seed=1))) == list(range(n))
+    assert list(ShardSampler(4, 2, 1, False)) == [1, 3] and len(ShardSampler(11, 2, 0, True, drop_last=True)) == 5
+    with pytest.raises(ValueError):
+        ShardSampler(4, 2, 2, False)
+
+
+def test_reference_data_config_instantiates_the_device_pipeline(tmp_path, toy_tokenizer, monkeypatch):
+    """``experiment=coop/clipseg`` of the reference's OWN config tree: cfg.data -> ImageTextDatamodule over ImageTextMaskDataset with the
+    albumentations list as a device plan (Resize INTER_CUBIC -> Affine p 0.2 -> RandomBrightnessContrast p 0.2 -> Normalize)."""
+    ref = Path("/root/reference/configs")
+    if not ref.exists():
+        pytest.skip("the reference's config tree is not on this machine")
+    from tunevlseg_amd import config_loader as CL
+    from tunevlseg_amd.data import Compose, ImageTextDatamodule, ImageTextMaskDataset
+
+    root = tmp_path / "kvasir"
+    root.mkdir()
+    _write_toy_dataset(root)
+    (root / "anns").mkdir()
+    for split in ("train", "val", "test"):
+        (root / "anns" / f"{split}.json").write_text((root / "anns.json").read_text())
+    monkeypatch.setenv("TVL_CLIP_BPE", str(toy_tokenizer.bpe_path))
+    cfg = CL.Composer(ref).compose("train", ["experiment=coop/clipseg", f"data_root={tmp_path}", "ds_name=kvasir", "prompt_index=1",
+                                             "data.batch_size=2", "data.num_workers=0"])
+    dm = CL.instantiate(CL.select(cfg, "data"))
+    assert isinstance(dm, ImageTextDatamodule) and isinstance(dm.train_ds, ImageTextMaskDataset) and len(dm.train_ds) == 3
+    plan = dm.train_ds.transforms.plan()
+    assert isinstance(dm.train_ds.transforms, Compose) and plan["size"] == (352, 352)
+    assert plan["affine"].p == 0.2 and plan["affine"].rotate == (-5.0, 5.0) and plan["affine"].scale == (0.98, 1.02) and plan["bc"].p == 0.2
+    assert plan["normalize"].mean == (0.485, 0.456, 0.406)
+    ev = dm.val_ds.transforms.plan()
+    assert ev["affine"] is None and ev["bc"] is None and ev["size"] == (352, 352)
+    item = dm.train_ds[1]   # decoded, untouched: the transforms run on the device per batch
+    assert item["image"].shape == (17, 17, 3) and item["prompt"] == "polyp number 1."
+    dm.setup("fit", world_size=2, rank=1, device="cpu")
+    assert dm.batch_size_per_device == 1
+    with pytest.raises(ValueError, match="not divisible"):
+        ImageTextDatamodule(train_ds=dm.train_ds, batch_size=3).setup("fit", world_size=2, rank=0)
+
+
+@pytest.mark.gpu
+def test_device_resize_and_augment_equal_the_cpu_restatement(tmp_path, toy_tokenizer):
+    """tvl_resize_u8 (cubic / nearest over a ragged batch) and tvl_augment_u8 (affine warp + brightness / contrast + normalise) against
+    oracle/augment_oracle.py on the same inputs and the same random draws: the integer paths bit for bit, the float warp to one grey level."""
+    import numpy as np
+
+    from oracle import augment_oracle as A
+    from tunevlseg_amd import hip
+    from tunevlseg_amd.data import ImageTextMaskDataset, PadToLongestCollator, RaggedCollator
+    from tunevlseg_amd.data import transforms as T
+
+    _write_toy_dataset(tmp_path)
+    S = 48
+    comp = T.Compose([T.Resize(S, S, interpolation=2), T.Affine(scale=[0.9, 1.1], translate_percent=[-0.05, 0.05], rotate=[-15, 15], interpolation=2, mode=1, p=0.7),
+                      T.PadIfNeeded(S, S, border_mode=1), T.CropNonEmptyMaskIfExists(S, S), T.RandomBrightnessContrast(0.2, 0.2, p=0.7),
+                      T.Normalize(), T.ToTensorV2(transpose_mask=True)])
+    ds = ImageTextMaskDataset(image_dir=tmp_path / "images", mask_dir=tmp_path / "masks", task_path=tmp_path / "anns.json", prompt_index=1,
+                              tokenizer=toy_tokenizer, transforms=comp)
+    batch = RaggedCollator(PadToLongestCollator(pad_token_id=toy_tokenizer.eos_token_id))([ds[i] for i in range(3)])
+    assert batch["image_hw"].tolist() == [[20, 30], [17, 17], [40, 24]] and batch["image_bytes"].numel() == 3 * (600 + 289 + 960)
+    dt = T.DeviceTransform(comp, "cuda", seed=3)
+    dt.set_epoch(0, 3, 0)
+    out = dt(batch)
+    # the same draws on the host
+    rng = np.random.default_rng([3, 0, 0])
+    nz = comp.plan()["normalize"]
+    for b in range(3):
+        item = ds[b]
+        img = A.resize_cubic_u8(item["image"].numpy(), S, S)
+        msk = A.resize_nearest_u8(item["mask"].numpy(), S, S)
+        if rng.random() < 0.7:
+            Minv = comp.plan()["affine"].sample(rng, S, S)
+            img_w, msk = A.warp_affine_cubic_u8(img, Minv), A.warp_affine_nearest_u8(msk, Minv)
+        else:
+            img_w = img
+        warped = img_w is not img
+        if rng.random() < 0.7:
+            al, be = comp.plan()["bc"].sample(rng)
+            img_w = A.brightness_contrast_u8(img_w, np.float32(al), np.float32(be))
+        ref = torch.from_numpy(A.normalize_chw(img_w, nz.mean, nz.std))
+        got = out["image"][b].cpu()
+        step = (1 / 255) / min(nz.std)   # one grey level after normalisation
+        diff = (got - ref).abs()
+        if warped:
+            assert diff.max().item() <= 1.3 * step and (diff > 1e-6).float().mean().item() < 0.02, (b, diff.max().item())
+        else:
+            assert diff.max().item() <= 1e-6, (b, diff.max().item())
+        mm = (out["mask"][b, 0].cpu() - torch.from_numpy(msk.astype(np.float32) / 255)).abs()
+        assert (mm > 0).float().mean().item() <= (0.01 if warped else 0.0)
+    # the resize alone, every sample, bit for bit
+    hw = batch["image_hw"]
+    px = hw[:, 0].long() * hw[:, 1].long()
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64), px.cumsum(0)[:-1]])
+    r = hip.resize_u8(batch["image_bytes"].cuda(), (3 * offs).cuda(), hw.cuda(), 3, S, S, hip.INTER_CUBIC).cpu().numpy()
+    for b in range(3):
+        assert np.array_equal(r[b], A.resize_cubic_u8(ds[b]["image"].numpy(), S, S))

@@ -214,3 +214,115 @@ def test_two_rank_step_on_hip_path_equals_global_batch_step(tmp_path):
         assert torch.equal(two["params"][k], other["params"][k]), f"ranks diverged on {k}"
         err = (two["params"][k] - one["params"][k]).abs().max().item()
         assert err <= 2e-3 * 2e-2, f"{k}: {err:.3e}"  # Adam's first steps move every entry by ~lr: compare against lr (as above)
+
+
+def test_train_entry_point_fits_from_a_directory_in_the_reference_layout(tmp_path, monkeypatch):
+    """``python -m tunevlseg_amd.train experiment=...`` end to end: a config tree with the reference's structure whose ``data`` node is
+    the reference's datamodule schema (``configs/data/image_text_mask.yaml``) over a toy dataset in the reference's wire format
+    (images/, masks/, anns/{train,val,test}.json) -> cfg.data is instantiated, decoded samples are resized / augmented / normalised on
+    the device, fit + test run.  A config WITHOUT a buildable data node raises instead of training on synthetic batches."""
+    import gzip
+    import json
+
+    import numpy as np
+    from PIL import Image
+
+    from tests.test_config_loader import write
+    from tunevlseg_amd import config_loader as CL
+    from tunevlseg_amd import train as T
+    from tunevlseg_amd.data.tokenizer import N_MERGES
+
+    root = tmp_path / "data" / "toy"
+    for d in ("images", "masks", "anns"):
+        (root / d).mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    tasks = []
+    for i in range(6):
+        h, w = int(rng.integers(40, 90)), int(rng.integers(40, 90))
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        m = np.zeros((h, w), np.uint8)
+        m[h // 4: h // 2, w // 4: 3 * w // 4] = 255
+        img[m > 0] = (img[m > 0] // 4 + 190).astype(np.uint8)   # a bright box: something to learn
+        Image.fromarray(img).save(root / "images" / f"im{i}.png")
+        Image.fromarray(m).save(root / "masks" / f"m{i}.png")
+        tasks.append({"img_name": f"im{i}.png", "mask_name": f"m{i}.png", "prompts": {"p0": "", "p1": "a bright box"}})
+    for split in ("train", "val", "test"):
+        (root / "anns" / f"{split}.json").write_text(json.dumps(tasks))
+    bpe = tmp_path / "merges.txt.gz"
+    with gzip.open(bpe, "wt", encoding="utf-8") as fh:
+        fh.write("#version: toy\n" + "\n".join(f"¤{i} ¤{i}" for i in range(N_MERGES)) + "\n")
+    monkeypatch.setenv("TVL_CLIP_BPE", str(bpe))
+
+    cfgdir = tmp_path / "configs"
+    write(cfgdir / "train.yaml", "# @package _global_\ndefaults:\n  - _self_\n  - data: image_text_mask\n  - model: vpt\n  - trainer: default\n"
+                                 "  - experiment: null\ntask_name: train\ntrain: true\ntest: true\nseed: 7\n")
+    write(cfgdir / "trainer" / "default.yaml", "max_epochs: 2\nmin_epochs: 1\naccumulate_grad_batches: 1\ncheck_val_every_n_epoch: 1\n")
+    write(cfgdir / "model" / "vpt.yaml", """_target_: src.models.image_text_mask_module.ImageTextMaskModule
+net:
+  _target_: src.models.core_models.coop.VPTCLIPSeg
+  model_cfg: {pretrained_model_name_or_path: "random:tiny:seed=11", freeze_encoder: false, freeze_decoder: false}
+  context_learner: {_target_: src.models.core_models.coop.context_learner.VPTContextLearner, _partial_: true, prompt_depth: 2, num_context: 4, vector_std: 0.02}
+  freeze_all: true
+  use_new_last_layer: true
+loss_fn: {_target_: monai.losses.DiceCELoss, sigmoid: true, lambda_dice: 1, lambda_ce: 0.2}
+weight_decay: 0.0
+optimizer: {_target_: torch.optim.AdamW, _partial_: true, lr: 1.0e-2}
+scheduler: null
+compile: false
+task: binary
+threshold: 0.5
+""")
+    ds = lambda split, tf: f"""  _target_: src.data.core_datasets.ImageTextMaskDataset
+  image_dir: ${{dataset_root}}/images
+  mask_dir: ${{dataset_root}}/masks
+  task_path: ${{dataset_root}}/anns/{split}.json
+  tokenizer_pretrained_path: ${{tokenizer_pretrained_path}}
+  prompt_index: ${{prompt_index}}
+  override_prompt: null
+  transforms: ${{{tf}}}
+  model_max_length: null
+  return_tensors: pt
+  collate_fn: ${{collate_fn}}
+  insert_stop_at_last: true
+"""  # noqa: E731
+    write(cfgdir / "data" / "image_text_mask.yaml", "_target_: src.data.image_text_mask_datamodule.ImageTextDatamodule\ntrain_ds:\n" + ds("train", "train_transforms")
+          + "val_ds:\n" + ds("val", "val_transforms") + "test_ds:\n" + ds("test", "val_transforms") + "batch_size: 4\nnum_workers: 0\ndrop_last: false\npin_memory: false\n")
+    write(cfgdir / "experiment" / "toy.yaml", f"""# @package _global_
+data_root: {tmp_path / 'data'}
+ds_name: toy
+dataset_root: ${{data_root}}/${{ds_name}}
+tokenizer_pretrained_path: CIDAS/clipseg-rd64
+prompt_index: 1
+img_size: 64
+train_transforms:
+  _target_: albumentations.Compose
+  transforms:
+    - {{_target_: albumentations.Resize, height: "${{img_size}}", width: "${{img_size}}", interpolation: "${{import_eval:cv2.INTER_CUBIC}}"}}
+    - {{_target_: albumentations.Affine, scale: [0.98, 1.02], translate_percent: [-0.02, 0.02], rotate: [-5, 5], interpolation: "${{import_eval:cv2.INTER_CUBIC}}", mode: "${{import_eval:cv2.BORDER_REPLICATE}}", p: 0.5}}
+    - {{_target_: albumentations.PadIfNeeded, min_height: "${{img_size}}", min_width: "${{img_size}}", border_mode: "${{import_eval:cv2.BORDER_REPLICATE}}"}}
+    - {{_target_: albumentations.CropNonEmptyMaskIfExists, width: "${{img_size}}", height: "${{img_size}}"}}
+    - {{_target_: albumentations.RandomBrightnessContrast, contrast_limit: 0.1, brightness_limit: 0.1, p: 0.5}}
+    - {{_target_: albumentations.Normalize, mean: [0.485, 0.456, 0.406], std: [0.229, 0.224, 0.225]}}
+    - {{_target_: albumentations.pytorch.ToTensorV2, transpose_mask: true}}
+val_transforms:
+  _target_: albumentations.Compose
+  transforms:
+    - {{_target_: albumentations.Resize, height: "${{img_size}}", width: "${{img_size}}", interpolation: "${{import_eval:cv2.INTER_CUBIC}}"}}
+    - {{_target_: albumentations.Normalize, mean: [0.485, 0.456, 0.406], std: [0.229, 0.224, 0.225]}}
+    - {{_target_: albumentations.pytorch.ToTensorV2, transpose_mask: true}}
+collate_fn:
+  _target_: src.data.components.data_collator.CustomDataCollatorWithPadding
+  tokenizer: {{_target_: transformers.AutoTokenizer.from_pretrained, pretrained_model_name_or_path: "${{tokenizer_pretrained_path}}"}}
+  padding_keys: ["input_ids", "attention_mask"]
+  padding: true
+paths: {{output_dir: {tmp_path / 'out'}}}
+""")
+    cfg = CL.Composer(cfgdir).compose("train", ["experiment=toy"])
+    metrics = T.train(cfg)
+    assert {"train_loss", "val_loss", "val_dice", "test_dice", "test_iou"} <= set(metrics), sorted(metrics)
+    assert all(np.isfinite(v) for v in metrics.values())
+    # no data node -> a loud error, not synthetic batches
+    cfg2 = CL.Composer(cfgdir).compose("train", ["experiment=toy"])
+    cfg2["data"] = {"batch_size": 4}
+    with pytest.raises(ValueError, match="no buildable `data` node"):
+        T.train(cfg2)

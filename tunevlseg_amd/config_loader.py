@@ -35,6 +35,14 @@ TARGET_MAP = {
     "monai.losses.DiceCELoss": "tunevlseg_amd.task.DiceCELoss",
     "torch.optim.AdamW": "tunevlseg_amd.task.FusedAdamW",
     "torch.optim.lr_scheduler.ReduceLROnPlateau": "tunevlseg_amd.task.ReduceLROnPlateau",
+    # input side (configs/data/image_text_mask.yaml, configs/experiment/**: train_transforms / collate_fn)
+    "src.data.image_text_mask_datamodule.ImageTextDatamodule": "tunevlseg_amd.data.datamodule.ImageTextDatamodule",
+    "src.data.core_datasets.ImageTextMaskDataset": "tunevlseg_amd.data.dataset.ImageTextMaskDataset",
+    "src.data.core_datasets.ImageDirTextMaskDataset": "tunevlseg_amd.data.dataset.ImageDirTextMaskDataset",
+    "src.data.components.data_collator.CustomDataCollatorWithPadding": "tunevlseg_amd.data.collate.PadToLongestCollator",
+    "transformers.AutoTokenizer.from_pretrained": "tunevlseg_amd.data.dataset.load_tokenizer",
+    "albumentations.pytorch.ToTensorV2": "tunevlseg_amd.data.transforms.ToTensorV2",
+    "albumentations.": "tunevlseg_amd.data.transforms.",
 }
 
 MISSING = "??"
@@ -184,6 +192,15 @@ def import_resolver(string: str):
     if len(parts) != 2:
         raise ValueError("The string must be a module path")
     module, rest = parts
+    if module == "cv2":   # OpenCV is not in the image: its enum values are what the YAML files ask for (cv2.INTER_CUBIC, cv2.BORDER_REPLICATE)
+        try:
+            importlib.import_module("cv2")
+        except ModuleNotFoundError:
+            from .data.transforms import CV2_CONSTANTS
+
+            if rest not in CV2_CONSTANTS:
+                raise KeyError(f"cv2.{rest}: cv2 is not installed and this constant is not in the built-in table") from None
+            return CV2_CONSTANTS[rest]
     obj = importlib.import_module(module)
     for attr in rest.split("."):
         obj = getattr(obj, attr)

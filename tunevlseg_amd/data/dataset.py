@@ -52,14 +52,47 @@ class ResizeTransform:
         return {"image": img, "mask": m}
 
 
-class ImageTextMaskDataset(Dataset):
-    def __init__(self, *, image_dir, mask_dir, task_path, prompt_index: int, tokenizer, transforms: Callable | None = None,
-                 override_prompt: str | None = None, insert_stop_at_last: bool = False, collate_fn=None, **_ignored: Any) -> None:
+def resolve_tokenizer(tokenizer=None, tokenizer_pretrained_path=None, model_max_length=None):
+    """The reference's datasets build ``AutoTokenizer.from_pretrained(tokenizer_pretrained_path)`` (basedataset.py:52-60); offline that
+    means a local CLIP tokenizer directory / ``merges.txt`` (or ``TVL_CLIP_BPE``).  A hub id such as ``CIDAS/clipseg-rd64`` cannot be
+    fetched: it falls back to ``TVL_CLIP_BPE`` and fails loudly when that is unset too."""
+    if tokenizer is not None:
+        return tokenizer
+    from .tokenizer import ClipBpeTokenizer
+
+    path = tokenizer_pretrained_path if tokenizer_pretrained_path is not None and Path(str(tokenizer_pretrained_path)).exists() else None
+    return ClipBpeTokenizer(path, **({"model_max_length": int(model_max_length)} if model_max_length else {}))
+
+
+def load_tokenizer(pretrained_model_name_or_path=None, *args, **kwargs):
+    """``transformers.AutoTokenizer.from_pretrained`` of the reference's collate_fn config, offline (see ``resolve_tokenizer``)."""
+    return resolve_tokenizer(None, pretrained_model_name_or_path, kwargs.get("model_max_length"))
+
+
+class _TransformMixin:
+    """``transforms`` is either a host callable with the albumentations calling convention (equal-size uint8 outputs: the legacy
+    ``ResizeTransform``) or a ``data.transforms.Compose`` -- then samples leave the dataset decoded and untouched and the whole pipeline
+    runs on the device per batch (``DeviceTransform``)."""
+
+    def apply_transforms(self, image, mask):
+        from .transforms import Compose
+
+        if self.transforms is None or isinstance(self.transforms, Compose):
+            return image, mask
+        out = self.transforms(image=image, mask=mask)
+        return out["image"], out["mask"]
+
+
+class ImageTextMaskDataset(_TransformMixin, Dataset):
+    def __init__(self, *, image_dir, mask_dir, task_path, prompt_index: int, tokenizer=None, transforms: Callable | None = None,
+                 override_prompt: str | None = None, insert_stop_at_last: bool = False, collate_fn=None, tokenizer_pretrained_path=None,
+                 model_max_length=None, return_tensors=None, **_ignored: Any) -> None:
         self.tasks = self.get_tasks(task_path)
         self.image_dir, self.mask_dir = Path(image_dir), Path(mask_dir)
         self.prompt_map_index = f"p{prompt_index}" if prompt_index >= 0 else "random"
         self.override_prompt, self.insert_stop_at_last = override_prompt, insert_stop_at_last
-        self.tokenizer, self.transforms, self.collate_fn = tokenizer, transforms, collate_fn
+        self.tokenizer = resolve_tokenizer(tokenizer, tokenizer_pretrained_path, model_max_length)
+        self.transforms, self.collate_fn = transforms, collate_fn
 
     @staticmethod
     def get_tasks(task_path) -> list[dict[str, Any]]:
@@ -92,15 +125,52 @@ class ImageTextMaskDataset(Dataset):
         mask_name = str(task["mask_name"])
         mask = load_image(self.mask_dir / mask_name, "L")
         mask_shape = np.array(mask.shape)   # the ORIGINAL shape: the predict tail resizes back to it
-        if self.transforms is not None:
-            out = self.transforms(image=image, mask=mask)
-            image, mask = out["image"], out["mask"]
+        image, mask = self.apply_transforms(image, mask)
         prompt = self.get_curr_prompt(task)
         if self.insert_stop_at_last and prompt[-1] != ".":
             prompt += "."
         text = self.tokenizer(prompt, truncation=True)
         return {"image": torch.from_numpy(np.array(image, copy=True)), "mask": torch.from_numpy(np.array(mask, copy=True)),
                 "mask_shape": mask_shape, "mask_name": mask_name, "prompt": prompt,
+                "input_ids": text["input_ids"], "attention_mask": text["attention_mask"]}
+
+
+class ImageDirTextMaskDataset(_TransformMixin, Dataset):
+    """One directory per class under ``mask_dir`` (reference ``image_dir_mask_text_dataset.py:17-116`` -- how the reference runs the
+    "20-class Pascal-VOC" data: 20 binary problems, the class name is the prompt): every ``mask_dir/<class>/<name><mask_suffix>`` is a
+    sample, its image is ``image_dir/<name><image_suffix>``, its prompt ``<class>`` (+ "." with ``insert_stop_at_last``)."""
+
+    def __init__(self, *, image_dir, mask_dir, image_suffix: str, mask_suffix: str, insert_stop_at_last: bool = False, tokenizer=None,
+                 transforms: Callable | None = None, collate_fn=None, tokenizer_pretrained_path=None, model_max_length=None,
+                 return_tensors=None, **_ignored: Any) -> None:
+        if image_suffix[0] != ".":
+            raise ValueError(f"image_suffix must start with a period: {image_suffix=}")
+        if mask_suffix[0] != ".":
+            raise ValueError(f"mask_suffix must start with a period: {mask_suffix=}")
+        self.image_dir, self.mask_dir = Path(image_dir), Path(mask_dir)
+        self.image_suffix, self.mask_suffix, self.insert_stop_at_last = image_suffix, mask_suffix, insert_stop_at_last
+        if not any(p.is_dir() for p in self.mask_dir.iterdir()):
+            raise ValueError(f"No directories found in {self.mask_dir}")
+        self.tasks = [{"class_name": p.parent.name, "mask_name": p.name} for p in sorted(self.mask_dir.glob(f"*/*{mask_suffix}"))]
+        self.tokenizer = resolve_tokenizer(tokenizer, tokenizer_pretrained_path, model_max_length)
+        self.transforms, self.collate_fn = transforms, collate_fn
+
+    def __len__(self) -> int:
+        return len(self.tasks)
+
+    def __getitem__(self, index: int) -> dict[str, Any]:
+        task = self.tasks[index]
+        cls = str(task["class_name"])
+        prompt = f"{cls}." if self.insert_stop_at_last and cls[-1] != "." else cls
+        name = Path(task["mask_name"])
+        image = load_image(self.image_dir / name.with_suffix(self.image_suffix), "RGB")
+        mask_name = Path(cls) / name
+        mask = load_image(self.mask_dir / mask_name, "L")
+        mask_shape = np.array(mask.shape)
+        image, mask = self.apply_transforms(image, mask)
+        text = self.tokenizer(prompt, truncation=True)
+        return {"image": torch.from_numpy(np.array(image, copy=True)), "mask": torch.from_numpy(np.array(mask, copy=True)),
+                "mask_shape": mask_shape, "mask_name": str(mask_name), "prompt": prompt,
                 "input_ids": text["input_ids"], "attention_mask": text["attention_mask"]}
 
 

@@ -56,6 +56,7 @@ class ClipBpeTokenizer:
         if not bpe_path or not Path(bpe_path).exists():
             raise FileNotFoundError("CLIP BPE merge table not found: pass bpe_path= (bpe_simple_vocab_16e6.txt.gz, a HF tokenizer "
                                     "directory or its merges.txt) or set TVL_CLIP_BPE")
+        self.bpe_path = Path(bpe_path)
         merges = _read_merges(Path(bpe_path))
         self._rank = {pair: i for i, pair in enumerate(merges)}
         symbols = _byte_symbols()

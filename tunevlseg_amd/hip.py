@@ -121,6 +121,8 @@ _SIGS = {
     "tvl_dicece_bwd": [_P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _P],
     "tvl_normalize_u8": [_P, _P, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)],
     "tvl_mask_u8": [_P, _P, _L],
+    "tvl_resize_u8": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "tvl_augment_u8": [_P, _P, _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _I, _I, _I],
     "tvl_mix": [_P, _P, _P, _P, _L],
     "tvl_scale_dev": [_P, _P, _I, _P, _L],
     "tvl_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F],
@@ -1116,6 +1118,31 @@ def dicece_bwd(logits, target, fsum, lambda_dice, lambda_ce, smooth_nr, smooth_d
     _call("tvl_dicece_bwd", _p(logits), _p(target), _p(fsum, torch.float64), _p(dl), B, N, float(lambda_dice), float(lambda_ce),
           float(smooth_nr), float(smooth_dr), _p(gscale))
     return dl
+
+
+INTER_NEAREST, INTER_CUBIC = 0, 2   # cv2's values (the reference's YAML resolves ${import_eval:cv2.INTER_CUBIC} to 2)
+
+
+def resize_u8(packed: torch.Tensor, offs: torch.Tensor, hw: torch.Tensor, C_: int, H: int, W: int, mode: int) -> torch.Tensor:
+    """Ragged batch -> [B, H, W, C] uint8 (albumentations.Resize with cv2.INTER_CUBIC / INTER_NEAREST).  ``packed`` uint8 [bytes] holds the
+    B images back to back, ``offs`` int64 [B] their byte offsets, ``hw`` int32 [B, 2] their (height, width)."""
+    B = hw.shape[0]
+    out = torch.empty((B, H, W, C_), device=packed.device, dtype=torch.uint8)
+    _call("tvl_resize_u8", _p(packed, torch.uint8), _p(offs, torch.int64), _p(hw, torch.int32), B, C_, H, W, int(mode), _p(out, torch.uint8))
+    return out
+
+
+def augment_u8(img_u8: torch.Tensor, mask_u8_: torch.Tensor | None, params: torch.Tensor, flags: torch.Tensor, mean, std):
+    """[B,H,W,3] uint8 (+ [B,H,W] uint8 mask) -> (normalised fp32 [B,3,H,W], fp32 mask / 255 [B,1,H,W] or None) with the per-sample
+    affine warp / brightness-contrast of ``params`` [B, 8] / ``flags`` [B] (tvl_augment_u8)."""
+    B, H, W, Cc = img_u8.shape
+    if Cc != 3:
+        raise RuntimeError(f"augment_u8 wants [B,H,W,3] uint8, got {tuple(img_u8.shape)}")
+    out = torch.empty((B, 3, H, W), device=img_u8.device, dtype=torch.float32)
+    om = torch.empty((B, 1, H, W), device=img_u8.device, dtype=torch.float32) if mask_u8_ is not None else None
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    _call("tvl_augment_u8", _p(img_u8, torch.uint8), _p(mask_u8_, torch.uint8), _p(params), _p(flags, torch.int32), m3, s3, _p(out), _p(om), B, H, W)
+    return out, om
 
 
 def normalize_u8(img_u8: torch.Tensor, mean, std) -> torch.Tensor:

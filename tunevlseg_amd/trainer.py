@@ -130,6 +130,8 @@ class Trainer:
             start_epoch = self.load(module, ckpt_path, opt, sched)["epoch"] + 1
         arm = getattr(opt, "set_exchange_armed", lambda armed: None)
         for epoch in range(start_epoch, self.max_epochs):
+            if hasattr(train_loader, "set_epoch"):   # per-rank shard order and augmentation draws of this epoch (DistributedSampler.set_epoch)
+                train_loader.set_epoch(epoch)
             opt.zero_grad()
             running, n_batches, pending = 0.0, 0, 0
             n_train = len(train_loader) if hasattr(train_loader, "__len__") else None
