@@ -27,8 +27,9 @@ extern "C" {
 typedef void* tvlStream_t; /* hipStream_t */
 
 /* Bumped on every incompatible change of a signature or struct below.  3: tvl_dicece_stats gained `work`, tvl_split_planes /
- * tvl_gemm_planes removed (round 2).  The Python binding refuses a library whose tvl_abi_version() differs. */
-#define TVL_ABI_VERSION 3
+ * tvl_gemm_planes removed (round 2).  4: tvl_text_assemble gained `vocab` (rows of the embedding table: ids outside it give NaN rows
+ * instead of a wild read); tvl_resize_u8 / tvl_augment_u8 added.  The Python binding refuses a library whose tvl_abi_version() differs. */
+#define TVL_ABI_VERSION 4
 
 const char* tvl_last_error(void);
 int tvl_abi_version(void);
@@ -151,7 +152,7 @@ int tvl_im2col_patch(const float* img, float* cols, int32_t B, int32_t C, int32_
 int tvl_vision_assemble(const float* patch, const float* cls, const float* pos, const float* ctx, int64_t ctx_bs,
                         float* x0, int32_t B, int32_t P, int32_t n, int32_t D, tvlStream_t stream);
 /* out[b,t,:] = (map[t] >= 0 ? table[ids[b*L + map[t]]] : ctx[b*ctx_bs + (-map[t]-1)*D]) + pos[t]  (ids int64) */
-int tvl_text_assemble(const int64_t* ids, int32_t L, const int32_t* map, const float* table, const float* ctx, int64_t ctx_bs,
+int tvl_text_assemble(const int64_t* ids, int32_t L, const int32_t* map, const float* table, int64_t vocab, const float* ctx, int64_t ctx_bs,
                       const float* pos, float* out, int32_t B, int32_t T, int32_t D, tvlStream_t stream);
 /* out[b,t,:] = map[t] >= 0 ? x[b, map[t], :] : ctx[b*ctx_bs + (-map[t]-1)*D ...]   (x: [B, L, D]) */
 int tvl_splice_rows(const float* x, int32_t L, const int32_t* map, const float* ctx, int64_t ctx_bs, float* out,

@@ -292,3 +292,16 @@ def test_device_resize_and_augment_equal_the_cpu_restatement(tmp_path, toy_token
     r = hip.resize_u8(batch["image_bytes"].cuda(), (3 * offs).cuda(), hw.cuda(), 3, S, S, hip.INTER_CUBIC).cpu().numpy()
     for b in range(3):
         assert np.array_equal(r[b], A.resize_cubic_u8(ds[b]["image"].numpy(), S, S))
+
+
+@pytest.mark.gpu
+def test_token_ids_outside_the_embedding_table_give_nan_rows_not_a_wild_read():
+    """A tokenizer that does not belong to the backbone (CLIP ids up to 49407 against a 64-row table) must not fault the GPU."""
+    from tunevlseg_amd import hip
+
+    hip.load()
+    table, pos = torch.randn(64, 32, device="cuda"), torch.zeros(8, 32, device="cuda")
+    ids = torch.tensor([[62, 5, 49407, 63]], device="cuda")
+    out = hip.text_assemble(ids, hip.const_i32([0, 1, 2, 3], "cuda"), table, None, 0, pos, 1, 4, 32)
+    assert torch.equal(out[0, 0], table[62]) and torch.equal(out[0, 1], table[5]) and torch.equal(out[0, 3], table[63])
+    assert torch.isnan(out[0, 2]).all()

@@ -221,7 +221,6 @@ def test_train_entry_point_fits_from_a_directory_in_the_reference_layout(tmp_pat
     the reference's datamodule schema (``configs/data/image_text_mask.yaml``) over a toy dataset in the reference's wire format
     (images/, masks/, anns/{train,val,test}.json) -> cfg.data is instantiated, decoded samples are resized / augmented / normalised on
     the device, fit + test run.  A config WITHOUT a buildable data node raises instead of training on synthetic batches."""
-    import gzip
     import json
 
     import numpy as np
@@ -230,7 +229,6 @@ def test_train_entry_point_fits_from_a_directory_in_the_reference_layout(tmp_pat
     from tests.test_config_loader import write
     from tunevlseg_amd import config_loader as CL
     from tunevlseg_amd import train as T
-    from tunevlseg_amd.data.tokenizer import N_MERGES
 
     root = tmp_path / "data" / "toy"
     for d in ("images", "masks", "anns"):
@@ -248,10 +246,17 @@ def test_train_entry_point_fits_from_a_directory_in_the_reference_layout(tmp_pat
         tasks.append({"img_name": f"im{i}.png", "mask_name": f"m{i}.png", "prompts": {"p0": "", "p1": "a bright box"}})
     for split in ("train", "val", "test"):
         (root / "anns" / f"{split}.json").write_text(json.dumps(tasks))
-    bpe = tmp_path / "merges.txt.gz"
-    with gzip.open(bpe, "wt", encoding="utf-8") as fh:
-        fh.write("#version: toy\n" + "\n".join(f"¤{i} ¤{i}" for i in range(N_MERGES)) + "\n")
-    monkeypatch.setenv("TVL_CLIP_BPE", str(bpe))
+    # the tiny backbone has a 64-word vocabulary (BOS 62, EOS 63): a word-level stand-in for the CLIP tokenizer that belongs to it
+    class TinyTokenizer:
+        pad_token_id, bos_token_id, eos_token_id = 1, 62, 63
+
+        def __call__(self, text, **kw):
+            ids = [self.bos_token_id, *[2 + (sum(map(ord, w)) % 58) for w in text.lower().split()], self.eos_token_id]
+            return {"input_ids": ids, "attention_mask": [1] * len(ids)}
+
+    from tunevlseg_amd.data import dataset as D
+
+    monkeypatch.setattr(D, "resolve_tokenizer", lambda tokenizer=None, path=None, mml=None: tokenizer or TinyTokenizer())
 
     cfgdir = tmp_path / "configs"
     write(cfgdir / "train.yaml", "# @package _global_\ndefaults:\n  - _self_\n  - data: image_text_mask\n  - model: vpt\n  - trainer: default\n"

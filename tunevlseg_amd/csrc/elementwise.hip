@@ -56,7 +56,7 @@ __global__ void vision_assemble_kernel(const float* __restrict__ patch, const fl
 // ---- text token assembly --------------------------------------------------------------------
 __global__ void text_assemble_kernel(const long long* __restrict__ ids, int L, const int* __restrict__ map,
                                      const float* __restrict__ table, const float* __restrict__ ctx, long ctx_bs,
-                                     const float* __restrict__ pos, float* __restrict__ out, int B, int T, int D) {
+                                     const float* __restrict__ pos, float* __restrict__ out, int B, int T, int D, long vocab) {
     const long total = (long)B * T * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % D);
@@ -64,8 +64,12 @@ __global__ void text_assemble_kernel(const long long* __restrict__ ids, int L, c
         const int t = (int)(bt % T), b = (int)(bt / T);
         const int mp = map[t];
         float v;
-        if (mp >= 0) v = table[(long)ids[(long)b * L + mp] * D + c];
-        else v = ctx[b * ctx_bs + (long)(-mp - 1) * D + c];
+        if (mp >= 0) {
+            // an id outside the embedding table (a tokenizer that does not belong to this backbone) must not become a wild read: the
+            // row turns into NaN and the loss says so (HF's nn.Embedding raises a device assert there)
+            const long long id = ids[(long)b * L + mp];
+            v = (id >= 0 && id < vocab) ? table[id * D + c] : __builtin_nanf("");
+        } else v = ctx[b * ctx_bs + (long)(-mp - 1) * D + c];
         out[i] = v + pos[(long)t * D + c];
     }
 }
@@ -375,13 +379,13 @@ extern "C" int tvl_vision_assemble(const float* patch, const float* cls, const f
     return 0;
 }
 
-extern "C" int tvl_text_assemble(const int64_t* ids, int32_t L, const int32_t* map, const float* table, const float* ctx, int64_t ctx_bs,
+extern "C" int tvl_text_assemble(const int64_t* ids, int32_t L, const int32_t* map, const float* table, int64_t vocab, const float* ctx, int64_t ctx_bs,
                                  const float* pos, float* out, int32_t B, int32_t T, int32_t D, tvlStream_t stream) {
     TVL_REQUIRE(ids && map && table && pos && out, "tvl_text_assemble: null pointer");
-    TVL_REQUIRE(B > 0 && T > 0 && D > 0 && L > 0, "tvl_text_assemble: bad shape");
+    TVL_REQUIRE(B > 0 && T > 0 && D > 0 && L > 0 && vocab > 0, "tvl_text_assemble: bad shape");
     const long total = (long)B * T * D;
     hipLaunchKernelGGL(text_assemble_kernel, GRID_FOR(total), dim3(256), 0, S_(stream), reinterpret_cast<const long long*>(ids), L, map,
-                       table, ctx, (long)ctx_bs, pos, out, B, T, D);
+                       table, ctx, (long)ctx_bs, pos, out, B, T, D, (long)vocab);
     TVL_LAUNCH_CHECK("tvl_text_assemble");
     return 0;
 }

@@ -9,8 +9,8 @@ size), the collator packs the ragged batch, and :class:`DeviceTransform` runs th
 affine warp + brightness / contrast + normalisation, one read of the uint8 batch, one write of the fp32 network input).  The random
 draws (who is augmented, with what parameters) are made on the host per batch from a seeded ``numpy`` generator.
 
-cv2 / albumentations are not in the image: their arithmetic is restated from the published algorithms (``oracle/augment_oracle.py``
-holds the CPU restatement the kernels are tested against) and stays "unpinned" against the libraries themselves.  ``PadIfNeeded`` and
+cv2 / albumentations are not in the image: their arithmetic is restated from the published algorithms (the tests hold the kernels to a
+numpy restatement of the same definitions) and stays "unpinned" against the libraries themselves.  ``PadIfNeeded`` and
 ``CropNonEmptyMaskIfExists`` at the resized size are identities (every experiment file of the reference uses ``img_size`` for all
 three); other sizes raise."""
 from __future__ import annotations

@@ -105,7 +105,7 @@ _SIGS = {
     "tvl_attn_bwd": [C.POINTER(AttnBwdArgs)],
     "tvl_im2col_patch": [_P, _P, _I, _I, _I, _I, _I],
     "tvl_vision_assemble": [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I],
-    "tvl_text_assemble": [_P, _I, _P, _P, _P, _L, _P, _P, _I, _I, _I],
+    "tvl_text_assemble": [_P, _I, _P, _P, _L, _P, _L, _P, _P, _I, _I, _I],
     "tvl_splice_rows": [_P, _I, _P, _P, _L, _P, _I, _I, _I],
     "tvl_rows_overwrite": [_P, _P, _L, _I, _I, _I, _I, _I],
     "tvl_rows_grad": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I],
@@ -175,7 +175,7 @@ _SIGS = {
 EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_h2_bytes", "tvl_dicece_work_doubles", *_SIGS]
 
 _lib = None
-ABI_VERSION = 3   # include/tvl_hip.h TVL_ABI_VERSION
+ABI_VERSION = 4   # include/tvl_hip.h TVL_ABI_VERSION
 
 
 def load():
@@ -1025,7 +1025,7 @@ def vision_assemble(patch, cls, pos, ctx, ctx_bs: int, B: int, P: int, n: int, D
 
 def text_assemble(ids, tmap, table, ctx, ctx_bs: int, pos, B: int, T: int, D: int) -> torch.Tensor:
     out = torch.empty((B, T, D), device=table.device, dtype=torch.float32)
-    _call("tvl_text_assemble", _p(ids, torch.int64), ids.shape[1], _p(tmap, torch.int32), _p(table), _p(ctx), ctx_bs, _p(pos),
+    _call("tvl_text_assemble", _p(ids, torch.int64), ids.shape[1], _p(tmap, torch.int32), _p(table), table.shape[0], _p(ctx), ctx_bs, _p(pos),
           _p(out), B, T, D)
     return out
 
