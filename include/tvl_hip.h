@@ -28,7 +28,7 @@ typedef void* tvlStream_t; /* hipStream_t */
 
 /* Bumped on every incompatible change of a signature or struct below.  3: tvl_dicece_stats gained `work`, tvl_split_planes /
  * tvl_gemm_planes removed (round 2).  4: tvl_text_assemble gained `vocab` (rows of the embedding table: ids outside it give NaN rows
- * instead of a wild read); tvl_resize_u8 / tvl_augment_u8 added.  The Python binding refuses a library whose tvl_abi_version() differs. */
+ * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  The Python binding refuses a library whose tvl_abi_version() differs. */
 #define TVL_ABI_VERSION 4
 
 const char* tvl_last_error(void);
@@ -289,6 +289,9 @@ int tvl_tp3_unpack(const void* in, int64_t rows, int32_t K, float* y, int64_t ld
  * transposed weight packed once).  Same epilogue contract and order as tvl_gemm_f32 (no row maps; pre_out shares ldc).
  * Outputs: C (fp32, may be NULL) and / or C_tp3, the tp3 image of the final value as the next GEMM's A operand [M, N].
  * K % 16 == 0, N % 16 == 0.  tile_m: 0 = choose, else 128 | 192 | 256 rows per workgroup; variant: scheduling A/B switch.
+ * workspace (optional, tvl_gemm_h2 / tvl_gemm_h2_out): >= 64 MiB of device memory owned by the calling stream; launches of more than
+ * 512 tiles whose epilogue writes an image (QKV, fc1, its data gradient's dz) then walk their tiles with one persistent workgroup per
+ * CU and park one partial tile per workgroup there (csrc/gemm_h2m_kernel.h).  NULL: one workgroup per tile.
  */
 typedef struct {
     int32_t M, N, K;
@@ -303,8 +306,14 @@ typedef struct {
     const float* dact_aux; int32_t ld_aux; int32_t dact;
     float alpha;
     int32_t tile_m, variant;
+    void* workspace; int64_t workspace_bytes;
+    int32_t aux_blocked;   /* tvl_gemm_h2_out only: pre_out (written) / dact_aux (read) is not a row-major matrix but a private buffer of
+                            * tvl_gemm_aux_floats(M, N) floats in the producing kernel's accumulator order -- fc1's z handed to its data
+                            * gradient's QuickGELU' epilogue; both calls must have the same M and N */
 } tvlGemmTp3Args;
 int tvl_gemm_tp3(const tvlGemmTp3Args* args, tvlStream_t stream);
+/* floats in an aux_blocked buffer for an [M, N] result (whole 256 x 256 tiles), or -1 when the shape cannot use one */
+int64_t tvl_gemm_aux_floats(int64_t M, int64_t N);
 
 /* "h2": two fp16 pieces per element (x * s = h0 + h1, s an exact power of two per row or per tensor), same block order as tp3 with
  * 2 KiB per 32 x 16 block.  Three MFMAs per product instead of six at the same (fp32-equivalent) accuracy: csrc/gemm_h2.hip.

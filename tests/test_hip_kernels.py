@@ -701,3 +701,51 @@ def test_attention_on_h2_operands(hip, B, T, H):
     den = g2.abs().double().cpu() @ w.abs().double().cpu().T
     got = hip.gemm_h2_ks(gk, hip.weight_h2(w)).cpu().double()
     assert ((got - ref).abs() / (den + 1e-300)).max().item() < 5e-6
+
+
+def test_gemm_h2_persistent_tile_walk_equals_one_workgroup_per_tile(hip):
+    """fc1's shape at the headline batch (M = 15840, N = 3072, K = 768: 744 tiles of 256 x 256 -> the persistent walk with XCD-phased split
+    first tiles, csrc/gemm_h2m_kernel.h) against the same kernel launched one workgroup per tile: the split tiles sum their two k-ranges in
+    another order, everything else is the same arithmetic -> equal to fp32 rounding; a subsample of rows against float64."""
+    M, N, K = 15840, 3072, 768
+    x = dev(rnd(M, K, seed=31))
+    w = rnd(N, K, seed=32) * 0.05
+    b1 = rnd(N, seed=33) * 0.1
+    X, W = hip.h2_pack(x, True, want_norm=True), hip.weight_h2(dev(w))
+    import os
+
+    outs = []
+    for persistent in (True, False):
+        os.environ["TVL_GEMM_PERSIST"] = "1" if persistent else "0"   # the walk is an opt-in experiment (read per launch by the library)
+        z = torch.empty(M, N, device="cuda")
+        _, a = hip.gemm_h2(X, W, want_f32=False, want_h2=True, out_add=float(b1.abs().max()), bias=dev(b1), act=hip.ACT_QUICK_GELU, pre_out=z,
+                           persistent=persistent)
+        outs.append((z, a.float(), a.inv_scale.clone()))
+    os.environ.pop("TVL_GEMM_PERSIST", None)
+    (z1, a1, s1), (z0, a0, s0) = outs
+    assert torch.equal(s1, s0)
+    assert (z1 - z0).abs().max().item() <= 2e-6 * z0.abs().max().item() and not torch.equal(z1, z0)   # the split tiles DID take the other order
+    assert (a1 - a0).abs().max().item() <= 4e-6 * a0.abs().max().item()
+    rows = torch.arange(0, M, 97)
+    ref = x[rows].double().cpu() @ w.double().T + b1.double()
+    den = x[rows].abs().double().cpu() @ w.abs().double().T + b1.abs().double()
+    assert ((z1[rows].cpu().double() - ref).abs() / den).max().item() < 2e-6
+
+
+def test_gemm_h2_pre_activation_in_accumulator_order_round_trips(hip):
+    """fc1 -> z (private accumulator-order buffer, hip.gemm_aux) -> the QuickGELU' epilogue of the data gradient: the same dz image as with
+    a row-major z, bit for bit; shapes that do not pick the 256-row tile of the 16x16x32 ring get no such buffer."""
+    M, N, K = 15840, 3072, 768
+    assert hip.gemm_aux(1000, 768, "cuda") is None and hip.gemm_aux(M, 2304, "cuda") is None
+    x, g = dev(rnd(M, K, seed=41)), dev(rnd(M, K, seed=42) * 1e-3)
+    w1, w2t, b1 = rnd(N, K, seed=43) * 0.05, rnd(N, K, seed=44) * 0.05, rnd(N, seed=45) * 0.1
+    X, G = hip.h2_pack(x, True, want_norm=True), hip.h2_pack(g, True, want_norm=True)
+    W1, W2T = hip.weight_h2(dev(w1)), hip.weight_h2(dev(w2t))
+    res = []
+    for blocked in (True, False):
+        z = hip.gemm_aux(M, N, "cuda") if blocked else torch.empty(M, N, device="cuda")
+        assert z is not None and (z.dim() == 1) == blocked
+        _, a = hip.gemm_h2(X, W1, want_f32=False, want_h2=True, out_add=float(b1.abs().max()), bias=dev(b1), act=hip.ACT_QUICK_GELU, pre_out=z, aux_blocked=blocked)
+        _, dz = hip.gemm_h2(G, W2T, want_f32=False, want_h2=True, out_mul=1.125 * W2T._bound, dact=hip.ACT_QUICK_GELU, dact_aux=z, aux_blocked=blocked)
+        res.append((a.buf.clone(), dz.buf.clone(), dz.inv_scale.clone()))
+    assert all(torch.equal(u, v) for u, v in zip(*res))

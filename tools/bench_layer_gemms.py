@@ -16,7 +16,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from tunevlseg_amd import hip  # noqa: E402
 
 args = dict(a.split("=") for a in sys.argv[1:])
-TILES = [int(t) for t in args.get("tiles", "0,128").split(",")]
+TILES = [int(t) for t in args.get("tiles", "0,128").split(",")]   # a negative tile code = the same tile WITHOUT the persistent tile walk
 M = int(args.get("M", 15840))
 ROUNDS = int(args.get("rounds", 7))
 D, F = 768, 3072
@@ -36,13 +36,13 @@ def main():
     zout = torch.empty(M, F, device=dev)
 
     calls = {
-        "qkv  385 N=2304 K=768 ": lambda t: hip.gemm_h2(x, W["wqkv"], want_f32=False, want_h2=True, out_per_tensor=True, out_add=4.0, bias=bq, tile_m=t),
-        "out  163 N=768  K=768 ": lambda t: hip.gemm_h2(o, W["wo"], bias=bo, residual=res, tile_m=t),
-        "fc1  405 N=3072 K=768 ": lambda t: hip.gemm_h2(x, W["w1"], want_f32=False, want_h2=True, out_add=4.0, bias=b1, act=hip.ACT_QUICK_GELU, pre_out=zout, tile_m=t),
-        "fc2  163 N=768  K=3072": lambda t: hip.gemm_h2(a, W["w2"], bias=bo, residual=res, tile_m=t),
-        "dz   392 N=3072 K=768 ": lambda t: hip.gemm_h2(x, W["w2_t"], want_f32=False, want_h2=True, out_mul=1.125 * W["w2_t"]._bound, dact=hip.ACT_QUICK_GELU, dact_aux=z, tile_m=t),
-        "dx2  160 N=768  K=3072": lambda t: hip.gemm_h2(a, W["w1_t"], tile_m=t),
-        "do   384 N=768  K=768 ": lambda t: hip.gemm_h2(x, W["wo_t"], want_f32=False, want_h2=True, out_per_tensor=True, tile_m=t),
+        "qkv  385 N=2304 K=768 ": lambda t: hip.gemm_h2(x, W["wqkv"], want_f32=False, want_h2=True, out_per_tensor=True, out_add=4.0, bias=bq, tile_m=abs(t), persistent=t >= 0),
+        "out  163 N=768  K=768 ": lambda t: hip.gemm_h2(o, W["wo"], bias=bo, residual=res, tile_m=abs(t)),
+        "fc1  405 N=3072 K=768 ": lambda t: hip.gemm_h2(x, W["w1"], want_f32=False, want_h2=True, out_add=4.0, bias=b1, act=hip.ACT_QUICK_GELU, pre_out=zout, tile_m=abs(t), persistent=t >= 0),
+        "fc2  163 N=768  K=3072": lambda t: hip.gemm_h2(a, W["w2"], bias=bo, residual=res, tile_m=abs(t)),
+        "dz   392 N=3072 K=768 ": lambda t: hip.gemm_h2(x, W["w2_t"], want_f32=False, want_h2=True, out_mul=1.125 * W["w2_t"]._bound, dact=hip.ACT_QUICK_GELU, dact_aux=z, tile_m=abs(t), persistent=t >= 0),
+        "dx2  160 N=768  K=3072": lambda t: hip.gemm_h2(a, W["w1_t"], tile_m=abs(t)),
+        "do   384 N=768  K=768 ": lambda t: hip.gemm_h2(x, W["wo_t"], want_f32=False, want_h2=True, out_per_tensor=True, tile_m=abs(t)),
     }
     flops = {k: 2.0 * M * int(k.split("N=")[1].split()[0]) * int(k.split("K=")[1]) for k in calls}
 
@@ -55,10 +55,8 @@ def main():
             parts += [ch.float(), ch.inv_scale]
         return parts
 
-    ref = {k: result(f(0)) for k, f in calls.items()}
+    ref = {k: result(f(2560 if "N=3072" in k else 1920)) for k, f in calls.items()}   # the 32x32x16 generation (scratch epilogue): independent code
     for t in TILES:
-        if t == 0:
-            continue
         for k, f in calls.items():
             got = result(f(t))
             same = all(torch.equal(g_, r_) for g_, r_ in zip(got, ref[k]))
@@ -85,7 +83,7 @@ def main():
             v = sorted(times[(k, t)])
             med = v[len(v) // 2]
             tot[t] += med
-            row.append(f"tile {t:3d}: {med * 1e3:7.1f} us {flops[k] / med / 1e9:6.1f} TF/s (min {v[0] * 1e3:6.1f})")
+            row.append(f"tile {t:5d}: {med * 1e3:7.1f} us {flops[k] / med / 1e9:6.1f} TF/s (min {v[0] * 1e3:6.1f})")
         print(f"{k}  " + "  |  ".join(row))
     fl = sum(flops.values())
     print("seven GEMMs (without the QKV data gradient): " + "  |  ".join(f"tile {t}: {tot[t]:.3f} ms {fl / tot[t] / 1e9:.1f} TF/s" for t in TILES))

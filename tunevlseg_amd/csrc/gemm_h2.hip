@@ -219,6 +219,16 @@ int launch_h2_conv(const Tp3Params& p, int bm, int epi, hipStream_t s) {
 
 }  // namespace
 
+// an aux_blocked buffer covers whole 256 x 256 tiles and exists only where tvl_gemm_h2_out picks the 256-row tile of the 16x16x32 ring
+static bool aux_blocked_ok(long M, long N, long K) {
+    if (M <= 0 || N <= 0 || N % 256 != 0 || !use_m16() || K < 96) return false;
+    const long t256 = ((M + 255) / 256) * (N / 256), t192 = ((M + 191) / 192) * (N / 256);
+    return ((t256 + 255) / 256) * 256 <= ((t192 + 255) / 256) * 192;
+}
+extern "C" int64_t tvl_gemm_aux_floats(int64_t M, int64_t N) {
+    return aux_blocked_ok(M, N, 96) ? ((M + 255) / 256) * 256 * N : -1;
+}
+
 extern "C" int64_t tvl_h2_bytes(int64_t rows, int32_t K) {
     if (rows <= 0 || K <= 0 || K % 16 != 0) return -1;
     return ((rows + 31) / 32) * (int64_t)(K / 16) * BLK2;
@@ -308,6 +318,11 @@ static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void*
     p.C = a->C; p.ldc = a->ldc; p.Cp = reinterpret_cast<unsigned char*>(a->C_tp3);
     p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.act = a->act; p.pre_out = a->pre_out;
     p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha; p.a_scale = a_row_scale; p.a_sstride = conv ? 0 : 1;
+    p.aux_blocked = a->aux_blocked;
+    TVL_REQUIRE(!a->aux_blocked || (c_h2 && !a->C && !a->C_tp3 && !a->residual && !conv && a->tile_m == 0 && aux_blocked_ok(a->M, a->N, a->K)),
+                "tvl_gemm_h2: aux_blocked needs an image-only epilogue on the automatically chosen 256-row tile (M=%d N=%d K=%d)", a->M, a->N, a->K);
+    p.work = reinterpret_cast<float*>(a->workspace); p.work_bytes = a->workspace ? a->workspace_bytes : 0;
+    TVL_REQUIRE(!a->workspace || tvl_aligned16(a->workspace), "tvl_gemm_h2: workspace must be 16-byte aligned");
     p.Ch2 = reinterpret_cast<unsigned char*>(c_h2); p.out_norm = out_row_norm; p.out_mul = out_mul; p.out_add = out_add; p.out_inv = out_inv_scale; p.out_stride = out_per_tensor ? 0 : 1;
     int bm = a->tile_m;
     static const int stagger_us = getenv("TVL_GEMM_STAGGER_US") ? atoi(getenv("TVL_GEMM_STAGGER_US")) : 0;   // experiment knob

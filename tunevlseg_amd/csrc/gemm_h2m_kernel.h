@@ -68,7 +68,80 @@ __device__ __forceinline__ void epilogue16(const Tp3Params& p, f32x4 (&acc)[TMo]
     }
 }
 
-template <int BM, int EPI, bool KS = false, bool CONV = false>
+// Epilogue of the image-writing GEMMs (QKV, dO, fc1, dz: E_H2OUT without an fp32 / tp3 result or a residual) straight from the
+// accumulators, no LDS round trip and no workgroup barrier.  A 16 x 16 accumulator tile has its row on (lane & 15) and columns
+// 4 (lane >> 4) .. + 3 in the four registers; in the h2 image those four columns are 8 bytes of slot (q >> 1) * 32 + row % 32, so the
+// sixteen lanes of a (tile, q) write 256 contiguous bytes per piece -- against sixteen-byte granules when the same values leave through
+// the row-major scratch (eight lanes per row, four columns each).  The pre-activation z (fc1's second output, the dz kernel's input) is
+// fp32 row-major: 64 contiguous bytes per row and instruction.
+// p.aux_blocked: z does not leave as a row-major matrix but in the accumulators' own order -- tile after tile, wave after wave, 1 KB per
+// (16 x 16 block): a private layout between fc1's epilogue and the dz epilogue of the same (M, N, tile), both fully coalesced.
+template <int TMo, int EPI>
+__device__ __forceinline__ void epilogue16_direct(const Tp3Params& p, f32x4 (&acc)[TMo][4], int row_base, int col_base, int lane, long blk_base) {
+    static_assert((EPI & E_H2OUT) && !(EPI & (E_F32 | E_TP3 | E_RES | E_RELU)) && (EPI & E_RSCALE), "image-only epilogues");
+    const int m = lane & 15, q = lane >> 4;
+    const int kbn = p.N >> 4;
+    float4 bias4[4];
+    if constexpr ((EPI & E_BIAS) != 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col_base + 16 * j + 4 * q;
+            bias4[j] = col + 3 < p.N ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TMo; ++i) {
+        const long row = row_base + 16 * i + m;
+        if (row >= p.M) continue;
+        const float f = p.alpha * p.a_scale[row * p.a_sstride];
+        const float inv = h2::inv_scale_of(p.out_norm[row * p.out_stride] * p.out_mul + p.out_add);
+        if (col_base == 0 && q == 0 && (p.out_stride || row == 0)) p.out_inv[row * p.out_stride] = inv;
+        const float sc = 1.0f / inv;   // a power of two: exact
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col_base + 16 * j + 4 * q;
+            if (col + 3 >= p.N) continue;
+            float v[4] = {acc[i][j][0] * f, acc[i][j][1] * f, acc[i][j][2] * f, acc[i][j][3] * f};
+            if constexpr ((EPI & E_BIAS) != 0) { v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w; }
+            if constexpr ((EPI & E_DQGELU) != 0) {
+                const float4 z4 = p.aux_blocked ? *reinterpret_cast<const float4*>(p.dact_aux + (blk_base + i * 4 + j) * 256 + lane * 4)
+                                                : *reinterpret_cast<const float4*>(p.dact_aux + row * p.ld_aux + col);
+                v[0] *= dact_f(z4.x, TVL_ACT_QUICK_GELU); v[1] *= dact_f(z4.y, TVL_ACT_QUICK_GELU);
+                v[2] *= dact_f(z4.z, TVL_ACT_QUICK_GELU); v[3] *= dact_f(z4.w, TVL_ACT_QUICK_GELU);
+            }
+            if constexpr ((EPI & E_PRE) != 0) {
+                float* zo = p.aux_blocked ? p.pre_out + (blk_base + i * 4 + j) * 256 + lane * 4 : p.pre_out + row * p.ldc + col;
+                *reinterpret_cast<float4*>(zo) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if constexpr ((EPI & E_QGELU) != 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], TVL_ACT_QUICK_GELU);
+            }
+            _Float16 h0[4], h1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float w = v[e] * sc;
+                h0[e] = (_Float16)w;
+                h1[e] = (_Float16)(w - (float)h0[e]);
+            }
+            unsigned char* o = p.Ch2 + ((row >> 5) * kbn + (col >> 4)) * (long)h2::BLK + (((q >> 1) * 32 + (int)(row & 31)) * 16 + (q & 1) * 8);
+            *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(h0);
+            *reinterpret_cast<uint2*>(o + h2::PIECE) = *reinterpret_cast<const uint2*>(h1);
+        }
+    }
+}
+
+// PERSIST: one workgroup per CU walks several tiles (launches of more than 256 tiles: fc1, its data gradient's dz, QKV).  The reason is
+// the epilogue: 256-640 KB of stores per tile that every CU of a lock-stepped round issues at the same moment -- a chip-wide HBM burst
+// of ~130 MB with no MFMA under it, three times per launch.  De-phasing workgroups INDIVIDUALLY would break what keeps the operand
+// stream in L2 (the 32 workgroups of an XCD read the same k-slabs of their 8 + 4 shared tiles at the same time), so whole XCDs are
+// de-phased against each other: XCD x starts its first tile at k-step nt * x / 8, parks that partial tile (fp32 accumulators, 256 KB,
+// in a workspace of its own: no other workgroup ever touches it), runs its remaining tiles, and finishes the first one last.  No
+// idle time, no inter-workgroup traffic; the eight XCDs reach their epilogues an eighth of a tile apart.
+// MEASURED (profiles/r3_gemm_experiments.md): 20-25 % SLOWER than one workgroup per tile -- inside one wave vmcnt counts stores and DMA
+// requests in one queue, so a tile's epilogue stores gate the first DMA wait of the next tile, while a fresh workgroup starts its
+// prologue beside the previous one's draining stores.  Kept as an opt-in experiment (TVL_GEMM_PERSIST=1), not on any default path.
+template <int BM, int EPI, bool KS = false, bool CONV = false, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
     constexpr int NW = 8, BN = 256, NP = 2;
     constexpr int WM = BM / 2;
@@ -79,70 +152,43 @@ __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
     constexpr int STAGE = PT * PIECE, PAIR = 2 * STAGE;
     constexpr int NM = 3 * TMo * 4;                 // MFMAs per 32-deep step and wave
     static_assert(WM % 32 == 0 && (BM == 256 || BM == 192), "tile");
+    static_assert(!PERSIST || (!KS && !CONV), "the persistent tile walk is built for the plain layer GEMMs");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    constexpr int GROUP_M = 8;
-    const int gsize_full = GROUP_M * p.tiles_n;
-    const int group = bid / gsize_full;
-    const int gm0 = group * GROUP_M;
-    const int gm = p.tiles_m - gm0 < GROUP_M ? p.tiles_m - gm0 : GROUP_M;
-    const int in_group = bid - group * gsize_full;
-    const int tile_m = gm0 + in_group % gm, tile_n = in_group / gm;
-
-    // De-phasing (speed only): every workgroup of the first dispatch round starts after its own pseudo-random share of `stagger_ticks`,
-    // so that CUs reach their epilogues -- 256 to 640 KB of stores each -- at different times instead of as one chip-wide HBM burst per
-    // round; later rounds inherit the offsets (a workgroup starts when a CU frees up).
-    if (p.stagger_ticks > 0 && blockIdx.x < 256) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long d = ((unsigned long long)p.stagger_ticks * ((blockIdx.x * 97u) & 255u)) >> 8;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
-    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int KB = p.K >> 4;
     const int nt = KB >> 1;                          // 32-deep steps (K % 32 == 0, K >= 96: nt >= 3)
 
-    // this wave's DMA sources (slab 0): wave-uniform bases + one lane offset
-    const unsigned char* src[PW];
-#pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        const int pc = wave + NW * i;
-        if (pc < PA) {
-            int rb = tile_m * (BM / 32) + pc / NP;
-            rb = rb < p.a_rb ? rb : p.a_rb - 1;
-            src[i] = p.A + ((long)rb * KB) * BLKP + (pc % NP) * PIECE;
-        } else {
-            const int q = pc < PT ? pc - PA : 0;
-            int rb = tile_n * (BN / 32) + q / NP;
-            rb = rb < p.b_rb ? rb : p.b_rb - 1;
-            src[i] = p.B + ((long)rb * KB) * BLKP + (q % NP) * PIECE;
-        }
+    // ---- which tiles, in which order ------------------------------------------------------------------------------------------------
+    // Tiles are numbered so that an XCD (hardware blocks b with equal b & 7 share one: observed placement, speed only) owns a contiguous
+    // chunk, swept in groups of 8 row tiles x all column tiles.  Non-persistent: block b takes tile chunk_base(b & 7) + (b >> 3).
+    // Persistent: block b takes chunk entries (b >> 3) + k * (gridDim.x >> 3), k = 0, 1, ...
+    const int n_tiles = p.tiles_m * p.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int chunk_base, chunk_size;
+    {
+        const int total = PERSIST ? n_tiles : (int)gridDim.x;
+        const int q = total >> 3, r = total & 7;
+        chunk_base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        chunk_size = q + (xcd < r ? 1 : 0);
     }
+    const int per_round = PERSIST ? (int)(gridDim.x >> 3) : 1;
+    const int my_tiles = PERSIST ? (slot < chunk_size ? (chunk_size - slot + per_round - 1) / per_round : 0) : 1;
+    if (my_tiles == 0) return;
+    int split = 0;   // first k-step of the first tile's FIRST pass (0: the tile is not split)
+    if constexpr (PERSIST) {
+        split = (my_tiles >= 2 && p.work) ? (nt * xcd) >> 3 : 0;
+        if (split < 3 || nt - split < 3) split = 0;
+    }
+    const int n_items = my_tiles + (split ? 1 : 0);
+
     const unsigned lane16 = lane * 16;
-    static_assert(!CONV || PA <= 2 * NW, "conv: at most two A pieces per wave");
+    const unsigned char* src[PW];
     int cv_row[2] = {-1, -1}, cv_yx[2] = {0, 0};
     int cv_dy = -1, cv_dx = -1, cv_cb = 0;
-    if constexpr (CONV) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pc = wave + NW * i;
-            if (pc < PA) {
-                const int r = tile_m * BM + (pc / NP) * 32 + (lane & 31);
-                const int hw = p.cH * p.cW;
-                const int rem = r % hw, oy = rem / p.cW;
-                cv_row[i] = r < p.M ? r : -1;
-                cv_yx[i] = (oy << 16) | (rem - oy * p.cW);
-            }
-        }
-    }
     auto conv_advance = [&]() {
         if constexpr (CONV) {
             if (++cv_dx == 2) {
@@ -151,11 +197,11 @@ __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
             }
         }
     };
-    // request piece i of this wave for 16-deep slab `slab` (into LDS stage slab & 3)
-    auto issue_piece = [&](auto idx, int slab) {
+    // request piece i of this wave: 16-deep slab `slab` of the operands into LDS stage `stage`
+    auto issue_piece = [&](auto idx, int slab, int stage) {
         constexpr int i = decltype(idx)::value;
         const int pc = wave + NW * i;
-        const unsigned dst = lds0 + (slab & 3) * STAGE + pc * PIECE;
+        const unsigned dst = lds0 + stage * STAGE + pc * PIECE;
         if constexpr (CONV && i < 2) {
             if (pc < PA) {   // wave-uniform
                 const int iy = (cv_yx[i] >> 16) + cv_dy, ix = (cv_yx[i] & 0xffff) + cv_dx;
@@ -174,18 +220,10 @@ __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
             glds16(reinterpret_cast<const unsigned char*>(((unsigned long)hi << 32) | lo) + lane16, dst);
         }
     };
-    auto issue_slab = [&](int slab) {
-        [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(std::integral_constant<int, I>{}, slab), ...); }(std::make_integer_sequence<int, PW>{});
+    auto issue_slab = [&](int slab, int stage) {
+        [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(std::integral_constant<int, I>{}, slab, stage), ...); }(std::make_integer_sequence<int, PW>{});
         conv_advance();
     };
-
-    f32x4 acc[TMo][4];
-#pragma unroll
-    for (int i = 0; i < TMo; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
     // fragment addresses inside pair 0: lane (r, q) -> k block (q >> 1), slot (q & 1) * 32 + r
     const unsigned lane_off = (unsigned)(((lane >> 5) & 1) * STAGE + ((((lane >> 4) & 1) * 32) + (lane & 15)) * 16);
@@ -202,8 +240,6 @@ __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
         b[n][0] = lds_frag<(n >> 1) * BLKP + (n & 1) * 256>(base);
         b[n][1] = lds_frag<(n >> 1) * BLKP + (n & 1) * 256 + PIECE>(base);
     };
-
-    // KS: ratio table R[row][c] = inv[row][c-1] / inv[row][c] (c >= 1) behind the four stages, before any LDS-DMA is in flight
     const unsigned ktab = lds0 + 4 * STAGE;
     float kratio[TMo];
     auto kratio_request = [&](int c) {
@@ -213,30 +249,10 @@ __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
                 asm volatile("ds_read_b32 %0, %1" : "=v"(kratio[i]) : "v"(ktab + (unsigned)(((wm * WM + i * 16 + (lane & 15)) * p.k_chunks + c) * 4)));
         }
     };
-    if constexpr (KS) {
-        float* tab = reinterpret_cast<float*>(smem + 4 * STAGE);
-        const int nch = p.k_chunks;
-        for (int e = threadIdx.x; e < BM * nch; e += 512) {
-            const int rl = e / nch, c = e - rl * nch;
-            long row = (long)tile_m * BM + rl;
-            row = row < p.M ? row : p.M - 1;
-            tab[e] = c ? p.a_kscale[row * nch + c - 1] / p.a_kscale[row * nch + c] : 1.0f;
-        }
-        __syncthreads();
-    }
+    f32x4 acc[TMo][4];
+    int kbase = 0;   // first 16-deep slab of the pass being run (2 * its first k-step)
 
-    // prologue: all four stages requested, wait for the first pair, fetch its fragments
-    issue_slab(0);
-    issue_slab(1);
-    issue_slab(2);
-    issue_slab(3);
-    wait_groups_ct<PT, NW, 2>(wave < PT % NW);
-    __builtin_amdgcn_s_barrier();
-    [&]<int... I>(std::integer_sequence<int, I...>) { (read_a(std::integral_constant<int, I>{}, a_frag), ...); }(std::make_integer_sequence<int, TMo>{});
-    [&]<int... I>(std::integer_sequence<int, I...>) { (read_b(std::integral_constant<int, I>{}, b_frag), ...); }(std::make_integer_sequence<int, 4>{});
-    if constexpr (KS) kratio_request(1);
-
-    // One 32-deep step.  MFMA q = (i * 4 + j) * 3 + product; rows i ascending, columns j ascending.
+    // One 32-deep step, `t` counted from the pass's first step.  MFMA q = (i * 4 + j) * 3 + product; rows i ascending, columns j ascending.
     //   after MFMA 8 (row 0, columns 0-2 done)        the step's only synchronisation B_t (unless this is the last step)
     //   DMA && after MFMA 9 + 3 d                     piece d of the 2 PW pieces of slabs 2t + 4, 2t + 5 (into the pair this step reads)
     //   NEXT && one MFMA into row i + 1               A operand i of step t + 1 (from the other pair); in the last row, B operand j
@@ -284,7 +300,7 @@ __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
             }
             if constexpr (DMA && q > SYNC_AT && (q - SYNC_AT - 1) % 3 == 0 && (q - SYNC_AT - 1) / 3 < 2 * PW) {
                 constexpr int d = (q - SYNC_AT - 1) / 3;
-                issue_piece(std::integral_constant<int, d % PW>{}, 2 * t + 4 + d / PW);
+                issue_piece(std::integral_constant<int, d % PW>{}, kbase + 2 * t + 4 + d / PW, (2 * t + d / PW) & 3);
                 if constexpr (d % PW == PW - 1) conv_advance();
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -298,16 +314,123 @@ __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
         [&]<int... Q>(std::integer_sequence<int, Q...>) { (body(std::integral_constant<int, Q>{}), ...); }(std::make_integer_sequence<int, NM>{});
     };
 
-    // nt >= 3 (the host sends K < 96 to the 32x32x16 kernel): first step, steady steps, the step with nothing left to request, the last
-    step(StepKind<true, true, true>{}, 0);
-#pragma unroll 1
-    for (int t = 1; t < nt - 2; ++t) step(StepKind<true, true, false>{}, t);
-    step(StepKind<false, true, false>{}, nt - 2);
-    step(StepKind<false, false, false>{}, nt - 1);
+    float4* const park = PERSIST && p.work ? reinterpret_cast<float4*>(p.work) + ((long)blockIdx.x * NW + wave) * (TMo * 4) * 64 + lane : nullptr;
 
-    __syncthreads();  // every wave is past its last LDS read: the stages become epilogue scratch
-    float* scratch = reinterpret_cast<float*>(smem) + wave * (TMo * 16 * 37);
-    epilogue16<TMo, EPI>(p, acc, tile_m * BM + wm * WM, tile_n * BN + wn * 64, lane, scratch);
+#pragma unroll 1
+    for (int item = 0; item < n_items; ++item) {
+        // item 0 with a split: k-steps [split, nt) of the first tile, accumulators parked; last item with a split: its k-steps [0, split)
+        // on top of the parked accumulators; everything else: a whole tile
+        const bool first_pass = split && item == 0, second_pass = split && item == n_items - 1;
+        const int tile_no = second_pass ? 0 : item;
+        const int t0 = first_pass ? split : 0, steps = first_pass ? nt - split : (second_pass ? split : nt);
+        const int bid = chunk_base + slot + tile_no * per_round;
+        constexpr int GROUP_M = 8;
+        const int gsize_full = GROUP_M * p.tiles_n;
+        const int group = bid / gsize_full;
+        const int gm0 = group * GROUP_M;
+        const int gm = p.tiles_m - gm0 < GROUP_M ? p.tiles_m - gm0 : GROUP_M;
+        const int in_group = bid - group * gsize_full;
+        const int tile_m = gm0 + in_group % gm, tile_n = in_group / gm;
+        kbase = 2 * t0;
+
+        // this wave's DMA sources (slab 0): wave-uniform bases + one lane offset
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int pc = wave + NW * i;
+            if (pc < PA) {
+                int rb = tile_m * (BM / 32) + pc / NP;
+                rb = rb < p.a_rb ? rb : p.a_rb - 1;
+                src[i] = p.A + ((long)rb * KB) * BLKP + (pc % NP) * PIECE;
+            } else {
+                const int q = pc < PT ? pc - PA : 0;
+                int rb = tile_n * (BN / 32) + q / NP;
+                rb = rb < p.b_rb ? rb : p.b_rb - 1;
+                src[i] = p.B + ((long)rb * KB) * BLKP + (q % NP) * PIECE;
+            }
+        }
+        static_assert(!CONV || PA <= 2 * NW, "conv: at most two A pieces per wave");
+        if constexpr (CONV) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pc = wave + NW * i;
+                if (pc < PA) {
+                    const int r = tile_m * BM + (pc / NP) * 32 + (lane & 31);
+                    const int hw = p.cH * p.cW;
+                    const int rem = r % hw, oy = rem / p.cW;
+                    cv_row[i] = r < p.M ? r : -1;
+                    cv_yx[i] = (oy << 16) | (rem - oy * p.cW);
+                }
+            }
+        }
+        if (second_pass) {
+            const float4* pk = park;
+            asm volatile("" : "+v"(pk));   // (keeps hipcc from hoisting 32 address pairs out of the tile loop and spilling them)
+#pragma unroll
+            for (int i = 0; i < TMo; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = pk[(i * 4 + j) * 64];
+                    acc[i][j][0] = v.x; acc[i][j][1] = v.y; acc[i][j][2] = v.z; acc[i][j][3] = v.w;
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TMo; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        }
+
+        // KS: ratio table R[row][c] = inv[row][c-1] / inv[row][c] (c >= 1) behind the four stages, before any LDS-DMA is in flight
+        if constexpr (KS) {
+            float* tab = reinterpret_cast<float*>(smem + 4 * STAGE);
+            const int nch = p.k_chunks;
+            for (int e = threadIdx.x; e < BM * nch; e += 512) {
+                const int rl = e / nch, c = e - rl * nch;
+                long row = (long)tile_m * BM + rl;
+                row = row < p.M ? row : p.M - 1;
+                tab[e] = c ? p.a_kscale[row * nch + c - 1] / p.a_kscale[row * nch + c] : 1.0f;
+            }
+            __syncthreads();
+        }
+
+        // prologue: all four stages requested, wait for the first pair, fetch its fragments
+        issue_slab(kbase + 0, 0);
+        issue_slab(kbase + 1, 1);
+        issue_slab(kbase + 2, 2);
+        issue_slab(kbase + 3, 3);
+        wait_groups_ct<PT, NW, 2>(wave < PT % NW);
+        __builtin_amdgcn_s_barrier();
+        [&]<int... I>(std::integer_sequence<int, I...>) { (read_a(std::integral_constant<int, I>{}, a_frag), ...); }(std::make_integer_sequence<int, TMo>{});
+        [&]<int... I>(std::integer_sequence<int, I...>) { (read_b(std::integral_constant<int, I>{}, b_frag), ...); }(std::make_integer_sequence<int, 4>{});
+        if constexpr (KS) kratio_request(1);
+
+        // steps >= 3 (the host sends K < 96 to the 32x32x16 kernel; a split leaves >= 3 steps on either side): first step, steady steps,
+        // the step with nothing left to request, the last
+        step(StepKind<true, true, true>{}, 0);
+#pragma unroll 1
+        for (int t = 1; t < steps - 2; ++t) step(StepKind<true, true, false>{}, t);
+        step(StepKind<false, true, false>{}, steps - 2);
+        step(StepKind<false, false, false>{}, steps - 1);
+
+        if (first_pass) {   // park the partial sums: 16 bytes per lane and instruction, 1 KB per wave-instruction, this workgroup's own slab
+            float4* pk = park;
+            asm volatile("" : "+v"(pk));
+#pragma unroll
+            for (int i = 0; i < TMo; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[(i * 4 + j) * 64] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            __syncthreads();   // every wave is past its last LDS read before the next pass's DMA overwrites the stages
+        } else if constexpr (EPI >= 0 && (EPI & E_H2OUT) != 0 && (EPI & (E_F32 | E_TP3 | E_RES | E_RELU)) == 0 && !PERSIST) {
+            epilogue16_direct<TMo, EPI>(p, acc, tile_m * BM + wm * WM, tile_n * BN + wn * 64, lane,   // registers -> images: no scratch, no barrier
+                                        (((long)tile_m * p.tiles_n + tile_n) * NW + wave) * (TMo * 4));
+        } else {
+            __syncthreads();  // every wave is past its last LDS read: the stages become epilogue scratch
+            float* scratch = reinterpret_cast<float*>(smem) + wave * (TMo * 16 * 37);
+            epilogue16<TMo, EPI>(p, acc, tile_m * BM + wm * WM, tile_n * BN + wn * 64, lane, scratch);
+            if constexpr (PERSIST) __syncthreads();   // ... and stage memory again before the next tile's first DMA
+        }
+    }
 }
 
 template <int BM, int EPI, bool KS = false, bool CONV = false>
@@ -320,15 +443,34 @@ int launch_m(const Tp3Params& p0, hipStream_t s) {
     constexpr size_t ks_bytes = KS ? (size_t)BM * 64 * sizeof(float) : 0;
     constexpr size_t smem = (stage_bytes + ks_bytes) > epi_bytes ? (stage_bytes + ks_bytes) : epi_bytes;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = gemm_h2m_kernel<BM, EPI, KS, CONV>;
-    static int attr_dev_mask = 0;
+    const long n_tiles = (long)p.tiles_m * p.tiles_n;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1;
+    // multi-round launches of the image-writing epilogues walk their tiles persistently (see the kernel): needs the caller's workspace
+    // (PERSIST_GRID x 8 waves x BM/2 x 64 floats) and at least two tiles per workgroup of every XCD
+    constexpr bool CAN_PERSIST = !KS && !CONV && EPI >= 0 && (EPI & (E_H2OUT | E_PRE)) != 0;
+    if constexpr (CAN_PERSIST) {
+        constexpr int PERSIST_GRID = 256;
+        constexpr size_t work_bytes = (size_t)PERSIST_GRID * 8 * (BM / 2 / 16 * 4) * 64 * sizeof(float4);
+        if (p.work && p.work_bytes >= (long)work_bytes && n_tiles >= 2 * PERSIST_GRID + 8 && p.K >= 8 * 32 && getenv("TVL_GEMM_PERSIST") && getenv("TVL_GEMM_PERSIST")[0] == '1') {   // opt-in: measured SLOWER (see below)
+            auto kern = gemm_h2m_kernel<BM, EPI, KS, CONV, true>;
+            static int attr_mask = 0;
+            if (!(attr_mask & (1 << dev))) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 1;
+                attr_mask |= 1 << dev;
+            }
+            hipLaunchKernelGGL(kern, dim3(PERSIST_GRID), dim3(512), smem, s, p);
+            return 0;
+        }
+    }
+    p.work = nullptr;
+    auto kern = gemm_h2m_kernel<BM, EPI, KS, CONV, false>;
+    static int attr_dev_mask = 0;
     if (!(attr_dev_mask & (1 << dev))) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 1;
         attr_dev_mask |= 1 << dev;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long)p.tiles_m * p.tiles_n)), dim3(512), smem, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(512), smem, s, p);
     return 0;
 }
 

@@ -56,6 +56,8 @@ class GemmTp3Args(C.Structure):
         ("dact_aux", C.c_void_p), ("ld_aux", C.c_int32), ("dact", C.c_int32),
         ("alpha", C.c_float),
         ("tile_m", C.c_int32), ("variant", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("aux_blocked", C.c_int32),
     ]
 
 
@@ -172,7 +174,8 @@ _SIGS = {
     "tvl_dynconv_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
     "tvl_dynconv_bwd": [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
 }
-EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_h2_bytes", "tvl_dicece_work_doubles", *_SIGS]
+EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_h2_bytes", "tvl_dicece_work_doubles",
+           "tvl_gemm_aux_floats", *_SIGS]
 
 _lib = None
 ABI_VERSION = 4   # include/tvl_hip.h TVL_ABI_VERSION
@@ -198,6 +201,8 @@ def load():
     lib.tvl_dynconv_bwd_work_floats.restype = C.c_int64
     lib.tvl_dicece_work_doubles.argtypes = [_I, _L]
     lib.tvl_dicece_work_doubles.restype = C.c_int64
+    lib.tvl_gemm_aux_floats.argtypes = [_L, _L]
+    lib.tvl_gemm_aux_floats.restype = C.c_int64
     lib.tvl_tp3_bytes.argtypes = [_L, _I]
     lib.tvl_tp3_bytes.restype = C.c_int64
     for name, sig in _SIGS.items():
@@ -512,6 +517,27 @@ def tp3_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, alph
     return f"gemm_tp3_kernel<{tile}, 256, {variant}, {epi}, 3, false, false>"
 
 
+GEMM_WORKSPACE_BYTES = 64 << 20
+_GEMM_WORK: dict = {}
+
+
+def gemm_aux(M: int, N: int, device) -> torch.Tensor | None:
+    """A buffer for fc1's pre-activation in the GEMM's own accumulator order (``aux_blocked``), or None when the shape does not qualify:
+    written by fc1's epilogue, read by the QuickGELU' epilogue of its data gradient, never anything else -- fully coalesced both ways."""
+    n = load().tvl_gemm_aux_floats(M, N)
+    return torch.empty(n, device=device, dtype=torch.float32) if n > 0 and GEMM_M16 else None
+
+
+def gemm_workspace() -> torch.Tensor:
+    """64 MiB of device memory per (device, stream) for the persistent tile walk of the image-writing GEMMs (tvlGemmTp3Args.workspace):
+    a workgroup parks one partial tile there between the two passes over its split first tile."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    w = _GEMM_WORK.get(key)
+    if w is None:
+        w = _GEMM_WORK[key] = torch.empty(GEMM_WORKSPACE_BYTES, device="cuda", dtype=torch.uint8)
+    return w
+
+
 class H2:
     """An fp32 matrix [rows, cols] as two fp16 pieces per element of the row- (activations) or tensor- (weights) scaled values, in
     MFMA-fragment order (include/tvl_hip.h, "h2"): the operand format of ``tvl_gemm_h2`` -- 3 MFMAs per product instead of tp3's 6.
@@ -588,7 +614,8 @@ def weight_h2(W: torch.Tensor) -> H2:
 
 def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = None, out_tp3: Tp3 | None = None, want_f32=True,
             want_tp3=False, bias=None, residual=None, act=ACT_NONE, pre_out=None, dact_aux=None, dact=ACT_NONE, tile_m: int = 0,
-            want_h2=False, out_mul: float | None = None, out_add: float = 0.0, out_per_tensor: bool = False):
+            want_h2=False, out_mul: float | None = None, out_add: float = 0.0, out_per_tensor: bool = False, persistent: bool = True,
+            aux_blocked: bool = False):
     """epilogue(A . B^T) over h2 operands (A row-scaled, B tensor-scaled); returns (C fp32 or None, C as Tp3 / H2 or None).
     ``want_h2``: the result as an H2 image (next GEMM's A operand); its row scales come from the bound
     ``A.row_norm[m] * out_mul + out_add`` (out_mul defaults to B's largest row norm)."""
@@ -605,10 +632,16 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
         if A.row_norm is None or (out_mul is None and B._bound is None):
             raise RuntimeError("gemm_h2(want_h2=True) needs A.row_norm (from A's producer) and a bound factor (weight_h2 / out_mul)")
         Ch = H2(M, N, dev, per_row=not out_per_tensor)
-    ldc = Cf.stride(0) if Cf is not None else (pre_out.stride(0) if pre_out is not None else N)
+    if aux_blocked:   # pre_out / dact_aux: flat private buffers of gemm_aux(M, N)
+        ldc, ld_aux, pre_p, aux_p = N, N, _p(pre_out), _p(dact_aux)
+    else:
+        ldc = Cf.stride(0) if Cf is not None else (pre_out.stride(0) if pre_out is not None else N)
+        ld_aux, pre_p, aux_p = (0 if dact_aux is None else dact_aux.stride(0)), _ps(pre_out), _ps(dact_aux)
     args = GemmTp3Args(M, N, K, A.buf.data_ptr(), A.rows, B.buf.data_ptr(), B.rows, _ps(Cf), ldc, None if Ct is None else Ct.buf.data_ptr(),
-                       _p(bias), _ps(residual), 0 if residual is None else residual.stride(0), act, _ps(pre_out), _ps(dact_aux),
-                       0 if dact_aux is None else dact_aux.stride(0), dact, B.alpha(), tile_m, GEMM_TP3_VARIANT)
+                       _p(bias), _ps(residual), 0 if residual is None else residual.stride(0), act, pre_p, aux_p,
+                       ld_aux, dact, B.alpha(), tile_m, GEMM_TP3_VARIANT,
+                       gemm_workspace().data_ptr() if (persistent and (Ch is not None or pre_out is not None)) else None, GEMM_WORKSPACE_BYTES,
+                       1 if aux_blocked else 0)
     if _gemm_prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

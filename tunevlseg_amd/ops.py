@@ -133,10 +133,16 @@ class EncoderLayerTp3Fn(Fn):
         else:
             h2, _ = hip.gemm_tp3(o, W["wo"], bias=lw.bo, residual=h2d)
         x2, mean2, rstd2 = ln_fwd(h2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
-        z = torch.empty((M, lw.w1.shape[0]), device=h.device, dtype=torch.float32) if need else None
+        h2_mlp = use_h2 and spec.act == hip.ACT_QUICK_GELU
+        # the MLP pre-activation is read by exactly one kernel, the QuickGELU' epilogue of the fc2 data gradient: on the h2 path it stays
+        # in the GEMM's own accumulator order (hip.gemm_aux: both sides fully coalesced) instead of a row-major [M, F] matrix
+        z = (hip.gemm_aux(M, lw.w1.shape[0], h.device) if h2_mlp else None) if need else None
+        if need and z is None:
+            z = torch.empty((M, lw.w1.shape[0]), device=h.device, dtype=torch.float32)
         out = torch.empty((B, T, D), device=h.device, dtype=torch.float32)  # a base tensor: deep prompts overwrite rows in place
-        if use_h2 and spec.act == hip.ACT_QUICK_GELU:   # fc1's epilogue writes QuickGELU(z) as h2 too: |QuickGELU(z)| <= |z| <= ||x2 row|| max_n ||W1 row n|| + max |b1|
-            _, a = hip.gemm_h2(x2, WL["w1"], want_f32=False, want_h2=True, out_add=WL["b1_max"], bias=lw.b1, act=spec.act, pre_out=z)
+        if h2_mlp:   # fc1's epilogue writes QuickGELU(z) as h2 too: |QuickGELU(z)| <= |z| <= ||x2 row|| max_n ||W1 row n|| + max |b1|
+            _, a = hip.gemm_h2(x2, WL["w1"], want_f32=False, want_h2=True, out_add=WL["b1_max"], bias=lw.b1, act=spec.act, pre_out=z,
+                               aux_blocked=z is not None and z.dim() == 1)
             hip.gemm_h2(a, WL["w2"], out=out.view(M, D), bias=lw.b2, residual=h2)
         else:
             _, a = gemm_ln(x2, WL["w1"], want_f32=False, want_tp3=True, bias=lw.b1, act=spec.act, pre_out=z)
@@ -165,7 +171,8 @@ class EncoderLayerTp3Fn(Fn):
         if dout_t is None or isinstance(dout_t, hip.H2) != use_h2:
             dout_t = hip.h2_pack(dout2d, per_row=True, want_norm=True) if use_h2 else hip.tp3_pack(dout2d)
         if use_h2 and spec.act == hip.ACT_QUICK_GELU:   # |dz| <= QUICK_GELU_LIP ||dout row|| max_n ||W2^T row n||
-            _, dz = hip.gemm_h2(dout_t, WL["w2_t"], want_f32=False, want_h2=True, out_mul=QUICK_GELU_LIP * WL["w2_t"]._bound, dact=spec.act, dact_aux=z)
+            _, dz = hip.gemm_h2(dout_t, WL["w2_t"], want_f32=False, want_h2=True, out_mul=QUICK_GELU_LIP * WL["w2_t"]._bound, dact=spec.act, dact_aux=z,
+                                aux_blocked=z.dim() == 1)
             dx2, _ = hip.gemm_h2(dz, WL["w1_t"])
         else:
             _, dz = gemm_ln(dout_t, WL["w2_t"], want_f32=False, want_tp3=True, dact=spec.act, dact_aux=z)
