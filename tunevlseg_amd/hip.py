@@ -677,7 +677,7 @@ def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_
               (8 if dact else 0) | (16 if pre_out else 0) | (32 if c_f32 else 0) | (64 if c_tp3 else 0) | 128 | (256 if c_h2 else 0)
         if (act & ~0xFF) or (act & 0xFF) not in (ACT_NONE, ACT_QUICK_GELU, ACT_RELU) or epi not in _H2M_EPI_BUILT:
             epi = -1
-        return f"gemm_h2m_kernel<{tile}, {epi}, false, false>"
+        return f"gemm_h2m_kernel<{tile}, {epi}, false, false, false>"
     tile = tile_m
     if tile not in (192, 256):
         t256, t192 = -(-M // 256) * -(-N // 256), -(-M // 192) * -(-N // 256)
@@ -703,7 +703,7 @@ def conv_h2_kernel_name(M, N, bias, act) -> str:
     tile = conv_h2_tile(M, N)
     epi = 673 if (bias and act == ACT_RELU) else (160 if not (bias or act) else -1)
     if GEMM_M16:
-        return f"gemm_h2m_kernel<{tile}, {epi}, false, true>"
+        return f"gemm_h2m_kernel<{tile}, {epi}, false, true, false>"
     return f"gemm_tp3_kernel<{tile}, 256, {2 if tile == 256 else 3}, {epi}, 2, false, true>"
 
 
@@ -979,7 +979,7 @@ def gemm_h2_ks(A: H2K, B: H2, out: torch.Tensor | None = None) -> torch.Tensor:
     _call("tvl_gemm_h2_ks", C.byref(args), _p(A.kscale))
     if _gemm_prof is not None:
         e1.record()
-        _gemm_prof.append(("gemm_h2m_kernel<192, 160, true, false>" if (GEMM_M16 and K >= 96) else "gemm_tp3_kernel<192, 256, 3, 160, 2, true, false>", 2.0 * M * N * K, e0, e1))
+        _gemm_prof.append(("gemm_h2m_kernel<192, 160, true, false, false>" if (GEMM_M16 and K >= 96) else "gemm_tp3_kernel<192, 256, 3, 160, 2, true, false>", 2.0 * M * N * K, e0, e1))
     return Cf
 
 
