@@ -28,8 +28,9 @@ typedef void* tvlStream_t; /* hipStream_t */
 
 /* Bumped on every incompatible change of a signature or struct below.  3: tvl_dicece_stats gained `work`, tvl_split_planes /
  * tvl_gemm_planes removed (round 2).  4: tvl_text_assemble gained `vocab` (rows of the embedding table: ids outside it give NaN rows
- * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  The Python binding refuses a library whose tvl_abi_version() differs. */
-#define TVL_ABI_VERSION 4
+ * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  5: tvl_dicece_loss added;
+ * tvl_layernorm_fwd_h2 / _bwd_h2 gained max_slot / tag (largest row norm by tagged atomicMax).  The Python binding refuses a library whose tvl_abi_version() differs. */
+#define TVL_ABI_VERSION 5
 
 const char* tvl_last_error(void);
 int tvl_abi_version(void);
@@ -201,6 +202,12 @@ int tvl_upconv_taps_bwd(const float* dout, float* dtaps, int32_t ldg, float* wor
 int64_t tvl_dicece_work_doubles(int32_t B, int64_t N);
 int tvl_dicece_stats(const float* logits, const float* target, double* fsum, int64_t* isum, uint8_t* label, double* work,
                      int32_t B, int64_t N, float thr, tvlStream_t stream);
+/* loss[0] = lambda_dice * mean_b[1 - (2 fsum[b][0] + smooth_nr) / (fsum[b][1] + fsum[b][2] + smooth_dr)] + lambda_ce * sum_b fsum[b][3] / (B N):
+ * monai DiceCELoss(sigmoid=True) for one channel (mean over the batch of the per-sample Dice term; BCE-with-logits, mean over all
+ * elements), float64 inside, fixed summation order, written as one fp32 scalar on the device (no host round trip, one launch instead of
+ * the dozen tensor-library launches of the same arithmetic) */
+int tvl_dicece_loss(const double* fsum, float* loss, int32_t B, int64_t N, float lambda_dice, float lambda_ce,
+                    float smooth_nr, float smooth_dr, tvlStream_t stream);
 /* dlogits = gscale * ( lambda_dice * dDice/dlogit + lambda_ce * (p - t)/(B*N) ), using fsum from tvl_dicece_stats */
 int tvl_dicece_bwd(const float* logits, const float* target, const double* fsum, float* dlogits,
                    int32_t B, int64_t N, float lambda_dice, float lambda_ce, float smooth_nr, float smooth_dr,
@@ -310,6 +317,8 @@ typedef struct {
     int32_t aux_blocked;   /* tvl_gemm_h2_out only: pre_out (written) / dact_aux (read) is not a row-major matrix but a private buffer of
                             * tvl_gemm_aux_floats(M, N) floats in the producing kernel's accumulator order -- fc1's z handed to its data
                             * gradient's QuickGELU' epilogue; both calls must have the same M and N */
+    int32_t a_scale_one;   /* tvl_gemm_h2 / tvl_gemm_h2_out: a_row_scale points at ONE inverse scale for every row of A (a tensor-scaled
+                            * activation image, e.g. the attention output that shares the QKV scale) instead of at M of them */
 } tvlGemmTp3Args;
 int tvl_gemm_tp3(const tvlGemmTp3Args* args, tvlStream_t stream);
 /* floats in an aux_blocked buffer for an [M, N] result (whole 256 x 256 tiles), or -1 when the shape cannot use one */
@@ -351,11 +360,16 @@ int tvl_attn_h2_fwd(const void* qkv_h2, const float* qkv_inv, void* o_img, int32
 int tvl_attn_h2_bwd(const void* qkv_h2, const float* qkv_inv, const void* o_img, int32_t o_is_h2, const void* do_h2, const float* do_inv, const float* lse,
                     float* delta, void* dnorm_ws, void* dqkv_img, int32_t g_as_h2 /* h2 image + g_kscale [B*T, 3*H], else tp3 */, float* g_kscale,
                     int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream);
-/* LayerNorm forward / backward writing their result as an h2 operand (+ inv_scale[rows]); otherwise as tvl_layernorm_fwd_tp3 / _bwd_tp3 */
+/* LayerNorm forward / backward writing their result as an h2 operand (+ inv_scale[rows]); otherwise as tvl_layernorm_fwd_tp3 / _bwd_tp3.
+ * max_slot (or null; needs row_norm): 8 bytes of device memory that receive max_m row_norm[m] without being cleared first -- every
+ * workgroup does ONE atomicMax of (tag << 32 | float bits of its largest row norm) on the 64-bit word, so the value of the call with
+ * the largest tag wins: the caller passes a tag larger than any the slot has seen (zero-initialised memory + a call counter), and the
+ * consumer (tvl_gemm_h2_out, out_per_tensor) reads the LOW 32 bits as a float: its out_row_norm.  Replaces a reduction launch per GEMM. */
 int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const float* beta, void* y_h2, float* inv_scale, float* row_norm /* or null */, float* mean, float* rstd,
-                         int64_t rows, int32_t cols, float eps, tvlStream_t stream);
+                         int64_t rows, int32_t cols, float eps, uint64_t* max_slot, uint32_t tag, tvlStream_t stream);
 int tvl_layernorm_bwd_h2(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres,
-                         float* dx, void* dx_h2, float* inv_scale, float* row_norm /* or null */, int64_t rows, int32_t cols, tvlStream_t stream);
+                         float* dx, void* dx_h2, float* inv_scale, float* row_norm /* or null */, int64_t rows, int32_t cols,
+                         uint64_t* max_slot, uint32_t tag, tvlStream_t stream);
 
 /* nn.AvgPool2d(k) / F.avg_pool2d(x, k, k) on [B,H,W,C] (H, W divisible by k) and its gradient (H, W = input sizes) */
 int tvl_avgpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, tvlStream_t stream);

@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     from tunevlseg_amd import hip
 
     lib = hip.load()
-    assert lib.tvl_abi_version() == 4
+    assert lib.tvl_abi_version() == 5
     decl = declared_symbols()
     assert len(decl) >= 30
     missing = [s for s in decl if not hasattr(lib, s)]
@@ -44,6 +44,8 @@ def test_struct_layouts_match_header(tmp_path):
         pytest.skip("gcc not available")
     probe = tmp_path / "probe.c"
     fields = {"tvlGemmArgs": ["layout", "A", "ldb", "C", "bias", "residual", "act", "pre_out", "dact_aux", "dact", "alpha", "a_map", "c_map"],
+              "tvlGemmTp3Args": ["M", "A", "a_rows", "B", "C", "ldc", "C_tp3", "bias", "residual", "ldr", "act", "pre_out", "dact_aux", "ld_aux", "dact", "alpha",
+                                 "tile_m", "variant", "workspace", "workspace_bytes", "aux_blocked", "a_scale_one"],
               "tvlAttnFwdArgs": ["q", "q_bs", "q_ts", "o", "ldo", "lse", "key_mask", "B", "causal", "scale", "Tk"],
               "tvlAttnBwdArgs": ["q", "v_ts", "o", "d_o", "ldo", "lse", "delta", "dq", "dq_bs", "dv_ts", "key_mask", "B", "scale", "Tk"]}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT / "include" / "tvl_hip.h"}"', "int main(void){"]
@@ -55,7 +57,7 @@ def test_struct_layouts_match_header(tmp_path):
     exe = tmp_path / "probe"
     subprocess.run(["gcc", str(probe), "-o", str(exe)], check=True)
     out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
-    mirror = {"tvlGemmArgs": hip.GemmArgs, "tvlAttnFwdArgs": hip.AttnFwdArgs, "tvlAttnBwdArgs": hip.AttnBwdArgs}
+    mirror = {"tvlGemmArgs": hip.GemmArgs, "tvlGemmTp3Args": hip.GemmTp3Args, "tvlAttnFwdArgs": hip.AttnFwdArgs, "tvlAttnBwdArgs": hip.AttnBwdArgs}
     for st, fs in fields.items():
         assert int(out[st]) == C.sizeof(mirror[st]), st
         for f in fs:

@@ -319,6 +319,8 @@ def test_dicece_stats_and_grad(hip):
     tp, fp, fn, tn = O.confusion_counts(torch.sigmoid(logits), target.long())
     assert torch.equal(isum.cpu(), torch.stack((tp, fp, fn, tn), 1))
     assert torch.equal(label.cpu().bool(), torch.sigmoid(logits) > 0.5)
+    loss_dev = hip.dicece_loss(fsum, S * S, 1.0, 0.2)   # the same arithmetic in one launch, fp32 scalar on the device
+    assert loss_dev.dtype == torch.float32 and loss_dev.item() == loss.to(torch.float32).item()
     gs = torch.tensor([0.7], device="cuda")
     dl = hip.dicece_bwd(dev(logits), dev(target), fsum, 1.0, 0.2, 1e-5, 1e-5, gs)
     close(dl, 0.7 * ld.grad, 2e-5, "dicece grad")
@@ -639,6 +641,14 @@ def test_layernorm_h2_forward_and_backward(hip):
     assert torch.equal(dx, dx3)   # the fp32 result is the same kernel code
     e = (dxt.float() - dx).abs()
     assert (e <= dx.abs().amax(1, keepdim=True) * 2.0**-20).all()
+    # the largest row norm arrives by tagged atomicMax in an un-cleared slot: equal to the reduction over row_norm, call after call
+    assert torch.equal(y.norm_max, y.row_norm.max().reshape(1)) and torch.equal(dxt.norm_max, dxt.row_norm.max().reshape(1))
+    from tunevlseg_amd import hip as H
+    first = y.norm_max.item()
+    H._max_slot_calls += 4096 - 2   # the next two calls land on the two slots just used, one turn of the pool later
+    ys, _, _ = hip.layernorm_fwd_h2(dev(x), dev(g * 1e-3), dev(b * 1e-3), 1e-5)      # smaller norms than the slot's previous owner
+    assert torch.equal(ys.norm_max, ys.row_norm.max().reshape(1)) and ys.norm_max.item() < 2e-3 * first
+    assert ys.norm_max.data_ptr() == y.norm_max.data_ptr()
 
 
 def test_gemm_h2_with_h2_output_feeds_the_next_gemm(hip):

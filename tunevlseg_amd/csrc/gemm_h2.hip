@@ -317,7 +317,7 @@ static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void*
     p.B = reinterpret_cast<const unsigned char*>(a->B); p.b_rb = (int)((a->b_rows + 31) / 32);
     p.C = a->C; p.ldc = a->ldc; p.Cp = reinterpret_cast<unsigned char*>(a->C_tp3);
     p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.act = a->act; p.pre_out = a->pre_out;
-    p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha; p.a_scale = a_row_scale; p.a_sstride = conv ? 0 : 1;
+    p.dact_aux = a->dact_aux; p.ld_aux = a->ld_aux; p.dact = a->dact; p.alpha = a->alpha; p.a_scale = a_row_scale; p.a_sstride = (conv || a->a_scale_one) ? 0 : 1;
     p.aux_blocked = a->aux_blocked;
     TVL_REQUIRE(!a->aux_blocked || (c_h2 && !a->C && !a->C_tp3 && !a->residual && !conv && a->tile_m == 0 && aux_blocked_ok(a->M, a->N, a->K)),
                 "tvl_gemm_h2: aux_blocked needs an image-only epilogue on the automatically chosen 256-row tile (M=%d N=%d K=%d)", a->M, a->N, a->K);

@@ -169,8 +169,9 @@ template <int LN_MAXV, int NW, int NP = 3>
 __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, unsigned char* __restrict__ out,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows, int cols,
-                                                         float eps, float* __restrict__ inv_scale, float* __restrict__ row_norm) {
-    __shared__ float s_mean[32], s_rstd[32], s_scale[32];
+                                                         float eps, float* __restrict__ inv_scale, float* __restrict__ row_norm,
+                                                         unsigned long long* __restrict__ max_slot, unsigned tag) {
+    __shared__ float s_mean[32], s_rstd[32], s_scale[32], s_norm[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rb = blockIdx.x;
     const float inv_n = 1.0f / (float)cols;
@@ -224,14 +225,21 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
                 ss = wave_sum(ss);
                 const float inv = h2::inv_scale_of(amax);
                 if (lane == 0) {
-                    inv_scale[row] = inv; s_scale[rl] = 1.0f / inv;
-                    if (row_norm) row_norm[row] = sqrtf(ss) * 1.0001f;   // ||y row||_2, rounded up: it feeds a bound (tvl_gemm_h2_out)
+                    const float nrm = sqrtf(ss) * 1.0001f;   // ||y row||_2, rounded up: it feeds a bound (tvl_gemm_h2_out)
+                    inv_scale[row] = inv; s_scale[rl] = 1.0f / inv; s_norm[rl] = nrm;
+                    if (row_norm) row_norm[row] = nrm;
                 }
             }
-        } else if (NP == 2 && lane == 0) s_scale[rl] = 1.0f;
+        } else if (NP == 2 && lane == 0) { s_scale[rl] = 1.0f; s_norm[rl] = 0.f; }
         if (lane == 0) { s_mean[rl] = mean; s_rstd[rl] = rstd; }
     }
     __syncthreads();
+    if constexpr (NP == 2) {   // largest row norm of the call: one tagged atomicMax per workgroup (include/tvl_hip.h)
+        if (max_slot && wave == 0) {
+            const float m = wave_max(lane < 32 ? s_norm[lane] : 0.f);
+            if (lane == 0) atomicMax(max_slot, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(m));
+        }
+    }
     const int r = lane & 31, h = lane >> 5;
     const long row = rb * 32 + r;
     const bool live = row < rows;
@@ -279,8 +287,9 @@ template <int LN_MAXV, int NW, int NP = 3>
 __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const float* __restrict__ dres, float* __restrict__ dx, unsigned char* __restrict__ out,
-                                                         long rows, int cols, float* __restrict__ inv_scale, float* __restrict__ row_norm) {
-    __shared__ float s_scale[32];
+                                                         long rows, int cols, float* __restrict__ inv_scale, float* __restrict__ row_norm,
+                                                         unsigned long long* __restrict__ max_slot, unsigned tag) {
+    __shared__ float s_scale[32], s_norm[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rb = blockIdx.x;
     const float inv_n = 1.0f / (float)cols;
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
     for (int rr = 0; rr < 32 / NW; ++rr) {
         const long row = rb * 32 + wave * (32 / NW) + rr;
         if (row >= rows) {
-            if (NP == 2 && lane == 0) s_scale[wave * (32 / NW) + rr] = 1.0f;
+            if (NP == 2 && lane == 0) { s_scale[wave * (32 / NW) + rr] = 1.0f; s_norm[wave * (32 / NW) + rr] = 0.f; }
             continue;
         }
         float amax = 0.f, ss = 0.f;
@@ -338,8 +347,9 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
             ss = wave_sum(ss);
             const float inv = h2::inv_scale_of(amax);
             if (lane == 0) {
-                inv_scale[row] = inv; s_scale[wave * (32 / NW) + rr] = 1.0f / inv;
-                if (row_norm) row_norm[row] = sqrtf(ss) * 1.0001f;
+                const float nrm = sqrtf(ss) * 1.0001f;
+                inv_scale[row] = inv; s_scale[wave * (32 / NW) + rr] = 1.0f / inv; s_norm[wave * (32 / NW) + rr] = nrm;
+                if (row_norm) row_norm[row] = nrm;
             }
         }
     }
@@ -348,6 +358,12 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
     __threadfence_block();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (NP == 2) {
+        if (max_slot && wave == 0) {
+            const float m = wave_max(lane < 32 ? s_norm[lane] : 0.f);
+            if (lane == 0) atomicMax(max_slot, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(m));
+        }
+    }
     const int r = lane & 31, h = lane >> 5;
     const long row = rb * 32 + r;
     const bool live = row < rows;
@@ -423,8 +439,8 @@ extern "C" int tvl_layernorm_fwd_tp3(const float* x, const float* gamma, const f
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(y_tp3);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr, (float*)nullptr);
-    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr, (float*)nullptr);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0u);
+    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0u);
     TVL_LAUNCH_CHECK("tvl_layernorm_fwd_tp3");
     return 0;
 }
@@ -438,38 +454,43 @@ extern "C" int tvl_layernorm_bwd_tp3(const float* dy, const float* x, const floa
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(dx_tp3);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr, (float*)nullptr);
-    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr, (float*)nullptr);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0u);
+    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0u);
     TVL_LAUNCH_CHECK("tvl_layernorm_bwd_tp3");
     return 0;
 }
 
 // The same two kernels writing the h2 operand format (two fp16 pieces of the row scaled by a power of two) + the rows' inverse scales.
 extern "C" int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const float* beta, void* y_h2, float* inv_scale, float* row_norm, float* mean, float* rstd,
-                                    int64_t rows, int32_t cols, float eps, tvlStream_t stream) {
+                                    int64_t rows, int32_t cols, float eps, uint64_t* max_slot, uint32_t tag, tvlStream_t stream) {
     TVL_REQUIRE(x && gamma && y_h2 && inv_scale, "tvl_layernorm_fwd_h2: null pointer");
+    TVL_REQUIRE(!max_slot || ((uintptr_t)max_slot % 8 == 0), "tvl_layernorm_fwd_h2: max_slot must be 8-byte aligned");
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(max_slot);
     TVL_REQUIRE(rows > 0 && cols > 0 && cols % 16 == 0 && cols <= 2048, "tvl_layernorm_fwd_h2: need cols %% 16 == 0 and cols <= 2048 (rows=%ld cols=%d)", (long)rows, cols);
     TVL_REQUIRE(tvl_aligned16(x) && tvl_aligned16(y_h2) && tvl_aligned16(gamma) && (!beta || tvl_aligned16(beta)), "tvl_layernorm_fwd_h2: operands must be 16-byte aligned");
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(y_h2);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm);
-    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm, slot, (unsigned)tag);
+    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm, slot, (unsigned)tag);
     TVL_LAUNCH_CHECK("tvl_layernorm_fwd_h2");
     return 0;
 }
 
 extern "C" int tvl_layernorm_bwd_h2(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                    const float* dres, float* dx, void* dx_h2, float* inv_scale, float* row_norm, int64_t rows, int32_t cols, tvlStream_t stream) {
+                                    const float* dres, float* dx, void* dx_h2, float* inv_scale, float* row_norm, int64_t rows, int32_t cols,
+                                    uint64_t* max_slot, uint32_t tag, tvlStream_t stream) {
     TVL_REQUIRE(dy && x && gamma && mean && rstd && dx && dx_h2 && inv_scale, "tvl_layernorm_bwd_h2: null pointer");
+    TVL_REQUIRE(!max_slot || ((uintptr_t)max_slot % 8 == 0), "tvl_layernorm_bwd_h2: max_slot must be 8-byte aligned");
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(max_slot);
     TVL_REQUIRE(rows > 0 && cols > 0 && cols % 16 == 0 && cols <= 2048, "tvl_layernorm_bwd_h2: need cols %% 16 == 0 and cols <= 2048 (rows=%ld cols=%d)", (long)rows, cols);
     TVL_REQUIRE(tvl_aligned16(x) && tvl_aligned16(dy) && tvl_aligned16(dx) && tvl_aligned16(dx_h2) && tvl_aligned16(gamma) && (!dres || tvl_aligned16(dres)),
                 "tvl_layernorm_bwd_h2: operands must be 16-byte aligned");
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(dx_h2);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm);
-    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm);
+    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm, slot, (unsigned)tag);
+    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm, slot, (unsigned)tag);
     TVL_LAUNCH_CHECK("tvl_layernorm_bwd_h2");
     return 0;
 }

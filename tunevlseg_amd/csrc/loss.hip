@@ -85,6 +85,29 @@ __global__ __launch_bounds__(256) void dicece_bwd_kernel(const float* __restrict
     }
 }
 
+// loss = lambda_dice * mean_b [1 - (2 I_b + snr) / (D_b + sdr)] + lambda_ce * (sum_b bce_b) / (B N), float64 inside, one workgroup, fixed
+// summation order (thread-strided partial sums, then a shared-memory tree): bitwise reproducible like fsum itself
+__global__ __launch_bounds__(256) void dicece_loss_kernel(const double* __restrict__ fsum, float* __restrict__ loss, int B, double n_pix,
+                                                          double lambda_dice, double lambda_ce, double snr, double sdr) {
+    __shared__ double sd[256], sb[256];
+    double d = 0.0, c = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        d += 1.0 - (2.0 * fsum[b * 4 + 0] + snr) / (fsum[b * 4 + 1] + fsum[b * 4 + 2] + sdr);
+        c += fsum[b * 4 + 3];
+    }
+    sd[threadIdx.x] = d;
+    sb[threadIdx.x] = c;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sd[threadIdx.x] += sd[threadIdx.x + w];
+            sb[threadIdx.x] += sb[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(lambda_dice * (sd[0] / (double)B) + lambda_ce * (sb[0] / ((double)B * n_pix)));
+}
+
 }  // namespace
 
 static long dicece_chunks(long N) {
@@ -119,5 +142,14 @@ extern "C" int tvl_dicece_bwd(const float* logits, const float* target, const do
     hipLaunchKernelGGL(dicece_bwd_kernel, dim3((unsigned)chunks, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, target,
                        fsum, dlogits, B, (long)N, lambda_dice, lambda_ce, smooth_nr, smooth_dr, gscale);
     TVL_LAUNCH_CHECK("tvl_dicece_bwd");
+    return 0;
+}
+
+extern "C" int tvl_dicece_loss(const double* fsum, float* loss, int32_t B, int64_t N, float lambda_dice, float lambda_ce,
+                               float smooth_nr, float smooth_dr, tvlStream_t stream) {
+    TVL_REQUIRE(fsum && loss && B > 0 && N > 0, "tvl_dicece_loss: bad arguments");
+    hipLaunchKernelGGL(dicece_loss_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), fsum, loss, (int)B, (double)N,
+                       (double)lambda_dice, (double)lambda_ce, (double)smooth_nr, (double)smooth_dr);
+    TVL_LAUNCH_CHECK("tvl_dicece_loss");
     return 0;
 }

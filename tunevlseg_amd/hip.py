@@ -57,7 +57,7 @@ class GemmTp3Args(C.Structure):
         ("alpha", C.c_float),
         ("tile_m", C.c_int32), ("variant", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-        ("aux_blocked", C.c_int32),
+        ("aux_blocked", C.c_int32), ("a_scale_one", C.c_int32),
     ]
 
 
@@ -121,6 +121,7 @@ _SIGS = {
     "tvl_upconv_taps_bwd": [_P, _P, _I, _P, _I, _I, _I, _I],
     "tvl_dicece_stats": [_P, _P, _P, _P, _P, _P, _I, _L, _F],
     "tvl_dicece_bwd": [_P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _P],
+    "tvl_dicece_loss": [_P, _P, _I, _L, _F, _F, _F, _F],
     "tvl_normalize_u8": [_P, _P, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)],
     "tvl_mask_u8": [_P, _P, _L],
     "tvl_resize_u8": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -159,8 +160,8 @@ _SIGS = {
     "tvl_gemm_h2_ks": [C.POINTER(GemmTp3Args), _P],
     "tvl_conv3x3_h2": [C.POINTER(GemmTp3Args), C.POINTER(ConvGeom), _P],
     "tvl_gemm_h2": [C.POINTER(GemmTp3Args), _P],
-    "tvl_layernorm_fwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F],
-    "tvl_layernorm_bwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I],
+    "tvl_layernorm_fwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, C.c_uint32],
+    "tvl_layernorm_bwd_h2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, C.c_uint32],
     "tvl_im2col3x3": [_P, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_avgpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
@@ -178,7 +179,7 @@ EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "
            "tvl_gemm_aux_floats", *_SIGS]
 
 _lib = None
-ABI_VERSION = 4   # include/tvl_hip.h TVL_ABI_VERSION
+ABI_VERSION = 5   # include/tvl_hip.h TVL_ABI_VERSION
 
 
 def load():
@@ -543,7 +544,7 @@ class H2:
     MFMA-fragment order (include/tvl_hip.h, "h2"): the operand format of ``tvl_gemm_h2`` -- 3 MFMAs per product instead of tp3's 6.
     ``inv_scale``: fp32 [rows] (per row) or [1] (per tensor) exact powers of two that the GEMM's epilogue multiplies back in."""
 
-    __slots__ = ("buf", "rows", "cols", "inv_scale", "per_row", "_alpha", "row_norm", "_bound")
+    __slots__ = ("buf", "rows", "cols", "inv_scale", "per_row", "_alpha", "row_norm", "_bound", "norm_max")
 
     def __init__(self, rows: int, cols: int, device, per_row: bool, zero_tail: bool = False):
         if cols % 16:
@@ -558,13 +559,14 @@ class H2:
         self.inv_scale = torch.empty(rows if per_row else 1, device=device, dtype=torch.float32)
         self._alpha = None   # host copy of a per-tensor inverse scale, read once (frozen weights)
         self.row_norm = None   # [rows] L2 norms of the rows (per-row operands whose consumer GEMM writes an h2 output)
+        self.norm_max = None   # [1] the largest of them, left behind by the producer (max_slot): a one-scale output needs no reduction launch
         self._bound = None
 
     @classmethod
     def wrap(cls, rows: int, cols: int, buf: torch.Tensor, inv_scale: torch.Tensor, per_row: bool) -> "H2":
         """An H2 over existing storage (tensors saved for the backward)."""
         t = cls.__new__(cls)
-        t.rows, t.cols, t.per_row, t.buf, t.inv_scale, t._alpha, t.row_norm, t._bound = rows, cols, per_row, buf, inv_scale, None, None, None
+        t.rows, t.cols, t.per_row, t.buf, t.inv_scale, t._alpha, t.row_norm, t._bound, t.norm_max = rows, cols, per_row, buf, inv_scale, None, None, None, None
         return t
 
     @property
@@ -623,7 +625,7 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
     N, K = B.rows, A.cols
     if B.cols != K or B.per_row:
         raise RuntimeError(f"gemm_h2: need B {B.shape} per-tensor scaled and K = {K}")
-    a_scale = A.inv_scale if A.per_row else A.inv_scale.expand(A.rows).contiguous()   # a one-scale activation image (attention's O)
+    a_scale = A.inv_scale   # [rows], or [1] for a one-scale activation image (attention's O): a_scale_one
     dev = A.buf.device
     Cf = out if out is not None else (torch.empty((M, N), device=dev, dtype=torch.float32) if want_f32 else None)
     Ct = out_tp3 if out_tp3 is not None else (Tp3(M, N, dev) if want_tp3 else None)
@@ -641,13 +643,13 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
                        _p(bias), _ps(residual), 0 if residual is None else residual.stride(0), act, pre_p, aux_p,
                        ld_aux, dact, B.alpha(), tile_m, GEMM_TP3_VARIANT,
                        gemm_workspace().data_ptr() if (persistent and (Ch is not None or pre_out is not None)) else None, GEMM_WORKSPACE_BYTES,
-                       1 if aux_blocked else 0)
+                       1 if aux_blocked else 0, 0 if A.per_row else 1)
     if _gemm_prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if Ch is not None:
         # per-tensor mode: ONE bound from the largest row norm of A (a one-element device tensor), one scale for the whole image
-        norm = A.row_norm.max().reshape(1) if out_per_tensor else A.row_norm
+        norm = (A.norm_max if A.norm_max is not None else A.row_norm.max().reshape(1)) if out_per_tensor else A.row_norm
         _call("tvl_gemm_h2_out", C.byref(args), _p(a_scale), Ch.buf.data_ptr(), _p(norm), float(B._bound if out_mul is None else out_mul),
               float(out_add), _p(Ch.inv_scale), 1 if out_per_tensor else 0)
     else:
@@ -840,6 +842,27 @@ def layernorm_fwd_tp3(x2d, gamma, beta, eps: float, want_stats=True):
     return y, mean, rstd
 
 
+_MAX_SLOTS: dict = {}   # device index -> (int64 zeros [4096], the same memory as fp32 [8192])
+_max_slot_calls = 0
+
+
+def _max_slot(device):
+    """(address of a 64-bit slot, tag, one-element fp32 view of the slot's low word) for a producer that leaves the largest of its row
+    norms behind by tagged atomicMax (tvl_layernorm_fwd_h2 / _bwd_h2 ``max_slot``): slots rotate, the tag grows with every turn of the
+    pool, so a slot never has to be cleared -- no fill and no reduction launch per use."""
+    global _max_slot_calls
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _MAX_SLOTS.get(key)
+    if pool is None:
+        z = torch.zeros(4096, device=device, dtype=torch.int64)
+        torch.cuda.current_stream(device).synchronize()   # once: other streams may use the pool next
+        pool = _MAX_SLOTS[key] = (z, z.view(torch.float32))
+    n = _max_slot_calls
+    _max_slot_calls += 1
+    i, tag = n % 4096, n // 4096 + 1
+    return pool[0].data_ptr() + 8 * i, tag, pool[1][2 * i: 2 * i + 1]
+
+
 def layernorm_fwd_h2(x2d, gamma, beta, eps: float, want_stats=True):
     """LayerNorm whose only consumer is an h2 GEMM: returns (H2 image of y with per-row scales, mean, rstd)."""
     rows, cols = x2d.shape
@@ -847,8 +870,10 @@ def layernorm_fwd_h2(x2d, gamma, beta, eps: float, want_stats=True):
     y.row_norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
     mean = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(rows, device=x2d.device, dtype=torch.float32) if want_stats else None
+    slot, tag, y.norm_max = _max_slot(x2d.device)
     with _aux_span("ln_fwd_h2", 0.0, 8.0 * rows * cols):   # read x fp32, write the two fp16 pieces
-        _call("tvl_layernorm_fwd_h2", _p(x2d), _p(gamma), _p(beta), y.buf.data_ptr(), _p(y.inv_scale), _p(y.row_norm), _p(mean), _p(rstd), rows, cols, float(eps))
+        _call("tvl_layernorm_fwd_h2", _p(x2d), _p(gamma), _p(beta), y.buf.data_ptr(), _p(y.inv_scale), _p(y.row_norm), _p(mean), _p(rstd), rows, cols, float(eps),
+              slot, tag)
     return y, mean, rstd
 
 
@@ -858,9 +883,10 @@ def layernorm_bwd_h2(dy2d, x2d, gamma, mean, rstd, dres=None):
     dx = torch.empty_like(x2d)
     dxt = H2(rows, cols, x2d.device, per_row=True)
     dxt.row_norm = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    slot, tag, dxt.norm_max = _max_slot(x2d.device)
     with _aux_span("ln_bwd_h2", 0.0, (20.0 if dres is not None else 16.0) * rows * cols):   # read dy, x [, dres]; write dx fp32 + image
         _call("tvl_layernorm_bwd_h2", _p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), dxt.buf.data_ptr(), _p(dxt.inv_scale),
-              _p(dxt.row_norm), rows, cols)
+              _p(dxt.row_norm), rows, cols, slot, tag)
     return dx, dxt
 
 
@@ -1142,6 +1168,14 @@ def dicece_stats(logits, target, thr: float, want_label=False):
     _call("tvl_dicece_stats", _p(logits), _p(target), _p(fsum, torch.float64), _p(isum, torch.int64), _p(label, torch.uint8),
           _p(work, torch.float64), B, N, float(thr))
     return fsum, isum, label
+
+
+def dicece_loss(fsum, N: int, lambda_dice, lambda_ce, smooth_nr=1e-5, smooth_dr=1e-5):
+    """fp32 scalar DiceCE loss from the per-sample sums of :func:`dicece_stats` (one launch, float64 inside)."""
+    loss = torch.empty((), device=fsum.device, dtype=torch.float32)
+    _call("tvl_dicece_loss", _p(fsum, torch.float64), _p(loss), fsum.shape[0], int(N), float(lambda_dice), float(lambda_ce),
+          float(smooth_nr), float(smooth_dr))
+    return loss
 
 
 def dicece_bwd(logits, target, fsum, lambda_dice, lambda_ce, smooth_nr, smooth_dr, gscale):

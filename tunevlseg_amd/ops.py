@@ -598,10 +598,7 @@ class DiceCELossFn(Fn):
         fsum, isum, _ = hip.dicece_stats(logits, target, threshold)
         ctx.save_for_backward(logits, target, fsum)
         ctx.lam = (lambda_dice, lambda_ce)
-        snr = sdr = 1e-5
-        dice = (1.0 - (2.0 * fsum[:, 0] + snr) / (fsum[:, 1] + fsum[:, 2] + sdr)).mean()
-        bce = fsum[:, 3].sum() / (B * N)
-        loss = (lambda_dice * dice + lambda_ce * bce).to(torch.float32)
+        loss = hip.dicece_loss(fsum, N, lambda_dice, lambda_ce, 1e-5, 1e-5)
         ctx.mark_non_differentiable(isum)
         return loss, isum
 

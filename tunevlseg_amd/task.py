@@ -58,13 +58,13 @@ class DiceSamples:
         self.values: list[torch.Tensor] = []
 
     def update(self, counts: torch.Tensor):
-        c = counts.to(torch.float64)
-        den = 2 * c[:, 0] + c[:, 1] + c[:, 2]
-        self.values.append(torch.where(den > 0, 2 * c[:, 0] / den.clamp(min=1), torch.full_like(den, self.zero_division)))
+        self.values.append(counts)   # int64 [B, 4]; the arithmetic waits for compute(): a train step launches nothing for its metrics
 
     def compute(self) -> float:
-        v = tdist.allgather_cat(torch.cat(self.values))
-        return float(v.mean().item())
+        c = torch.cat(self.values).to(torch.float64)
+        den = 2 * c[:, 0] + c[:, 1] + c[:, 2]
+        v = torch.where(den > 0, 2 * c[:, 0] / den.clamp(min=1), torch.full_like(den, self.zero_division))
+        return float(tdist.allgather_cat(v).mean().item())
 
 
 class JaccardBinary:
@@ -75,14 +75,13 @@ class JaccardBinary:
         self.reset()
 
     def reset(self):
-        self.counts: torch.Tensor | None = None
+        self.batches: list[torch.Tensor] = []
 
     def update(self, counts: torch.Tensor):
-        s = counts.sum(0)
-        self.counts = s if self.counts is None else self.counts + s
+        self.batches.append(counts)   # summed in compute()
 
     def compute(self) -> float:
-        c = tdist.allreduce_counts(self.counts.clone())
+        c = tdist.allreduce_counts(torch.cat(self.batches).sum(0))
         tp, fp, fn = (float(c[i].item()) for i in range(3))
         den = tp + fp + fn
         return tp / den if den > 0 else self.zero_division
@@ -125,35 +124,37 @@ class ImageTextMaskModule(nn.Module):
         return self(image_input=batch["image"], text_input=text_input)
 
     def model_step(self, batch: Mapping[str, Any]):
+        """reference ``model_step`` (``image_text_mask_module.py:87-107``): (loss, predictions, integer targets)."""
         logits = self.get_logits(batch)
         mask = batch["mask"]
         loss = self.loss_fn(logits, mask)
         preds = self.activation_fn(logits)
         return loss, preds, mask.long()
 
-    def _step(self, stage: str, batch):
-        loss, preds, targets = self.model_step(batch)
+    def _step(self, stage: str, batch) -> torch.Tensor:
+        """``model_step`` + metric update as the reference's ``*_step`` methods do it -- but the confusion counts the metrics need were
+        already taken by the loss's own pass over (logits, mask), so neither the probabilities nor ``mask.long()`` are materialised."""
+        logits = self.get_logits(batch)
+        mask = batch["mask"]
+        loss = self.loss_fn(logits, mask)
         counts = getattr(self.loss_fn, "last_counts", None)
-        if counts is None:  # foreign loss: statistics from a dedicated pass
-            _, counts, _ = hip.dicece_stats(ops._c(preds.detach()), ops._c(targets.to(torch.float32)), self.hparams["threshold"])
+        if counts is None:  # foreign loss: statistics from a dedicated pass over the logits (sigmoid(x) > thr and (int64)mask)
+            _, counts, _ = hip.dicece_stats(ops._c(logits.detach()), ops._c(mask.to(torch.float32)), self.hparams["threshold"])
         if f"{stage}_dice" in self.metrics:
             self.metrics[f"{stage}_dice"].update(counts)
             self.metrics[f"{stage}_iou"].update(counts)
-        return loss, preds, targets
+        return loss
 
     def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
-        loss, _, _ = self._step("train", batch)
-        return loss
+        return self._step("train", batch)
 
     def validation_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         with torch.no_grad():
-            loss, _, _ = self._step("val", batch)
-        return loss
+            return self._step("val", batch)
 
     def test_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         with torch.no_grad():
-            loss, _, _ = self._step("test", batch)
-        return loss
+            return self._step("test", batch)
 
     def predict_step(self, batch, batch_idx: int = 0):
         """reference image_text_mask_module.py:244-255: probabilities + what is needed to save them at the original size."""
