@@ -28,7 +28,7 @@ typedef void* tvlStream_t; /* hipStream_t */
 
 /* Bumped on every incompatible change of a signature or struct below.  3: tvl_dicece_stats gained `work`, tvl_split_planes /
  * tvl_gemm_planes removed (round 2).  4: tvl_text_assemble gained `vocab` (rows of the embedding table: ids outside it give NaN rows
- * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  5: tvl_dicece_loss added;
+ * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  5: tvl_dicece_loss, tvl_mlp64_* added;
  * tvl_layernorm_fwd_h2 / _bwd_h2 gained max_slot / tag (largest row norm by tagged atomicMax).  The Python binding refuses a library whose tvl_abi_version() differs. */
 #define TVL_ABI_VERSION 5
 
@@ -212,6 +212,24 @@ int tvl_dicece_loss(const double* fsum, float* loss, int32_t B, int64_t N, float
 int tvl_dicece_bwd(const float* logits, const float* target, const double* fsum, float* dlogits,
                    int32_t B, int64_t N, float lambda_dice, float lambda_ce, float smooth_nr, float smooth_dr,
                    const float* gscale, tvlStream_t stream);
+
+/* ---- feed-forward half of a CLIPSeg decoder layer in one kernel (reduce_dim = 64, hidden_act = relu; HF CLIPSegDecoderLayer,
+ *      modeling_clipseg.py:393-410 as called from the reference's decoder loop, src/models/core_models/coop/base_clipseg.py via
+ *      CLIPSegDecoder):   out = LayerNorm(x + W2 relu(W1 x + b1) + b2),  x [M, 64], W1 [F, 64], W2 [64, F], F % 128 == 0.
+ * The F-wide intermediate never leaves the registers (csrc/mlp64.hip); two fp16 pieces per operand, three MFMAs per product.
+ * tvl_mlp64_pack: the frozen weights once -> img (tvl_mlp64_image_bytes(F) bytes: four fragment-ordered images), scaled by
+ * scale1 / scale2 = the powers of two that put max |W1| / max |W2| into [2^13, 2^14); the kernels get their inverses.
+ * tvl_mlp64_fwd: also t2 = the LayerNorm's input and mean / rstd [M] (null when no backward follows).  w1_rownorm = max_f ||W1[f, :]||_2,
+ * b1_max = max |b1| (bound of the hidden rows, which sets their fp16 scale).
+ * tvl_mlp64_bwd: dx = d out / d x applied to dout (LayerNorm backward, both GEMM data gradients with the relu gate recomputed from
+ * x, and the residual path); w2_colnorm = max_f ||W2[:, f]||_2. */
+int64_t tvl_mlp64_image_bytes(int32_t F);
+int tvl_mlp64_pack(const float* W1, const float* W2, int32_t F, float scale1, float scale2, void* img, tvlStream_t stream);
+int tvl_mlp64_fwd(const float* x, const void* img, const float* b1, const float* b2, const float* gamma, const float* beta, float* out, float* t2,
+                  float* mean, float* rstd, int64_t M, int32_t F, float inv_w1, float inv_w2, float w1_rownorm, float b1_max, float eps,
+                  tvlStream_t stream);
+int tvl_mlp64_bwd(const float* dout, const float* x, const float* t2, const float* mean, const float* rstd, const void* img, const float* b1,
+                  const float* gamma, float* dx, int64_t M, int32_t F, float inv_w1, float inv_w2, float w2_colnorm, tvlStream_t stream);
 
 /* ---- input side (row f2): decoded uint8 sample -> network input, on the device ----
  * tvl_normalize_u8: albumentations Normalize(mean, std, max_pixel_value=255) + ToTensorV2 of the reference's transforms

@@ -759,3 +759,37 @@ def test_gemm_h2_pre_activation_in_accumulator_order_round_trips(hip):
         _, dz = hip.gemm_h2(G, W2T, want_f32=False, want_h2=True, out_mul=1.125 * W2T._bound, dact=hip.ACT_QUICK_GELU, dact_aux=z, aux_blocked=blocked)
         res.append((a.buf.clone(), dz.buf.clone(), dz.inv_scale.clone()))
     assert all(torch.equal(u, v) for u, v in zip(*res))
+
+
+@pytest.mark.parametrize("M,F", [(15520, 2048), (77, 128), (64, 256), (1000, 2048)])
+def test_mlp64_block_forward_and_backward_match_float64(hip, M, F):
+    """LayerNorm(x + W2 relu(W1 x + b1) + b2) and its data gradient in one launch each (csrc/mlp64.hip) against float64 torch;
+    rows spread over five decades (every row carries its own power-of-two scale) and a few exactly-zero rows."""
+    from tunevlseg_amd import hip as H
+
+    g = torch.Generator().manual_seed(M + F)
+    x = torch.randn(M, 64, generator=g) * torch.logspace(-3, 2, M)[torch.randperm(M, generator=g)][:, None]
+    x[::97] = 0
+    W1, b1 = torch.randn(F, 64, generator=g) * 0.2, torch.randn(F, generator=g) * 0.3
+    W2, b2 = torch.randn(64, F, generator=g) * 0.05, torch.randn(64, generator=g) * 0.1
+    gamma, beta = 1 + 0.2 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    dout = torch.randn(M, 64, generator=g) * torch.logspace(-6, -2, M)[:, None]
+    xd = x.double().requires_grad_(True)
+    t2_ref = xd + torch.relu(xd @ W1.double().T + b1.double()) @ W2.double().T + b2.double()
+    out_ref = torch.nn.functional.layer_norm(t2_ref, (64,), gamma.double(), beta.double(), 1e-5)
+    out_ref.backward(dout.double())
+    w = H.Mlp64Weights(dev(W1), dev(b1), dev(W2))
+    out, t2, mean, rstd = H.mlp64_fwd(dev(x), w, dev(b1), dev(b2), dev(gamma), dev(beta), 1e-5)
+    scale_t = t2_ref.detach().abs().amax(1, keepdim=True).clamp(min=1e-30)
+    assert ((t2.cpu().double() - t2_ref.detach()).abs() / scale_t).max().item() < 2e-6
+    assert (out.cpu().double() - out_ref.detach()).abs().max().item() < 2e-5
+    # against the op-by-op fp32 path of the same library (what the fused kernel replaces)
+    u = H.linear_fwd(dev(x), dev(W1), dev(b1), act=H.ACT_RELU)
+    t2_ops = H.linear_fwd(u, dev(W2), dev(b2), residual=dev(x))
+    assert ((t2 - t2_ops).abs().cpu().double() / scale_t).max().item() < 4e-6
+    dx = H.mlp64_bwd(dev(dout), dev(x), t2, mean, rstd, w, dev(b1), dev(gamma))
+    ref = xd.grad
+    rel = ((dx.cpu().double() - ref).norm(dim=1) / ref.norm(dim=1).clamp(min=1e-300))
+    assert rel.max().item() < 2e-5, rel.max()   # row by row: small-gradient rows keep their own precision
+    out_nostat, t2n, _, _ = H.mlp64_fwd(dev(x), w, dev(b1), dev(b2), dev(gamma), dev(beta), 1e-5, want_stats=False)
+    assert t2n is None and torch.equal(out_nostat, out)

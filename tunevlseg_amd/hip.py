@@ -8,6 +8,7 @@ stream; every wrapper passes raw device pointers + sizes + the stream handle.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from pathlib import Path
 
@@ -122,6 +123,9 @@ _SIGS = {
     "tvl_dicece_stats": [_P, _P, _P, _P, _P, _P, _I, _L, _F],
     "tvl_dicece_bwd": [_P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _P],
     "tvl_dicece_loss": [_P, _P, _I, _L, _F, _F, _F, _F],
+    "tvl_mlp64_pack": [_P, _P, _I, _F, _F, _P],
+    "tvl_mlp64_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F],
+    "tvl_mlp64_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _F],
     "tvl_normalize_u8": [_P, _P, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)],
     "tvl_mask_u8": [_P, _P, _L],
     "tvl_resize_u8": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -176,7 +180,7 @@ _SIGS = {
     "tvl_dynconv_bwd": [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
 }
 EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_h2_bytes", "tvl_dicece_work_doubles",
-           "tvl_gemm_aux_floats", *_SIGS]
+           "tvl_gemm_aux_floats", "tvl_mlp64_image_bytes", *_SIGS]
 
 _lib = None
 ABI_VERSION = 5   # include/tvl_hip.h TVL_ABI_VERSION
@@ -200,6 +204,8 @@ def load():
                            f"(`make -C {LIB_PATH.parent}`)")
     lib.tvl_dynconv_bwd_work_floats.argtypes = [_I, _I, _I, _I]
     lib.tvl_dynconv_bwd_work_floats.restype = C.c_int64
+    lib.tvl_mlp64_image_bytes.argtypes = [_I]
+    lib.tvl_mlp64_image_bytes.restype = C.c_int64
     lib.tvl_dicece_work_doubles.argtypes = [_I, _L]
     lib.tvl_dicece_work_doubles.restype = C.c_int64
     lib.tvl_gemm_aux_floats.argtypes = [_L, _L]
@@ -1158,6 +1164,57 @@ def upconv_taps_bwd(dout, B: int, G: int, ps: int, k: int):
 # --------------------------------------------------------------------------------------
 # loss / metrics / optimiser / misc
 # --------------------------------------------------------------------------------------
+MLP64 = os.environ.get("TVL_MLP64", "1") != "0"   # the decoder's feed-forward block as one kernel (csrc/mlp64.hip); 0 = op by op (A/B switch)
+
+
+class Mlp64Weights:
+    """The four fragment-ordered two-piece fp16 images of a frozen (W1 [F, 64], W2 [64, F]) pair + the scalars the kernels need."""
+
+    __slots__ = ("img", "F", "inv_w1", "inv_w2", "w1_rownorm", "b1_max", "w2_colnorm")
+
+    def __init__(self, W1: torch.Tensor, b1: torch.Tensor, W2: torch.Tensor):
+        F = W1.shape[0]
+        if W1.shape[1] != 64 or tuple(W2.shape) != (64, F) or F % 128:
+            raise RuntimeError(f"mlp64 wants W1 [F, 64], W2 [64, F], F % 128 == 0; got {tuple(W1.shape)}, {tuple(W2.shape)}")
+        W1, W2 = W1.detach().float().contiguous(), W2.detach().float().contiguous()
+
+        def inv_scale(amax: float) -> float:   # h2::inv_scale_of on the host
+            if not (1.0e-30 < amax < 3.0e38):
+                return 1.0
+            return math.ldexp(1.0, math.frexp(amax)[1] - 14)
+
+        self.F = F
+        self.inv_w1, self.inv_w2 = inv_scale(float(W1.abs().max().item())), inv_scale(float(W2.abs().max().item()))
+        self.w1_rownorm = float(W1.norm(dim=1).max().item()) * 1.0001
+        self.w2_colnorm = float(W2.norm(dim=0).max().item()) * 1.0001
+        self.b1_max = float(b1.detach().abs().max().item()) * 1.0001
+        self.img = torch.empty(load().tvl_mlp64_image_bytes(F), device=W1.device, dtype=torch.uint8)
+        _call("tvl_mlp64_pack", _p(W1), _p(W2), F, 1.0 / self.inv_w1, 1.0 / self.inv_w2, self.img.data_ptr())
+
+
+def mlp64_fwd(x2d, w: Mlp64Weights, b1, b2, gamma, beta, eps: float, want_stats=True):
+    """LayerNorm(x + W2 relu(W1 x + b1) + b2) for x [M, 64] in one launch: returns (out, t2 = the LayerNorm's input, mean, rstd)."""
+    M = x2d.shape[0]
+    out = torch.empty_like(x2d)
+    t2 = torch.empty_like(x2d) if want_stats else None
+    mean = torch.empty(M, device=x2d.device, dtype=torch.float32) if want_stats else None
+    rstd = torch.empty(M, device=x2d.device, dtype=torch.float32) if want_stats else None
+    with _aux_span("mlp64_fwd", 4.0 * M * w.F * 64, 4.0 * M * 64 * (3 if want_stats else 2)):
+        _call("tvl_mlp64_fwd", _p(x2d), w.img.data_ptr(), _p(b1), _p(b2), _p(gamma), _p(beta), _p(out), _p(t2), _p(mean), _p(rstd), M, w.F,
+              w.inv_w1, w.inv_w2, w.w1_rownorm, w.b1_max, float(eps))
+    return out, t2, mean, rstd
+
+
+def mlp64_bwd(dout2d, x2d, t2, mean, rstd, w: Mlp64Weights, b1, gamma):
+    """Gradient of :func:`mlp64_fwd` w.r.t. x (frozen weights: data gradient only), one launch."""
+    M = x2d.shape[0]
+    dx = torch.empty_like(x2d)
+    with _aux_span("mlp64_bwd", 6.0 * M * w.F * 64, 4.0 * M * 64 * 4):
+        _call("tvl_mlp64_bwd", _p(dout2d), _p(x2d), _p(t2), _p(mean), _p(rstd), w.img.data_ptr(), _p(b1), _p(gamma), _p(dx), M, w.F,
+              w.inv_w1, w.inv_w2, w.w2_colnorm)
+    return dx
+
+
 def dicece_stats(logits, target, thr: float, want_label=False):
     B = logits.shape[0]
     N = logits[0].numel()

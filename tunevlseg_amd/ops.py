@@ -38,6 +38,15 @@ class LayerWeights:
     w2_t: torch.Tensor | None = None
     _tp3: dict | None = None
     _h2: dict | None = None
+    _mlp64: object | None = None
+
+    def mlp64(self):
+        """Fragment-ordered images of (w1, w2) for the one-kernel feed-forward block of a 64-wide decoder layer (hip.Mlp64Weights), or
+        None when the layer does not have that geometry."""
+        if self._mlp64 is None:
+            ok = hip.MLP64 and self.w1.shape[1] == 64 and tuple(self.w2.shape) == (64, self.w1.shape[0]) and self.w1.shape[0] % 128 == 0
+            self._mlp64 = hip.Mlp64Weights(self.w1, self.b1, self.w2) if ok else False
+        return self._mlp64 or None
 
     def tp3(self) -> dict:
         """The eight weight operands of the layer's tp3 GEMMs (forward: W as stored [N, K]; data gradients: W^T), packed once."""
@@ -278,16 +287,21 @@ class DecoderLayerFn(Fn):
         o, lse = hip.attn_fwd_packed(qkv, B, T, H, dh, dh**-0.5, False, None, want_lse=need)
         t1 = hip.linear_fwd(o, lw.wo, lw.bo, residual=x2d)
         x1, m1, r1 = hip.layernorm_fwd(t1, lw.ln1_w, lw.ln1_b, spec.eps, want_stats=need)
-        if need:
-            u, zu = hip.linear_fwd(x1, lw.w1, lw.b1, act=spec.act, want_pre=True)
+        fused = lw.mlp64() if (D == 64 and spec.act == hip.ACT_RELU) else None
+        if fused is not None:   # the whole feed-forward block + LayerNorm2 in one launch; the backward recomputes the relu gate from x1
+            out, t2, m2, r2 = hip.mlp64_fwd(x1, fused, lw.b1, lw.b2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
+            zu = x1
         else:
-            u, zu = hip.linear_fwd(x1, lw.w1, lw.b1, act=spec.act), None
-        t2 = hip.linear_fwd(u, lw.w2, lw.b2, residual=x1)
-        del u
-        out, m2, r2 = hip.layernorm_fwd(t2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
+            if need:
+                u, zu = hip.linear_fwd(x1, lw.w1, lw.b1, act=spec.act, want_pre=True)
+            else:
+                u, zu = hip.linear_fwd(x1, lw.w1, lw.b1, act=spec.act), None
+            t2 = hip.linear_fwd(u, lw.w2, lw.b2, residual=x1)
+            del u
+            out, m2, r2 = hip.layernorm_fwd(t2, lw.ln2_w, lw.ln2_b, spec.eps, want_stats=need)
         if need:
             ctx.save_for_backward(qkv, o, lse, t1, m1, r1, zu, t2, m2, r2)
-            ctx.lw, ctx.spec, ctx.shape = lw, spec, (B, T, D)
+            ctx.lw, ctx.spec, ctx.shape, ctx.fused = lw, spec, (B, T, D), fused
         return out.view(B, T, D)
 
     @staticmethod
@@ -298,10 +312,13 @@ class DecoderLayerFn(Fn):
         H = spec.heads
         dh = D // H
         dout2d = _c(dout).view(B * T, D)
-        dt2 = hip.layernorm_bwd(dout2d, t2, lw.ln2_w, m2, r2)
-        dzu = hip.linear_dgrad(dt2, lw.w2, dact=spec.act, dact_aux=zu, Wt=lw.w2_t)
-        dx1 = hip.linear_dgrad(dzu, lw.w1, residual=dt2, Wt=lw.w1_t)
-        del dzu, dt2
+        if ctx.fused is not None:   # zu holds x1, the block's input
+            dx1 = hip.mlp64_bwd(dout2d, zu, t2, m2, r2, ctx.fused, lw.b1, lw.ln2_w)
+        else:
+            dt2 = hip.layernorm_bwd(dout2d, t2, lw.ln2_w, m2, r2)
+            dzu = hip.linear_dgrad(dt2, lw.w2, dact=spec.act, dact_aux=zu, Wt=lw.w2_t)
+            dx1 = hip.linear_dgrad(dzu, lw.w1, residual=dt2, Wt=lw.w1_t)
+            del dzu, dt2
         dt1 = hip.layernorm_bwd(dx1, t1, lw.ln1_w, m1, r1)
         del dx1
         do = hip.linear_dgrad(dt1, lw.wo, Wt=lw.wo_t)
