@@ -63,6 +63,16 @@ __device__ __forceinline__ float quick_gelu_grad_f(float z) {
     const float s = 1.0f / (1.0f + expf(-1.702f * z));
     return s + 1.702f * z * s * (1.0f - s);
 }
+// QuickGELU and its derivative on the hardware transcendentals (v_exp_f32 = 2^x, v_rcp_f32; 1 ulp each) for the GEMM epilogues, where
+// the IEEE expf / division sequences of the functions above cost ~50 vector instructions per element: s = 1 / (1 + 2^(-1.702 log2(e) z))
+__device__ __forceinline__ float sigmoid1702_fast(float z) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * z));
+}
+__device__ __forceinline__ float quick_gelu_fast(float z) { return z * sigmoid1702_fast(z); }
+__device__ __forceinline__ float quick_gelu_grad_fast(float z) {
+    const float s = sigmoid1702_fast(z);
+    return s + 1.702f * z * s * (1.0f - s);
+}
 __device__ __forceinline__ float act_f(float v, int act) {
     if (act == TVL_ACT_QUICK_GELU) return quick_gelu_f(v);
     if (act == TVL_ACT_RELU) return v > 0.f ? v : 0.f;

@@ -89,46 +89,64 @@ __device__ __forceinline__ void epilogue16_direct(const Tp3Params& p, f32x4 (&ac
             bias4[j] = col + 3 < p.N ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    // the QuickGELU' epilogue reads one float4 of z per 16 x 16 tile: row i + 1's four loads are in flight while row i is computed (issued one
+    // by one behind their uses they cost a full memory latency per tile, 32 in a row -- 40 us of a 260 us launch)
+    float4 zrow[2][4];
+    auto load_z = [&](auto ic, auto bc) {   // row block i's four z tiles into zrow[b]
+        constexpr int i = decltype(ic)::value, bsel = decltype(bc)::value;
+        if constexpr ((EPI & E_DQGELU) != 0 && i < TMo) {
+            const long row = row_base + 16 * i + m;
+            [&]<int... J>(std::integer_sequence<int, J...>) {
+                ((zrow[bsel][J] = p.aux_blocked ? *reinterpret_cast<const float4*>(p.dact_aux + (blk_base + i * 4 + J) * 256 + lane * 4)
+                                                : ((row < p.M && col_base + 16 * J + 4 * q + 3 < p.N)
+                                                       ? *reinterpret_cast<const float4*>(p.dact_aux + row * p.ld_aux + col_base + 16 * J + 4 * q)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f))), ...);
+            }(std::make_integer_sequence<int, 4>{});
+        }
+    };
+    auto tile = [&](auto ic, auto jc, long row, float f, float sc) {
+        constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+        const int col = col_base + 16 * j + 4 * q;
+        if (col + 3 >= p.N) return;
+        float v[4] = {acc[i][j][0] * f, acc[i][j][1] * f, acc[i][j][2] * f, acc[i][j][3] * f};
+        if constexpr ((EPI & E_BIAS) != 0) { v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w; }
+        if constexpr ((EPI & E_DQGELU) != 0) {
+            const float4 z4 = zrow[i & 1][j];
+            v[0] *= quick_gelu_grad_fast(z4.x); v[1] *= quick_gelu_grad_fast(z4.y);
+            v[2] *= quick_gelu_grad_fast(z4.z); v[3] *= quick_gelu_grad_fast(z4.w);
+        }
+        if constexpr ((EPI & E_PRE) != 0) {
+            float* zo = p.aux_blocked ? p.pre_out + (blk_base + i * 4 + j) * 256 + lane * 4 : p.pre_out + row * p.ldc + col;
+            *reinterpret_cast<float4*>(zo) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if constexpr ((EPI & E_QGELU) != 0) {
 #pragma unroll
-    for (int i = 0; i < TMo; ++i) {
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu_fast(v[e]);
+        }
+        _Float16 h0[4], h1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float w = v[e] * sc;
+            h0[e] = (_Float16)w;
+            h1[e] = (_Float16)(w - (float)h0[e]);
+        }
+        unsigned char* o = p.Ch2 + ((row >> 5) * kbn + (col >> 4)) * (long)h2::BLK + (((q >> 1) * 32 + (int)(row & 31)) * 16 + (q & 1) * 8);
+        *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(h0);
+        *reinterpret_cast<uint2*>(o + h2::PIECE) = *reinterpret_cast<const uint2*>(h1);
+    };
+    auto row_block = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        load_z(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
         const long row = row_base + 16 * i + m;
-        if (row >= p.M) continue;
+        if (row >= p.M) return;
         const float f = p.alpha * p.a_scale[row * p.a_sstride];
         const float inv = h2::inv_scale_of(p.out_norm[row * p.out_stride] * p.out_mul + p.out_add);
         if (col_base == 0 && q == 0 && (p.out_stride || row == 0)) p.out_inv[row * p.out_stride] = inv;
         const float sc = 1.0f / inv;   // a power of two: exact
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = col_base + 16 * j + 4 * q;
-            if (col + 3 >= p.N) continue;
-            float v[4] = {acc[i][j][0] * f, acc[i][j][1] * f, acc[i][j][2] * f, acc[i][j][3] * f};
-            if constexpr ((EPI & E_BIAS) != 0) { v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w; }
-            if constexpr ((EPI & E_DQGELU) != 0) {
-                const float4 z4 = p.aux_blocked ? *reinterpret_cast<const float4*>(p.dact_aux + (blk_base + i * 4 + j) * 256 + lane * 4)
-                                                : *reinterpret_cast<const float4*>(p.dact_aux + row * p.ld_aux + col);
-                v[0] *= dact_f(z4.x, TVL_ACT_QUICK_GELU); v[1] *= dact_f(z4.y, TVL_ACT_QUICK_GELU);
-                v[2] *= dact_f(z4.z, TVL_ACT_QUICK_GELU); v[3] *= dact_f(z4.w, TVL_ACT_QUICK_GELU);
-            }
-            if constexpr ((EPI & E_PRE) != 0) {
-                float* zo = p.aux_blocked ? p.pre_out + (blk_base + i * 4 + j) * 256 + lane * 4 : p.pre_out + row * p.ldc + col;
-                *reinterpret_cast<float4*>(zo) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-            if constexpr ((EPI & E_QGELU) != 0) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], TVL_ACT_QUICK_GELU);
-            }
-            _Float16 h0[4], h1[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float w = v[e] * sc;
-                h0[e] = (_Float16)w;
-                h1[e] = (_Float16)(w - (float)h0[e]);
-            }
-            unsigned char* o = p.Ch2 + ((row >> 5) * kbn + (col >> 4)) * (long)h2::BLK + (((q >> 1) * 32 + (int)(row & 31)) * 16 + (q & 1) * 8);
-            *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(h0);
-            *reinterpret_cast<uint2*>(o + h2::PIECE) = *reinterpret_cast<const uint2*>(h1);
-        }
-    }
+        [&]<int... J>(std::integer_sequence<int, J...>) { (tile(ic, std::integral_constant<int, J>{}, row, f, sc), ...); }(std::make_integer_sequence<int, 4>{});
+    };
+    load_z(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    [&]<int... I>(std::integer_sequence<int, I...>) { (row_block(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, TMo>{});
 }
 
 // PERSIST: one workgroup per CU walks several tiles (launches of more than 256 tiles: fc1, its data gradient's dz, QKV).  The reason is
