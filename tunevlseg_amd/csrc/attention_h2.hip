@@ -15,6 +15,8 @@
 // Outputs: O as an h2 image that shares the QKV scale (|O| <= max |V|) and dQ | dK | dV as an h2 image with one exact scale per
 // (row, 64-column block) -- each such block is written by one lane pair that holds all of it (store_block) -- for tvl_gemm_h2 /
 // tvl_gemm_h2_ks; or both as tp3 images (three bf16 pieces) for the tp3 consumers.
+#include <type_traits>
+#include <utility>
 #include "common.h"
 #include "tp3.h"
 
@@ -199,47 +201,59 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_h2_kernel(FwdP p) {
     const unsigned tr_off = (4 * h + (li >> 2)) * 32 + (li & 3) * 8 + g1 * VCH;
     const unsigned k_rd = lds0 + lane * 16, v_rd = lds0 + 2 * K_STAGE + tr_off;
 
-    issue(0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    // One key tile.  Vector work is what bounds this kernel next to its 24 MFMAs (stamps: profiles/r2_attention_experiments.md), so:
+    // no clamps (v_exp_f32 of a hugely negative argument is 0, of -1e30 * sc2 too), the key mask exists only in the peeled last tile, and
+    // the rescaling of O by alpha is skipped whenever no lane of the wave saw a new maximum (alpha = 1 exactly: most tiles after the first
+    // few).  P's static scale 2^13 stays a multiplication: folded into the exponent it would move the argument of the dominant terms
+    // from ~0 to ~13 and cost them three bits (the argument's rounding error becomes P's relative error).
+    auto tile = [&]<bool LAST>(std::integral_constant<bool, LAST>, int kt) {
         wait_vm<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nkt) issue(kt + 1);
+        if (!LAST) issue(kt + 1);
         const unsigned kb_ = k_rd + (kt & 1) * K_STAGE, vb_ = v_rd + (kt & 1) * V_STAGE;
         f32x16 sc = mma_rows(kb_, qf);                 // S^T [key (register), query (lane)], scaled by s^2
         u32x2 va[4], vb[4];
         read_t<0, 256>(va, vb_); read_t<0, 256>(vb, vb_ + 512);
-        if (kt == nkt - 1) {
+        if constexpr (LAST) {
             const int key0 = 32 * kt + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[r] = (key0 + (r & 3) + 8 * (r >> 2) < T) ? sc[r] : NEG_BIG;
         }
         // raw-unit running maximum (sc2 > 0 commutes with max); masked entries: -1e30 * sc2 is still hugely negative for any sane scale
-        float mx = fmaxf(sc[0], sc[1]);
+        float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
 #pragma unroll
-        for (int r = 2; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
+        mx = fmaxf(mx, sc[15]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(fmaxf((m_run - m_new) * sc2, -126.0f * 64.0f));
-        const float nm = -m_new * sc2;
-        float pv[16];
-        float rs = 0.f;
+        const bool grew = mx > m_run;
+        if (__builtin_amdgcn_ballot_w64(grew)) {       // wave-uniform: some query of this wave has a new maximum
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
+            m_run = m_new;
+            l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = __builtin_amdgcn_exp2f(fmaxf(fmaf(sc[r], sc2, nm), -126.0f * 64.0f));
-            rs += e;
-            pv[r] = e * P_SCALE;
+            for (int r = 0; r < 16; ++r) { acc_o[0][r] *= alpha; acc_o[1][r] *= alpha; }
         }
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
+        const float nm = -m_run * sc2;
+        float pv[16];
+        float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float e0 = __builtin_amdgcn_exp2f(fmaf(sc[r], sc2, nm)), e1 = __builtin_amdgcn_exp2f(fmaf(sc[r + 1], sc2, nm));
+            rs0 += e0; rs1 += e1;
+            pv[r] = e0 * P_SCALE; pv[r + 1] = e1 * P_SCALE;
+        }
+        l_run += rs0 + rs1;
         f16x8 pf0[2], pf1[2];
         pieces_of(pv, pf0, pf1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc_o[0][r] *= alpha; acc_o[1][r] *= alpha; }
         wait_v<4>(va); acc_o[0] = mma3_t(va, pf0, acc_o[0]);
         read_t<2 * VCH, 256>(va, vb_); wait_v<4>(vb); acc_o[0] = mma3_t(vb, pf1, acc_o[0]);
         read_t<2 * VCH, 256>(vb, vb_ + 512); wait_v<4>(va); acc_o[1] = mma3_t(va, pf0, acc_o[1]);
         wait_v<0>(vb); acc_o[1] = mma3_t(vb, pf1, acc_o[1]);
-    }
+    };
+    issue(0);
+    for (int kt = 0; kt < nkt - 1; ++kt) tile(std::false_type{}, kt);
+    tile(std::true_type{}, nkt - 1);
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     // P's scale and the softmax denominator; V's scale is undone for a tp3 image and KEPT for an h2 image: O is a convex combination of
     // V rows, so |O s| <= max |V s| < 2^14 -- the QKV image's scale is a valid scale for O as well
@@ -376,18 +390,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_h2_kernel(BwdP p) {
     const int li = lane & 15, g1 = (lane >> 4) & 1;
     const unsigned tr_off = ((li & 3) >> 1) * 512 + (4 * h + (li >> 2)) * 16 + (li & 1) * 8 + g1 * BLK2;
 
-    issue(0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    // dS = P (dP - delta), scaled for its fp16 pieces: the factors that do not depend on the key are folded once per lane
+    const float c_dp = dp_unscale * ds_scale, c_dl = dl * ds_scale;
+    auto tile = [&]<bool LAST>(std::integral_constant<bool, LAST>, int kt) {
         wait_vm<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nkt) issue(kt + 1);
+        if (!LAST) issue(kt + 1);
         const unsigned st = lds0 + (kt & 1) * BWD_STAGE;
         f32x16 sc = mma_rows(st + lane * 16, qf);                  // S^T  [key (register), query (lane)]
         f32x16 dp = mma_rows(st + 8 * PIECE + lane * 16, dof);     // dP^T
         float ds[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(fminf(fmaf(sc[r], sc2, nlse2), 1.0f)) * (dp[r] * dp_unscale - dl) * ds_scale;
-        if (kt == nkt - 1) {
+        for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], sc2, nlse2)) * fmaf(dp[r], c_dp, -c_dl);
+        if constexpr (LAST) {   // keys beyond the sample exist only in the last tile
             const int key0 = 32 * kt + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ds[r] = (key0 + (r & 3) + 8 * (r >> 2) < T) ? ds[r] : 0.f;
@@ -395,7 +410,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_h2_kernel(BwdP p) {
         f16x8 x0[2], x1[2];
         pieces_of(ds, x0, x1);
         mma_cols(st + tr_off, x0, x1, acc_dq);                     // dQ^T += K^T . dS^T
-    }
+    };
+    issue(0);
+    for (int kt = 0; kt < nkt - 1; ++kt) tile(std::false_type{}, kt);
+    tile(std::true_type{}, nkt - 1);
     if (qi < T) store_block(p, (long)b * T + qi, head * DH, head, h, acc_dq, p.scale * inv_q * ds_inv);
 }
 
@@ -455,11 +473,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_h2_kernel(BwdP p) {
     const int li = lane & 15, g1 = (lane >> 4) & 1;
     const unsigned tr_off = ((li & 3) >> 1) * 512 + (4 * h + (li >> 2)) * 16 + (li & 1) * 8 + g1 * BLK2;
 
-    issue(0);
-    for (int qt = 0; qt < nqt; ++qt) {
+    // dS = P (dP - delta) with the key-independent factors folded once.  Keys are on the LANE here, so a lane of a key beyond the sample
+    // only ever pollutes its own (never stored) column: the one mask left is the query mask of the peeled last tile.
+    const float c_ds = ds_scale, c_dp = dp_unscale * c_ds;
+    auto tile = [&]<bool LAST>(std::integral_constant<bool, LAST>, int qt) {
         wait_vm<0>();
         __builtin_amdgcn_s_barrier();
-        if (qt + 1 < nqt) issue(qt + 1);
+        if (!LAST) issue(qt + 1);
         const unsigned st = lds0 + (qt & 1) * BWD_STAGE;
         f32x16 sc = mma_rows(st + lane * 16, kf);                  // S   [query (register), key (lane)]
         f32x16 dp = mma_rows(st + 8 * PIECE + lane * 16, vf);      // dP
@@ -472,15 +492,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_h2_kernel(BwdP p) {
         float pv[16], dsv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(fminf(fmaf(sc[r], sc2, -LOG2E * l4[r >> 2][r & 3]), 1.0f));
+            const float pr = __builtin_amdgcn_exp2f(fmaf(sc[r], sc2, -LOG2E * l4[r >> 2][r & 3]));
             pv[r] = pr * P_SCALE;
-            dsv[r] = pr * (dp[r] * dp_unscale - d4[r >> 2][r & 3]) * ds_scale;
+            dsv[r] = pr * fmaf(dp[r], c_dp, -c_ds * d4[r >> 2][r & 3]);
         }
-        if (qt == nqt - 1 || !key_ok) {
+        if constexpr (LAST) {
             const int q0 = 32 * qt + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool ok = key_ok && q0 + (r & 3) + 8 * (r >> 2) < T;
+                const bool ok = q0 + (r & 3) + 8 * (r >> 2) < T;
                 pv[r] = ok ? pv[r] : 0.f;
                 dsv[r] = ok ? dsv[r] : 0.f;
             }
@@ -490,7 +510,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_h2_kernel(BwdP p) {
         mma_cols(st + 8 * PIECE + tr_off, x0, x1, acc_dv);         // dV^T += dO^T . P
         pieces_of(dsv, x0, x1);
         mma_cols(st + tr_off, x0, x1, acc_dk);                     // dK^T += Q^T . dS
-    }
+    };
+    issue(0);
+    for (int qt = 0; qt < nqt - 1; ++qt) tile(std::false_type{}, qt);
+    tile(std::true_type{}, nqt - 1);
     if (key_ok) {
         const long m = (long)b * T + ki;
         store_block(p, m, D + head * DH, p.H + head, h, acc_dk, p.scale * inv_q * ds_inv);

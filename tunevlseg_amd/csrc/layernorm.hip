@@ -4,7 +4,33 @@
 #include "common.h"
 #include "tp3.h"
 
+// No implicit multiply-add fusion in this file: the image-writing kernels must reproduce the fp32 kernels bit for bit
+// (tests/test_hip_kernels.py::test_layernorm_tp3, ::test_layernorm_h2_forward_and_backward), and what -ffp-contract=fast fuses depends on the
+// code around an expression.  Fused operations are written out (__builtin_fmaf); the kernels are HBM-bound, the lost fusions cost nothing.
+#pragma clang fp contract(off)
+
 namespace {
+
+// y = ((x - mean) * rstd) * g + b with the last step as ONE fused multiply-add in every kernel of this file: the image-writing kernels must
+// reproduce the fp32 kernel bit for bit (tests/test_hip_kernels.py::test_layernorm_tp3), which -ffp-contract's own choices do not guarantee
+__device__ __forceinline__ float ln_y(float x, float mean, float rstd, float g, float b) { return __builtin_fmaf((x - mean) * rstd, g, b); }
+// the same for the backward: xhat, g = dy gamma, the two row sums' terms and dx, every product either an explicit fma or a multiply that
+// cannot be fused into a neighbour (__fmul_rn)
+__device__ __forceinline__ float4 ln_xhat4(float4 x, float mean, float rstd) {
+    return make_float4(__fmul_rn(x.x - mean, rstd), __fmul_rn(x.y - mean, rstd), __fmul_rn(x.z - mean, rstd), __fmul_rn(x.w - mean, rstd));
+}
+__device__ __forceinline__ float4 ln_mul4(float4 a, float4 b) { return make_float4(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y), __fmul_rn(a.z, b.z), __fmul_rn(a.w, b.w)); }
+__device__ __forceinline__ float ln_sq4(float a, float b, float c, float d) {
+    return __builtin_fmaf(a, a, __fmul_rn(b, b)) + __builtin_fmaf(c, c, __fmul_rn(d, d));
+}
+__device__ __forceinline__ float ln_sum4(float4 g) { return (g.x + g.y) + (g.z + g.w); }
+__device__ __forceinline__ float ln_dot4(float4 g, float4 xh) {
+    return __builtin_fmaf(g.x, xh.x, __fmul_rn(g.y, xh.y)) + __builtin_fmaf(g.z, xh.z, __fmul_rn(g.w, xh.w));
+}
+__device__ __forceinline__ float ln_dx1(float g, float xh, float m1, float m2, float rstd) { return __fmul_rn(rstd, __builtin_fmaf(-xh, m2, g - m1)); }
+__device__ __forceinline__ float4 ln_dx4(float4 g, float4 xh, float m1, float m2, float rstd) {
+    return make_float4(ln_dx1(g.x, xh.x, m1, m2, rstd), ln_dx1(g.y, xh.y, m1, m2, rstd), ln_dx1(g.z, xh.z, m1, m2, rstd), ln_dx1(g.w, xh.w, m1, m2, rstd));
+}
 
 // LN_MAXV float4 per lane held in registers: 4 -> cols <= 1024, 8 -> cols <= 2048 (the CRIS decoder's LayerNorm(2048))
 
@@ -38,7 +64,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             const int c = lane + 64 * i;
             if (c < nv) {
                 const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-                q += (a * a + b * b) + (cc * cc + d * d);
+                q += ln_sq4(a, b, cc, d);
             }
         }
         const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
@@ -50,10 +76,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (beta) b = reinterpret_cast<const float4*>(beta)[c];
                 float4 o;
-                o.x = (v[i].x - mean) * rstd * g.x + b.x;
-                o.y = (v[i].y - mean) * rstd * g.y + b.y;
-                o.z = (v[i].z - mean) * rstd * g.z + b.z;
-                o.w = (v[i].w - mean) * rstd * g.w + b.w;
+                o.x = ln_y(v[i].x, mean, rstd, g.x, b.x);
+                o.y = ln_y(v[i].y, mean, rstd, g.y, b.y);
+                o.z = ln_y(v[i].z, mean, rstd, g.z, b.z);
+                o.w = ln_y(v[i].w, mean, rstd, g.w, b.w);
                 reinterpret_cast<float4*>(yr)[c] = o;
             }
         }
@@ -71,7 +97,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             q += d * d;
         }
         const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
-        for (int c = lane; c < cols; c += 64) yr[c] = (xr[c] - mean) * rstd * gamma[c] + (beta ? beta[c] : 0.f);
+        for (int c = lane; c < cols; c += 64) yr[c] = ln_y(xr[c], mean, rstd, gamma[c], (beta ? beta[c] : 0.f));
         if (lane == 0) {
             if (mean_out) mean_out[row] = mean;
             if (rstd_out) rstd_out[row] = rstd;
@@ -106,10 +132,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 const float4 d = reinterpret_cast<const float4*>(dyr)[c];
                 const float4 xv = reinterpret_cast<const float4*>(xr)[c];
                 const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
-                xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-                g[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
-                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
-                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                xh[i] = ln_xhat4(xv, mean, rstd);
+                g[i] = ln_mul4(d, gm);
+                s1 += ln_sum4(g[i]);
+                s2 += ln_dot4(g[i], xh[i]);
                 if (dgamma) {
                     atomicAdd(&dgamma[4 * c + 0], d.x * xh[i].x); atomicAdd(&dgamma[4 * c + 1], d.y * xh[i].y);
                     atomicAdd(&dgamma[4 * c + 2], d.z * xh[i].z); atomicAdd(&dgamma[4 * c + 3], d.w * xh[i].w);
@@ -125,11 +151,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
-                float4 o;
-                o.x = rstd * (g[i].x - m1 - xh[i].x * m2);
-                o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
-                o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
-                o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+                float4 o = ln_dx4(g[i], xh[i], m1, m2, rstd);
                 if (rr) {
                     const float4 r4 = reinterpret_cast<const float4*>(rr)[c];
                     o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
@@ -172,66 +194,75 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
                                                          float eps, float* __restrict__ inv_scale, float* __restrict__ row_norm,
                                                          unsigned long long* __restrict__ max_slot, unsigned tag) {
     __shared__ float s_mean[32], s_rstd[32], s_scale[32], s_norm[32];
+    __shared__ float4 s_gb[2][LN_MAXV * 64];   // gamma | beta for the second phase (every lane of a half-wave reads the same 32 bytes there)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rb = blockIdx.x;
     const float inv_n = 1.0f / (float)cols;
     const int nv = cols >> 2;
-    for (int rr = 0; rr < 32 / NW; ++rr) {
-        const int rl = wave * (32 / NW) + rr;
+    constexpr int RPW = 32 / NW;   // rows per wave
+    for (int c = threadIdx.x; c < 2 * nv; c += 64 * NW)
+        s_gb[c >= nv][c >= nv ? c - nv : c] = c < nv ? reinterpret_cast<const float4*>(gamma)[c]
+                                                     : (beta ? reinterpret_cast<const float4*>(beta)[c - nv] : make_float4(0.f, 0.f, 0.f, 0.f));
+    __syncthreads();   // gamma | beta staged
+    // Every load of a row is issued before the first use of any of them (clamped indices instead of branches around the loads: a branch
+    // per chunk made hipcc wait for each 16-byte load on its own -- eight HBM latencies in a row per wave, 31 us for a 97 MB pass).
+    auto row_stats = [&](int rr) {
+        const int rl = wave * RPW + rr;
         const long row = rb * 32 + rl;
-        float mean = 0.f, rstd = 0.f;
-        if (row < rows) {
-            const float* xr = x + row * cols;
-            float4 v[LN_MAXV];
-            float s = 0.f;
+        const bool live_row = row < rows;   // wave-uniform
+        const float4* xr = reinterpret_cast<const float4*>(x + (live_row ? row : rows - 1) * cols);
+        float4 v[LN_MAXV];
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = xr[c < nv ? c : nv - 1];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) s += (lane + 64 * i < nv) ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.f;
+        const float mean = wave_sum(s) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (lane + 64 * i < nv) ? ln_sq4(a, b, cc, d) : 0.f;
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+        if (lane == 0 && live_row) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+        if constexpr (NP == 2) {
+            float amax = 0.f, ss = 0.f;
 #pragma unroll
             for (int i = 0; i < LN_MAXV; ++i) {
-                const int c = lane + 64 * i;
-                if (c < nv) {
-                    v[i] = reinterpret_cast<const float4*>(xr)[c];
-                    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-                }
+                const int c = lane + 64 * i, cc = c < nv ? c : nv - 1;
+                const float4 g4 = s_gb[0][cc], b4 = s_gb[1][cc];
+                const float y0 = ln_y(v[i].x, mean, rstd, g4.x, b4.x), y1 = ln_y(v[i].y, mean, rstd, g4.y, b4.y);
+                const float y2 = ln_y(v[i].z, mean, rstd, g4.z, b4.z), y3 = ln_y(v[i].w, mean, rstd, g4.w, b4.w);
+                amax = c < nv ? fmaxf(fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1))), fmaxf(fabsf(y2), fabsf(y3))) : amax;
+                ss += c < nv ? (y0 * y0 + y1 * y1) + (y2 * y2 + y3 * y3) : 0.f;
             }
-            mean = wave_sum(s) * inv_n;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < LN_MAXV; ++i) {
-                const int c = lane + 64 * i;
-                if (c < nv) {
-                    const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-                    q += (a * a + b * b) + (cc * cc + d * d);
-                }
-            }
-            rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+            amax = wave_max(amax);
+            ss = wave_sum(ss);
+            const float inv = live_row ? h2::inv_scale_of(amax) : 1.0f;
             if (lane == 0) {
-                if (mean_out) mean_out[row] = mean;
-                if (rstd_out) rstd_out[row] = rstd;
-            }
-            if constexpr (NP == 2) {
-                float amax = 0.f, ss = 0.f;
-#pragma unroll
-                for (int i = 0; i < LN_MAXV; ++i) {
-                    const int c = lane + 64 * i;
-                    if (c < nv) {
-                        const float4 g4 = reinterpret_cast<const float4*>(gamma)[c];
-                        const float4 b4 = beta ? reinterpret_cast<const float4*>(beta)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        const float y0 = (v[i].x - mean) * rstd * g4.x + b4.x, y1 = (v[i].y - mean) * rstd * g4.y + b4.y;
-                        const float y2 = (v[i].z - mean) * rstd * g4.z + b4.z, y3 = (v[i].w - mean) * rstd * g4.w + b4.w;
-                        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1))), fmaxf(fabsf(y2), fabsf(y3)));
-                        ss += (y0 * y0 + y1 * y1) + (y2 * y2 + y3 * y3);
-                    }
-                }
-                amax = wave_max(amax);
-                ss = wave_sum(ss);
-                const float inv = h2::inv_scale_of(amax);
-                if (lane == 0) {
-                    const float nrm = sqrtf(ss) * 1.0001f;   // ||y row||_2, rounded up: it feeds a bound (tvl_gemm_h2_out)
-                    inv_scale[row] = inv; s_scale[rl] = 1.0f / inv; s_norm[rl] = nrm;
+                const float nrm = live_row ? sqrtf(ss) * 1.0001f : 0.f;   // ||y row||_2, rounded up: it feeds a bound (tvl_gemm_h2_out)
+                s_scale[rl] = 1.0f / inv; s_norm[rl] = nrm;
+                if (live_row) {
+                    inv_scale[row] = inv;
                     if (row_norm) row_norm[row] = nrm;
                 }
             }
-        } else if (NP == 2 && lane == 0) { s_scale[rl] = 1.0f; s_norm[rl] = 0.f; }
-        if (lane == 0) { s_mean[rl] = mean; s_rstd[rl] = rstd; }
+        }
+        if (lane == 0) { s_mean[rl] = live_row ? mean : 0.f; s_rstd[rl] = live_row ? rstd : 0.f; }
+    };
+    if constexpr (LN_MAXV > 4) {   // wide rows: one row's registers at a time
+#pragma unroll 1
+        for (int rr = 0; rr < RPW; ++rr) row_stats(rr);
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) row_stats(rr);
     }
     __syncthreads();
     if constexpr (NP == 2) {   // largest row norm of the call: one tagged atomicMax per workgroup (include/tvl_hip.h)
@@ -246,37 +277,48 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
     const float mean = s_mean[r], rstd = s_rstd[r];
     const int KB = cols >> 4;
     const float* xr = x + (live ? row : 0) * cols;
-    for (int kb = wave; kb < KB; kb += NW) {
-        const int c0 = kb * 16 + h * 8;
-        float v[8];
-        const float4 a = *reinterpret_cast<const float4*>(xr + c0), b = *reinterpret_cast<const float4*>(xr + c0 + 4);
-        const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
-        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-        if (beta) { b0 = *reinterpret_cast<const float4*>(beta + c0); b1 = *reinterpret_cast<const float4*>(beta + c0 + 4); }
-        v[0] = (a.x - mean) * rstd * g0.x + b0.x; v[1] = (a.y - mean) * rstd * g0.y + b0.y;
-        v[2] = (a.z - mean) * rstd * g0.z + b0.z; v[3] = (a.w - mean) * rstd * g0.w + b0.w;
-        v[4] = (b.x - mean) * rstd * g1.x + b1.x; v[5] = (b.y - mean) * rstd * g1.y + b1.y;
-        v[6] = (b.z - mean) * rstd * g1.z + b1.z; v[7] = (b.w - mean) * rstd * g1.w + b1.w;
+    constexpr int NIT = (LN_MAXV * 16 + NW - 1) / NW;   // k-blocks of this wave (cols <= 256 LN_MAXV)
+    constexpr int GRP = NIT < 4 ? NIT : 4;
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT && wave + NW * it0 < KB; it0 += GRP) {
+    float4 pa[GRP], pb[GRP];
+#pragma unroll
+    for (int it = 0; it < GRP; ++it) {   // the rows of a group of the wave's blocks first (L2 hits: this workgroup has just read these rows)
+        const int kb = wave + NW * (it0 + it), c0 = (kb < KB ? kb : KB - 1) * 16 + h * 8;
+        pa[it] = *reinterpret_cast<const float4*>(xr + c0); pb[it] = *reinterpret_cast<const float4*>(xr + c0 + 4);
+    }
+#pragma unroll
+    for (int it = 0; it < GRP; ++it) {
+        const int kb = wave + NW * (it0 + it);
+        if (kb >= KB) break;
+        const int c4 = kb * 4 + h * 2;
+        const float4 a = pa[it], b = pb[it], g0 = s_gb[0][c4], g1 = s_gb[0][c4 + 1], b0 = s_gb[1][c4], b1 = s_gb[1][c4 + 1];
+        float v8[8];
+        v8[0] = ln_y(a.x, mean, rstd, g0.x, b0.x); v8[1] = ln_y(a.y, mean, rstd, g0.y, b0.y);
+        v8[2] = ln_y(a.z, mean, rstd, g0.z, b0.z); v8[3] = ln_y(a.w, mean, rstd, g0.w, b0.w);
+        v8[4] = ln_y(b.x, mean, rstd, g1.x, b1.x); v8[5] = ln_y(b.y, mean, rstd, g1.y, b1.y);
+        v8[6] = ln_y(b.z, mean, rstd, g1.z, b1.z); v8[7] = ln_y(b.w, mean, rstd, g1.w, b1.w);
         if (!live) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            for (int e = 0; e < 8; ++e) v8[e] = 0.f;
         }
         if constexpr (NP == 3) {
             uint4 pl[3];
-            tp3::split8(v, pl);
+            tp3::split8(v8, pl);
             unsigned char* o = out + (rb * KB + kb) * (long)tp3::BLK + lane * 16;
 #pragma unroll
             for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(o + s * tp3::PIECE) = pl[s];
         } else {
             const float sc = s_scale[r];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= sc;
+            for (int e = 0; e < 8; ++e) v8[e] *= sc;
             uint4 pl[2];
-            h2::split8(v, pl);
+            h2::split8(v8, pl);
             unsigned char* o = out + (rb * KB + kb) * (long)h2::BLK + lane * 16;
             *reinterpret_cast<uint4*>(o) = pl[0];
             *reinterpret_cast<uint4*>(o + h2::PIECE) = pl[1];
         }
+    }
     }
 }
 
@@ -290,68 +332,72 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
                                                          long rows, int cols, float* __restrict__ inv_scale, float* __restrict__ row_norm,
                                                          unsigned long long* __restrict__ max_slot, unsigned tag) {
     __shared__ float s_scale[32], s_norm[32];
+    __shared__ float4 s_g[LN_MAXV * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rb = blockIdx.x;
     const float inv_n = 1.0f / (float)cols;
     const int nv = cols >> 2;
-    for (int rr = 0; rr < 32 / NW; ++rr) {
-        const long row = rb * 32 + wave * (32 / NW) + rr;
-        if (row >= rows) {
-            if (NP == 2 && lane == 0) { s_scale[wave * (32 / NW) + rr] = 1.0f; s_norm[wave * (32 / NW) + rr] = 0.f; }
-            continue;
+    constexpr int RPW = 32 / NW;
+    for (int c = threadIdx.x; c < nv; c += 64 * NW) s_g[c] = reinterpret_cast<const float4*>(gamma)[c];
+    __syncthreads();
+    auto row_grad = [&](int rr) {
+        const int rl = wave * RPW + rr;
+        const long row = rb * 32 + rl;
+        const bool live_row = row < rows;   // wave-uniform
+        const long rowc = live_row ? row : rows - 1;
+        // all of the row's loads before the first use (see ln_fwd_tp3_kernel)
+        float4 d[LN_MAXV], xv[LN_MAXV], r4[LN_MAXV];
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i, cc = c < nv ? c : nv - 1;
+            d[i] = reinterpret_cast<const float4*>(dy + rowc * cols)[cc];
+            xv[i] = reinterpret_cast<const float4*>(x + rowc * cols)[cc];
+            r4[i] = dres ? reinterpret_cast<const float4*>(dres + rowc * cols)[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        float amax = 0.f, ss = 0.f;
-        const float* xr = x + row * cols;
-        const float* dyr = dy + row * cols;
-        float* dxr = dx + row * cols;
-        const float* rres = dres ? dres + row * cols : nullptr;
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        float4 g[LN_MAXV], xh[LN_MAXV];
+        const float mean = mean_in[rowc], rstd = rstd_in[rowc];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nv) {
-                const float4 d = reinterpret_cast<const float4*>(dyr)[c];
-                const float4 xv = reinterpret_cast<const float4*>(xr)[c];
-                const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
-                xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-                g[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
-                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
-                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
-            }
+            xv[i] = ln_xhat4(xv[i], mean, rstd);
+            const bool in = lane + 64 * i < nv;
+            d[i] = ln_mul4(d[i], s_g[in ? lane + 64 * i : nv - 1]);   // g
+            s1 += in ? ln_sum4(d[i]) : 0.f;
+            s2 += in ? ln_dot4(d[i], xv[i]) : 0.f;
         }
         const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
+        float amax = 0.f, ss = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + 64 * i;
-            if (c < nv) {
-                float4 o;
-                o.x = rstd * (g[i].x - m1 - xh[i].x * m2);
-                o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
-                o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
-                o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
-                if (rres) {
-                    const float4 r4 = reinterpret_cast<const float4*>(rres)[c];
-                    o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
-                }
-                reinterpret_cast<float4*>(dxr)[c] = o;
-                if constexpr (NP == 2) {
-                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-                    ss += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-                }
+            float4 o = ln_dx4(d[i], xv[i], m1, m2, rstd);
+            if (dres) { o.x += r4[i].x; o.y += r4[i].y; o.z += r4[i].z; o.w += r4[i].w; }
+            if (c < nv && live_row) reinterpret_cast<float4*>(dx + row * cols)[c] = o;
+            if constexpr (NP == 2) {
+                const bool in = c < nv;
+                amax = in ? fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w))) : amax;
+                ss += in ? (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w) : 0.f;
             }
         }
         if constexpr (NP == 2) {
             amax = wave_max(amax);
             ss = wave_sum(ss);
-            const float inv = h2::inv_scale_of(amax);
+            const float inv = live_row ? h2::inv_scale_of(amax) : 1.0f;
             if (lane == 0) {
-                const float nrm = sqrtf(ss) * 1.0001f;
-                inv_scale[row] = inv; s_scale[wave * (32 / NW) + rr] = 1.0f / inv; s_norm[wave * (32 / NW) + rr] = nrm;
-                if (row_norm) row_norm[row] = nrm;
+                const float nrm = live_row ? sqrtf(ss) * 1.0001f : 0.f;
+                s_scale[rl] = 1.0f / inv; s_norm[rl] = nrm;
+                if (live_row) {
+                    inv_scale[row] = inv;
+                    if (row_norm) row_norm[row] = nrm;
+                }
             }
         }
+    };
+    if constexpr (LN_MAXV > 4) {
+#pragma unroll 1
+        for (int rr = 0; rr < RPW; ++rr) row_grad(rr);
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) row_grad(rr);
     }
     // the block's dx rows are re-read by other waves of this workgroup: drain the stores, then make them visible (the lines
     // were never in this CU's L1, but the order store -> load across waves still needs the fence + barrier)
@@ -369,11 +415,23 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
     const bool live = row < rows;
     const int KB = cols >> 4;
     const float* dxr = dx + (live ? row : 0) * cols;
-    for (int kb = wave; kb < KB; kb += NW) {
-        const int c0 = kb * 16 + h * 8;
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dxr + c0));  // past this CU's L1
-        const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dxr + c0 + 4));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NIT = (LN_MAXV * 16 + NW - 1) / NW;
+    constexpr int GRP = NIT < 4 ? NIT : 4;
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT && wave + NW * it0 < KB; it0 += GRP) {
+    f32x4 pa[GRP], pb[GRP];
+#pragma unroll
+    for (int it = 0; it < GRP; ++it) {
+        const int kb = wave + NW * (it0 + it), c0 = (kb < KB ? kb : KB - 1) * 16 + h * 8;
+        pa[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dxr + c0));  // past this CU's L1
+        pb[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dxr + c0 + 4));
+    }
+#pragma unroll
+    for (int it = 0; it < GRP; ++it) {
+        const int kb = wave + NW * (it0 + it);
+        if (kb >= KB) break;
+        const f32x4 a = pa[it], b = pb[it];
         float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         if (!live) {
 #pragma unroll
@@ -395,6 +453,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
             *reinterpret_cast<uint4*>(o) = pl[0];
             *reinterpret_cast<uint4*>(o + h2::PIECE) = pl[1];
         }
+    }
     }
 }
 
@@ -440,7 +499,7 @@ extern "C" int tvl_layernorm_fwd_tp3(const float* x, const float* gamma, const f
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(y_tp3);
     if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0u);
-    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0u);
+    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 8>), dim3(grid), dim3(512), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0u);
     TVL_LAUNCH_CHECK("tvl_layernorm_fwd_tp3");
     return 0;
 }
@@ -455,7 +514,7 @@ extern "C" int tvl_layernorm_bwd_tp3(const float* dy, const float* x, const floa
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(dx_tp3);
     if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0u);
-    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0u);
+    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 8>), dim3(grid), dim3(512), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0u);
     TVL_LAUNCH_CHECK("tvl_layernorm_bwd_tp3");
     return 0;
 }
@@ -472,7 +531,7 @@ extern "C" int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const fl
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(y_h2);
     if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm, slot, (unsigned)tag);
-    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm, slot, (unsigned)tag);
+    else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 8, 2>), dim3(grid), dim3(512), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm, slot, (unsigned)tag);
     TVL_LAUNCH_CHECK("tvl_layernorm_fwd_h2");
     return 0;
 }
@@ -490,7 +549,7 @@ extern "C" int tvl_layernorm_bwd_h2(const float* dy, const float* x, const float
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(dx_h2);
     if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm, slot, (unsigned)tag);
-    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm, slot, (unsigned)tag);
+    else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 8, 2>), dim3(grid), dim3(512), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm, slot, (unsigned)tag);
     TVL_LAUNCH_CHECK("tvl_layernorm_bwd_h2");
     return 0;
 }
