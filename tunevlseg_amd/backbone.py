@@ -134,6 +134,8 @@ class CLIPSegBackbone(_Node):
                 "vision_layers": [self._layer_weights(l) for l in v.encoder.layers],
                 "text_layers": [self._layer_weights(l) for l in t.encoder.layers],
                 "decoder_layers": [self._layer_weights(l) for l in self.decoder.layers],
+                # the decoder's reduce Linears (768 -> 64) with their transposes: the data gradient into the tower runs as an NT GEMM
+                "reduces": [(r.weight.detach().contiguous(), r.bias.detach().contiguous(), r.weight.detach().t().contiguous()) for r in self.decoder.reduces],
                 "patch_w": v.embeddings.patch_embedding.weight.detach().reshape(self.config.vision_config.hidden_size, -1).contiguous(),
                 "patch_size": ps,
             }

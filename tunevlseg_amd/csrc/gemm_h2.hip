@@ -327,6 +327,8 @@ static int gemm_h2_impl(const tvlGemmTp3Args* a, const float* a_row_scale, void*
     int bm = a->tile_m;
     static const int stagger_us = getenv("TVL_GEMM_STAGGER_US") ? atoi(getenv("TVL_GEMM_STAGGER_US")) : 0;   // experiment knob
     p.stagger_ticks = stagger_us * 100;
+    static const int f32_direct = getenv("TVL_GEMM_F32_DIRECT") ? atoi(getenv("TVL_GEMM_F32_DIRECT")) : 1;   // A/B switch (0 = through the LDS scratch)
+    p.f32_direct = f32_direct;
     if (bm == 128 && !conv) {
     } else if (bm != 256 && bm != 192 && bm != 2564 && bm != 2565 && bm != 1924 && bm != 1925 && bm != 2566 && bm != 1926 && bm != 2560 && bm != 1920) {
         const long t256 = ((long)(a->M + 255) / 256) * ((a->N + 255) / 256), t192 = ((long)(a->M + 191) / 192) * ((a->N + 255) / 256);
@@ -415,6 +417,8 @@ extern "C" int tvl_gemm_h2_ks(const tvlGemmTp3Args* a, const float* a_kscale, tv
     p.A = reinterpret_cast<const unsigned char*>(a->A); p.a_rb = (int)((a->a_rows + 31) / 32);
     p.B = reinterpret_cast<const unsigned char*>(a->B); p.b_rb = (int)((a->b_rows + 31) / 32);
     p.C = a->C; p.ldc = a->ldc; p.alpha = a->alpha; p.a_kscale = a_kscale; p.k_chunks = a->K / 64; p.a_sstride = 1;
+    static const int f32_direct_ks = getenv("TVL_GEMM_F32_DIRECT") ? atoi(getenv("TVL_GEMM_F32_DIRECT")) : 1;
+    p.f32_direct = f32_direct_ks;
     const int rc = (use_m16() && p.K >= 96) ? tvl_gemm_h2m_ks_t192(&p, reinterpret_cast<hipStream_t>(stream))
                                             : launch<192, 256, 3, E_F32 | E_RSCALE, 2, true>(p, reinterpret_cast<hipStream_t>(stream));
     TVL_REQUIRE(rc == 0, "tvl_gemm_h2_ks: launch failed (dynamic LDS opt-in?)");

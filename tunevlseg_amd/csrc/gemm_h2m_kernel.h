@@ -149,6 +149,62 @@ __device__ __forceinline__ void epilogue16_direct(const Tp3Params& p, f32x4 (&ac
     [&]<int... I>(std::integer_sequence<int, I...>) { (row_block(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, TMo>{});
 }
 
+// The fp32-output epilogues (out-projection / fc2: bias + residual; the data gradients: plain; frozen Linears / convs: bias [+ ReLU]) straight
+// from the accumulators as well: a lane's four registers of a 16 x 16 tile are 16 contiguous bytes of one row, the four lane groups of a
+// tile 64 contiguous bytes, so a row leaves as 64-byte segments (the scratch path: 128-byte segments, after an LDS round trip behind a
+// workgroup barrier).  The residual's four tiles of row block i + 1 are requested while row block i is computed.
+template <int TMo, int EPI>
+__device__ __forceinline__ void epilogue16_direct_f32(const Tp3Params& p, f32x4 (&acc)[TMo][4], int row_base, int col_base, int lane) {
+    static_assert((EPI & E_F32) && !(EPI & (E_TP3 | E_H2OUT | E_PRE | E_DQGELU | E_QGELU)) && (EPI & E_RSCALE), "plain fp32 epilogues");
+    const int m = lane & 15, q = lane >> 4;
+    float4 bias4[4];
+    if constexpr ((EPI & E_BIAS) != 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col_base + 16 * j + 4 * q;
+            bias4[j] = col + 3 < p.N ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float4 res[2][4];
+    auto load_res = [&](auto ic, auto bc) {
+        constexpr int i = decltype(ic)::value, bsel = decltype(bc)::value;
+        if constexpr ((EPI & E_RES) != 0 && i < TMo) {
+            const long row = row_base + 16 * i + m;
+            [&]<int... J>(std::integer_sequence<int, J...>) {
+                ((res[bsel][J] = (row < p.M && col_base + 16 * J + 4 * q + 3 < p.N)
+                                     ? *reinterpret_cast<const float4*>(p.residual + row * p.ldr + col_base + 16 * J + 4 * q)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f)), ...);
+            }(std::make_integer_sequence<int, 4>{});
+        }
+    };
+    auto tile = [&](auto ic, auto jc, long row, float f) {
+        constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+        const int col = col_base + 16 * j + 4 * q;
+        if (col + 3 >= p.N) return;
+        float v[4] = {acc[i][j][0] * f, acc[i][j][1] * f, acc[i][j][2] * f, acc[i][j][3] * f};
+        if constexpr ((EPI & E_BIAS) != 0) { v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w; }
+        if constexpr ((EPI & E_RELU) != 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if constexpr ((EPI & E_RES) != 0) {
+            const float4 r4 = res[i & 1][j];
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        *reinterpret_cast<float4*>(p.C + row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+    };
+    auto row_block = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        load_res(std::integral_constant<int, i + 1>{}, std::integral_constant<int, (i + 1) & 1>{});
+        const long row = row_base + 16 * i + m;
+        if (row >= p.M) return;
+        const float f = p.a_kscale ? p.alpha * p.a_kscale[row * p.k_chunks + p.k_chunks - 1] : p.alpha * p.a_scale[row * p.a_sstride];
+        [&]<int... J>(std::integer_sequence<int, J...>) { (tile(ic, std::integral_constant<int, J>{}, row, f), ...); }(std::make_integer_sequence<int, 4>{});
+    };
+    load_res(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    [&]<int... I>(std::integer_sequence<int, I...>) { (row_block(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, TMo>{});
+}
+
 // PERSIST: one workgroup per CU walks several tiles (launches of more than 256 tiles: fc1, its data gradient's dz, QKV).  The reason is
 // the epilogue: 256-640 KB of stores per tile that every CU of a lock-stepped round issues at the same moment -- a chip-wide HBM burst
 // of ~130 MB with no MFMA under it, three times per launch.  De-phasing workgroups INDIVIDUALLY would break what keeps the operand
@@ -443,6 +499,12 @@ __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
             epilogue16_direct<TMo, EPI>(p, acc, tile_m * BM + wm * WM, tile_n * BN + wn * 64, lane,   // registers -> images: no scratch, no barrier
                                         (((long)tile_m * p.tiles_n + tile_n) * NW + wave) * (TMo * 4));
         } else {
+            if constexpr (EPI >= 0 && (EPI & E_F32) != 0 && (EPI & (E_TP3 | E_H2OUT | E_PRE | E_DQGELU | E_QGELU)) == 0 && (EPI & E_RSCALE) != 0 && !PERSIST) {
+                if (p.f32_direct) {   // kernel-uniform
+                    epilogue16_direct_f32<TMo, EPI>(p, acc, tile_m * BM + wm * WM, tile_n * BN + wn * 64, lane);
+                    return;
+                }
+            }
             __syncthreads();  // every wave is past its last LDS read: the stages become epilogue scratch
             float* scratch = reinterpret_cast<float*>(smem) + wave * (TMo * 16 * 37);
             epilogue16<TMo, EPI>(p, acc, tile_m * BM + wm * WM, tile_n * BN + wn * 64, lane, scratch);

@@ -73,6 +73,7 @@ struct Tp3Params {
     int cH, cW, cC16;
     int tiles_m, tiles_n;
     int stagger_ticks;   // NW = 4 kernels: start delay (10 ns ticks of s_memrealtime) of the second workgroup of each CU, 0 = none
+    int f32_direct;                 // gemm_h2m_kernel: plain fp32-output epilogues straight from the accumulators (64-byte row segments, no LDS round trip)
     int aux_blocked;                // gemm_h2m_kernel's direct epilogue: pre_out / dact_aux in accumulator order (tvlGemmTp3Args.aux_blocked)
     float* work; long work_bytes;   // gemm_h2m_kernel<PERSIST>: where a workgroup parks the partial sums of its split first tile (or null)
 };

@@ -741,6 +741,9 @@ def _gemm_takes_h2(layout, M, N, K, A, lda, B, ldb, Cout, ldc, residual, ldr, pr
                 and (dact_aux is None or (dact_aux.dim() == 2 and dact_aux.stride(0) == ld_aux)))
 
 
+SPLITK_MIN_K = int(os.environ.get("TVL_GEMM_SPLITK_MIN_K", "768"))   # (1024 until round 3: the decoder's reduce Linears have K = 768)
+
+
 def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias=None, residual=None, ldr=0, act=ACT_NONE,
          pre_out=None, dact_aux=None, ld_aux=0, dact=ACT_NONE, alpha=1.0, a_map=None, c_map=None, a_relu_mask=None):
     takes_h2 = _gemm_takes_h2(layout, M, N, K, A, lda, B, ldb, Cout, ldc, residual, ldr, pre_out, dact_aux, ld_aux, alpha, a_map, c_map)
@@ -756,7 +759,7 @@ def gemm(layout: int, M: int, N: int, K: int, A, lda, B, ldb, Cout, ldc, *, bias
     split = _NSPLIT.get(GEMM_MODE, 0) if (layout == NT and M >= 256) else 0
     # skinny and deep (text-tower GEMMs: a few dozen 64x64 tiles, 48-64 k-slabs each): split K over more workgroups
     tiles64 = ((M + 63) // 64) * ((N + 63) // 64)
-    if split == 3 and SPLITK and tiles64 <= 256 and K >= 1024:
+    if split == 3 and SPLITK and tiles64 <= 256 and K >= SPLITK_MIN_K:
         splits = min(8, K // 256)
         ws = torch.empty(splits * M * N, device=Cout.device, dtype=torch.float32)
         if _gemm_prof is not None:

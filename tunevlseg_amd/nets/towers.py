@@ -171,8 +171,8 @@ def decoder_tokens(model: CLIPSegBackbone, activations, conditional_embeddings: 
     spec = ops.AttnSpec(cfg.decoder_num_attention_heads, hip.ACT_RELU, cfg.vision_config.layer_norm_eps)
     out = None
     for i, act in enumerate(activations[::-1]):
-        red = dec.reduces[i]
-        out = ops.linear(act, red.weight.detach(), red.bias.detach(), hip.ACT_NONE, out)
+        rw, rb, rwt = prep["reduces"][i]
+        out = ops.linear(act, rw, rb, hip.ACT_NONE, out, rwt)
         if i == dec.conditional_layer:
             mul = ops.linear(conditional_embeddings, dec.film_mul.weight.detach(), dec.film_mul.bias.detach())
             add = ops.linear(conditional_embeddings, dec.film_add.weight.detach(), dec.film_add.bias.detach())

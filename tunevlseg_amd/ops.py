@@ -334,10 +334,11 @@ class LinearFn(Fn):
     """y = act(x W^T + b) [+ residual]; data gradient always, weight/bias gradients when they are trainable."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act, residual):
+    def forward(ctx, x, W, b, act, residual, Wt=None):
         shape = x.shape
         x2d = _c(x).view(-1, shape[-1])
         W = _c(W)
+        ctx.Wt = Wt   # W^T kept by the caller for a frozen W: the data gradient becomes an NT GEMM (split-bf16 kernel)
         need_any = any(ctx.needs_input_grad)
         if act != hip.ACT_NONE and need_any:
             y, pre = hip.linear_fwd(x2d, W, b, act=act, residual=None if residual is None else _c(residual).view(-1, W.shape[0]), want_pre=True)
@@ -359,18 +360,18 @@ class LinearFn(Fn):
             dz = dy2d
         dx = dW = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = hip.linear_dgrad(dz, W).view(ctx.in_shape)
+            dx = hip.linear_dgrad(dz, W, Wt=ctx.Wt).view(ctx.in_shape)
         if ctx.needs_input_grad[1]:
             dW = hip.linear_wgrad(dz, x2d)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = hip.colsum(dz)
         if ctx.needs_input_grad[4]:
             dres = dy
-        return dx, dW, db, None, dres
+        return dx, dW, db, None, dres, None
 
 
-def linear(x, W, b=None, act=hip.ACT_NONE, residual=None):
-    return LinearFn.apply(x, W, b, act, residual)
+def linear(x, W, b=None, act=hip.ACT_NONE, residual=None, Wt=None):
+    return LinearFn.apply(x, W, b, act, residual, Wt)
 
 
 class LayerNormFn(Fn):
