@@ -14,8 +14,8 @@ class BaseMultimodalCLIPSeg(BaseCLIPSeg):
     # pass (shared_attn_learner.py:89-90): they keep the reference's sequential order.
     TEXT_BESIDE_VISION = False
 
-    def get_vision_outputs(self, pixel_values: torch.Tensor):
-        acts, _ = towers.vision_tower(self.model, pixel_values, self.context_learner)
+    def get_vision_outputs(self, pixel_values: torch.Tensor, visual_contexts=None, ready=None):
+        acts, _ = towers.vision_tower(self.model, pixel_values, self.context_learner, visual_contexts=visual_contexts, ready=ready)
         return acts
 
     def get_conditional_embeddings(self, batch_size, input_ids, attention_mask):
@@ -33,8 +33,13 @@ class BaseMultimodalCLIPSeg(BaseCLIPSeg):
         if conditional_embeddings is None and self.TEXT_BESIDE_VISION:
             side = towers.SideStream(pixel_values.device)
             with side:
+                # the visual prompts of every depth are projections of parameters (maple_context_learner.py:7-20): computed ahead of the
+                # text tower on the side stream, they (and their weight gradients in the backward) leave the vision tower's critical path
+                learner = self.context_learner
+                vis = [learner.get_visual_context(index=i) for i in range(learner.prompt_depth)] if side.on else None
+                ready = side.mark()
                 conditional_embeddings = self.get_conditional_embeddings(pixel_values.shape[0], input_ids, attention_mask)
-            activations = self.get_vision_outputs(pixel_values)
+            activations = self.get_vision_outputs(pixel_values, vis, ready)
             side.join(conditional_embeddings)
             out = self.decoder_forward(activations, conditional_embeddings)
             out.conditional_embeddings = conditional_embeddings

@@ -67,6 +67,10 @@ class SideStream:
                 if t is not None:
                     t.record_stream(self.cur)
 
+    def mark(self):
+        """An event after everything enqueued on the side stream so far (call inside the ``with`` block); None when off."""
+        return self.side.record_event() if self.on else None
+
 
 def patch_embeddings(model: CLIPSegBackbone, pixel_values: torch.Tensor) -> torch.Tensor:
     """16x16/s16 patch conv as im2col + GEMM (HF:195-197).  Frozen, image carries no grad -> no autograd node."""
@@ -81,8 +85,10 @@ def patch_embeddings(model: CLIPSegBackbone, pixel_values: torch.Tensor) -> torc
     return patch.view(B, (H // ps) * (W // ps), -1)
 
 
-def vision_tower(model: CLIPSegBackbone, pixel_values: torch.Tensor, learner=None, full: bool = False):
-    """Returns ``(activations at extract_layers, pooled)``; ``pooled`` = visual_projection(post_layernorm(CLS)) when ``full``."""
+def vision_tower(model: CLIPSegBackbone, pixel_values: torch.Tensor, learner=None, full: bool = False, visual_contexts=None, ready=None):
+    """Returns ``(activations at extract_layers, pooled)``; ``pooled`` = visual_projection(post_layernorm(CLS)) when ``full``.
+    ``visual_contexts``: the learner's visual prompts of every depth, computed ahead (they depend on parameters only) -- e.g. on the side
+    stream, in which case ``ready`` is the event after them: the tower then launches nothing between its layers but the row overwrite."""
     cfg = model.config
     v = cfg.vision_config
     prep = model.prepared()
@@ -93,8 +99,15 @@ def vision_tower(model: CLIPSegBackbone, pixel_values: torch.Tensor, learner=Non
     prompts = None
     depth = 1
     if learner is not None and not full:
-        prompts = learner.get_visual_context(index=0)
         depth = learner.prompt_depth
+        if visual_contexts is not None:
+            if ready is not None:
+                torch.cuda.current_stream(pixel_values.device).wait_event(ready)
+                for c in visual_contexts:
+                    c.record_stream(torch.cuda.current_stream(pixel_values.device))
+            prompts = visual_contexts[0]
+        else:
+            prompts = learner.get_visual_context(index=0)
     x = ops.VisionAssembleFn.apply(patch, vm.embeddings.class_embedding.detach(), pos, prompts)
     # NB concat happens BEFORE pre_layrnorm (vpt_clipseg.py:178-181)
     x = ops.layer_norm(x, vm.pre_layrnorm.weight.detach(), vm.pre_layrnorm.bias.detach(), v.layer_norm_eps)
@@ -104,7 +117,10 @@ def vision_tower(model: CLIPSegBackbone, pixel_values: torch.Tensor, learner=Non
     for idx in range(1, v.num_hidden_layers + 1):
         x = ops.encoder_layer(x, prep["vision_layers"][idx - 1], spec)
         if prompts is not None and idx < depth:
-            x = learner.mutate_image_hidden_states(x, index=idx)
+            if visual_contexts is not None:   # learner.mutate_image_hidden_states with the context computed ahead
+                x = ops.RowsOverwriteFn.apply(x, visual_contexts[idx], x.shape[1] - learner.num_context)
+            else:
+                x = learner.mutate_image_hidden_states(x, index=idx)
         states.append(x)
         if not full and idx > max_idx:  # "No need to run the vision transformer for more layers" (vpt_clipseg.py:129-131)
             break
