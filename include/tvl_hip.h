@@ -28,7 +28,7 @@ typedef void* tvlStream_t; /* hipStream_t */
 
 /* Bumped on every incompatible change of a signature or struct below.  3: tvl_dicece_stats gained `work`, tvl_split_planes /
  * tvl_gemm_planes removed (round 2).  4: tvl_text_assemble gained `vocab` (rows of the embedding table: ids outside it give NaN rows
- * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  5: tvl_dicece_loss, tvl_mlp64_* added;
+ * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  5: tvl_dicece_loss, tvl_mlp64_*, tvl_h2_zero_rows added;
  * tvl_layernorm_fwd_h2 / _bwd_h2 gained max_slot / tag (largest row norm by tagged atomicMax).  The Python binding refuses a library whose tvl_abi_version() differs. */
 #define TVL_ABI_VERSION 5
 
@@ -354,6 +354,9 @@ int tvl_h2_pack(const float* x, int64_t ldx, int64_t rows, int32_t K, void* out,
 /* tvl_h2_pack of x * (mask > 0): a ReLU layer's data gradient gated while it is packed (mask = the layer's output) */
 int tvl_h2_pack_masked(const float* x, int64_t ldx, const float* mask, int64_t ldm, int64_t rows, int32_t K, void* out, float* inv_scale,
                        float* row_norm /* [rows] or null */, int32_t per_row, void* work, tvlStream_t stream);
+/* rows b*T + row0 .. + n - 1 (b < B) of an h2 image of [B*T, K] := 0: keeps the image that travels with a gradient valid across the gradient
+ * cut of an in-place prompt overwrite (tvl_rows_grad with zero_src; reference base_visual_learner.py:18-23) */
+int tvl_h2_zero_rows(void* img, int32_t K, int32_t B, int32_t T, int32_t row0, int32_t n, tvlStream_t stream);
 int tvl_h2_absmax(const float* x, int64_t ldx, int64_t rows, int32_t K, void* bits /* 4 bytes: max |x| as float bits */, tvlStream_t stream);
 int tvl_gemm_h2(const tvlGemmTp3Args* args, const float* a_row_scale, tvlStream_t stream);
 /* ... with the result written as an h2 image (the next GEMM's A operand).  Its row scales come from the bound

@@ -278,6 +278,31 @@ extern "C" int tvl_h2_pack_masked(const float* x, int64_t ldx, const float* mask
     return h2_pack_impl(x, ldx, mask, ldm, rows, K, out, inv_scale, row_norm, per_row, work, stream);
 }
 
+// rows b * T + row0 .. + n - 1 (b = 0 .. B - 1) of an h2 image := 0 (both pieces): the gradient cut of an in-place row overwrite
+// (tvl_rows_grad, zero_src) applied to the operand image that travels with the gradient, so the image need not be packed again
+__global__ __launch_bounds__(256) void h2_zero_rows_kernel(unsigned char* __restrict__ img, int K, int B, int T, int row0, int n) {
+    const int kb2 = K >> 3;                       // 16-byte units per row and piece
+    const long total = (long)B * n * kb2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int u = (int)(i % kb2);
+        const long rj = i / kb2;
+        const long m = (rj / n) * T + row0 + (rj % n);
+        unsigned char* o = img + ((m >> 5) * (K >> 4) + (u >> 1)) * (long)BLK2 + (((u & 1) * 32 + (int)(m & 31)) * 16);
+        *reinterpret_cast<uint4*>(o) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(o + 1024) = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+extern "C" int tvl_h2_zero_rows(void* img, int32_t K, int32_t B, int32_t T, int32_t row0, int32_t n, tvlStream_t stream) {
+    TVL_REQUIRE(img && K > 0 && K % 16 == 0 && B > 0 && T > 0 && n > 0 && row0 >= 0 && row0 + n <= T, "tvl_h2_zero_rows: bad arguments (K=%d B=%d T=%d row0=%d n=%d)", K, B, T, row0, n);
+    const long total = (long)B * n * (K / 8);
+    long nb = (total + 255) / 256;
+    nb = nb > 4096 ? 4096 : nb;
+    hipLaunchKernelGGL(h2_zero_rows_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<unsigned char*>(img), K, B, T, row0, n);
+    TVL_LAUNCH_CHECK("tvl_h2_zero_rows");
+    return 0;
+}
+
 // max |x| over [rows, K] as the bit pattern of a non-negative float in bits[0] (4 bytes, zeroed here): the first half of the per-tensor
 // tvl_h2_pack, for producers that write their own h2 image (tvl_bilinear_up_h2)
 extern "C" int tvl_h2_absmax(const float* x, int64_t ldx, int64_t rows, int32_t K, void* bits, tvlStream_t stream) {

@@ -172,6 +172,7 @@ _SIGS = {
     "tvl_bilinear_up_fwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_bilinear_up_h2": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I],
     "tvl_h2_absmax": [_P, _L, _L, _I, _P],
+    "tvl_h2_zero_rows": [_P, _I, _I, _I, _I, _I],
     "tvl_bilinear_up_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_bicubic_ac_fwd": [_P, _P, _P, _F, _F, _I, _I, _I, _I, _I],
     "tvl_bicubic_ac_bwd": [_P, _F, _P, _I, _I, _I, _I, _I],
@@ -1106,6 +1107,13 @@ def rows_overwrite(x, src, src_bs: int, row0: int, n: int):
 def rows_grad(g, dst, row0: int, n: int, reduce_batch: bool, zero_src: bool, accumulate: bool = False):
     B, T, D = g.shape
     _call("tvl_rows_grad", _p(g), _p(dst), B, T, D, row0, n, int(reduce_batch), int(zero_src), int(accumulate))
+
+
+def h2_zero_rows(img: "H2", B: int, T: int, row0: int, n: int) -> None:
+    """Rows ``b*T + row0 .. + n - 1`` of the image := 0 (the image of a gradient whose rows were cut in place)."""
+    if img.rows != B * T:
+        raise RuntimeError(f"h2_zero_rows: image has {img.rows} rows, expected {B * T}")
+    _call("tvl_h2_zero_rows", img.buf.data_ptr(), img.cols, B, T, row0, n)
 
 
 def gather_rows(x, idx):
