@@ -548,7 +548,7 @@ extern "C" int tvl_attn_fwd(const tvlAttnFwdArgs* a, tvlStream_t stream) {
     TVL_REQUIRE(!a->causal || p.Tk == p.T, "tvl_attn_fwd: causal needs Tk == T");
     dim3 grid((a->T + 127) / 128, a->H, a->B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (a->dh == 64 && !a->causal && !a->key_mask && p.Tk == p.T && tvl_attn_mode_bf16s()) {
+    if ((a->dh == 64 || a->dh == 16) && !a->causal && !a->key_mask && p.Tk == p.T && tvl_attn_mode_bf16s()) {
         TVL_REQUIRE(tvl_attn_fwd_bf16s_impl(a, nullptr, s) == 0, "tvl_attn_fwd: split-bf16 launch failed");
         TVL_LAUNCH_CHECK("tvl_attn_fwd(bf16s)");
         return 0;
@@ -595,7 +595,7 @@ extern "C" int tvl_attn_bwd(const tvlAttnBwdArgs* a, tvlStream_t stream) {
                                                   a->delta, a->B, a->H, a->T));
         TVL_LAUNCH_CHECK("tvl_attn_bwd(delta)");
     }
-    if (a->dh == 64 && !a->causal && !a->key_mask && p.Tk == p.T && tvl_attn_mode_bf16s()) {
+    if ((a->dh == 64 || a->dh == 16) && !a->causal && !a->key_mask && p.Tk == p.T && tvl_attn_mode_bf16s()) {
         TVL_REQUIRE(tvl_attn_bwd_bf16s_impl(a, nullptr, nullptr, s) == 0, "tvl_attn_bwd: split-bf16 launch failed");
         TVL_LAUNCH_CHECK("tvl_attn_bwd(bf16s)");
         return 0;

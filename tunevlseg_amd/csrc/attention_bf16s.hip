@@ -20,10 +20,18 @@ namespace {
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
-constexpr int DH = 64;
-constexpr int LDKB = DH + 8;   // K rows: 144 B -> ds_read_b128 conflict free
-constexpr int LDVB = DH + 32;  // V rows: 192 B -> the 4 rows of a transposed-read block land on disjoint bank windows
+// DH = 64: the vision tower (fp32 operands: layers below the image-format threshold, CRIS).  DH = 16 (round 3): the CLIPSeg decoder's
+// 4 x 16 heads (reduce_dim 64) -- one k-step for S, half of each 32-row output block unused, still 18 MFMAs of 32 cycles per key tile
+// against 24 of 64 cycles on the fp32 MFMA the decoder ran on before.
 constexpr int S = 3;
+template <int DH> struct Geo {
+    static constexpr int LDKB = DH + 8;    // K rows: 144 B (DH = 64) -> ds_read_b128 conflict free
+    static constexpr int LDVB = DH + 32;   // V rows: 192 B (DH = 64) -> the 4 rows of a transposed-read block land on disjoint bank windows
+    static constexpr int KS = DH / 16;     // k-steps of a product that contracts over d
+    static constexpr int NDB = (DH + 31) / 32;   // 32-row blocks of an output whose rows are d
+    static constexpr int F4 = 32 * DH / 4;       // float4 of a [32][DH] tile
+    static constexpr int NLD = (F4 + 255) / 256; // ... per thread
+};
 
 struct Params {
     const float *q, *k, *v; long q_bs, k_bs, v_bs; int q_ts, k_ts, v_ts;
@@ -55,33 +63,41 @@ __device__ __forceinline__ bf16x8 frag_of(unsigned a, unsigned b, unsigned c, un
     return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d));
 }
 
-// stage a [32][64] fp32 tile (rows clamped to T-1) as three bf16 planes [3][32][LD]
-struct TileRegs { float4 v[2]; };
-__device__ __forceinline__ void tile_gload(TileRegs& s, const float* __restrict__ base, int ts, int row0, int T) {
+// stage a [32][DH] fp32 tile (rows clamped to T-1) as three bf16 planes [3][32][LD]
+template <int DH> struct TileRegs { float4 v[Geo<DH>::NLD]; };
+template <int DH>
+__device__ __forceinline__ void tile_gload(TileRegs<DH>& s, const float* __restrict__ base, int ts, int row0, int T) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < Geo<DH>::NLD; ++i) {
         const int idx = threadIdx.x + 256 * i;
-        int r = row0 + (idx >> 4);
-        r = r < T ? r : T - 1;
-        s.v[i] = *reinterpret_cast<const float4*>(base + (long)r * ts + 4 * (idx & 15));
+        if (idx < Geo<DH>::F4) {
+            int r = row0 + idx / (DH / 4);
+            r = r < T ? r : T - 1;
+            s.v[i] = *reinterpret_cast<const float4*>(base + (long)r * ts + 4 * (idx % (DH / 4)));
+        }
     }
 }
-template <int LD>
-__device__ __forceinline__ void tile_sstore(const TileRegs& s, __bf16* __restrict__ lds) {
+template <int DH, int LD>
+__device__ __forceinline__ void tile_sstore(const TileRegs<DH>& s, __bf16* __restrict__ lds) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < Geo<DH>::NLD; ++i) {
         const int idx = threadIdx.x + 256 * i;
-        float x[4] = {s.v[i].x, s.v[i].y, s.v[i].z, s.v[i].w};
-        unsigned p0[2], p1[2], p2[2];
-        split3<4>(x, p0, p1, p2);
-        const int off = (idx >> 4) * LD + 4 * (idx & 15);
-        *reinterpret_cast<uint2*>(&lds[off]) = make_uint2(p0[0], p0[1]);
-        *reinterpret_cast<uint2*>(&lds[32 * LD + off]) = make_uint2(p1[0], p1[1]);
-        *reinterpret_cast<uint2*>(&lds[64 * LD + off]) = make_uint2(p2[0], p2[1]);
+        if (idx < Geo<DH>::F4) {
+            float x[4] = {s.v[i].x, s.v[i].y, s.v[i].z, s.v[i].w};
+            unsigned p0[2], p1[2], p2[2];
+            split3<4>(x, p0, p1, p2);
+            const int off = (idx / (DH / 4)) * LD + 4 * (idx % (DH / 4));
+            *reinterpret_cast<uint2*>(&lds[off]) = make_uint2(p0[0], p0[1]);
+            *reinterpret_cast<uint2*>(&lds[32 * LD + off]) = make_uint2(p1[0], p1[1]);
+            *reinterpret_cast<uint2*>(&lds[64 * LD + off]) = make_uint2(p2[0], p2[1]);
+        }
     }
 }
 
+template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
+    constexpr int LDKB = Geo<DH>::LDKB, LDVB = Geo<DH>::LDVB, KS = Geo<DH>::KS, NDB = Geo<DH>::NDB;
+    (void)LDVB;
     constexpr int KSZ = S * 32 * LDKB, VSZ = S * 32 * LDVB;
     __shared__ __attribute__((aligned(16))) __bf16 Ks[2][KSZ];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[2][VSZ];
@@ -97,11 +113,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
     const float* vb = p.v + b * p.v_bs + head * DH;
 
     // Q fragments: 4 k16-steps x 3 planes, element j of half h = Q[q][16s + 8h + j], pre-scaled by scale*log2(e)
-    bf16x8 qf[4][S];
+    bf16x8 qf[KS][S];
     {
         const float sc = p.scale * LOG2E;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KS; ++s) {
             const float4 a = *reinterpret_cast<const float4*>(qb + (long)qrow * p.q_ts + 16 * s + 8 * h);
             const float4 c = *reinterpret_cast<const float4*>(qb + (long)qrow * p.q_ts + 16 * s + 8 * h + 4);
             float x[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, c.x * sc, c.y * sc, c.z * sc, c.w * sc};
@@ -113,9 +129,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
         }
     }
 
-    f32x16 acc_o[2];
+    f32x16 acc_o[NDB];
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
     float m_run = NEG_BIG, l_run = 0.f;
@@ -125,11 +141,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
     const int tr_row = li >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (li & 3);
 
     const int nkt = (T + 31) / 32;
-    TileRegs sk, sv;
+    TileRegs<DH> sk, sv;
     tile_gload(sk, kb, p.k_ts, 0, T);
     tile_gload(sv, vb, p.v_ts, 0, T);
-    tile_sstore<LDKB>(sk, Ks[0]);
-    tile_sstore<LDVB>(sv, Vs[0]);
+    tile_sstore<DH, LDKB>(sk, Ks[0]);
+    tile_sstore<DH, LDVB>(sv, Vs[0]);
     __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KS; ++s) {
             bf16x8 kf[S];
 #pragma unroll
             for (int pl = 0; pl < S; ++pl) kf[pl] = *reinterpret_cast<const bf16x8*>(&ks[(pl * 32 + l31) * LDKB + 16 * s + 8 * h]);
@@ -182,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
         split3<16>(pv, pp0, pp1, pp2);
         // ---- O^T += V^T . P^T ----
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < NDB; ++d) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
 #pragma unroll
@@ -207,8 +223,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
             }
         }
         if (kt + 1 < nkt) {
-            tile_sstore<LDKB>(sk, Ks[cur ^ 1]);
-            tile_sstore<LDVB>(sv, Vs[cur ^ 1]);
+            tile_sstore<DH, LDKB>(sk, Ks[cur ^ 1]);
+            tile_sstore<DH, LDVB>(sv, Vs[cur ^ 1]);
         }
         __syncthreads();
     }
@@ -218,11 +234,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
     if (qi < T) {
         const long m = (long)b * T + qi;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+        for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float v[4] = {acc_o[d][4 * g] * inv, acc_o[d][4 * g + 1] * inv, acc_o[d][4 * g + 2] * inv, acc_o[d][4 * g + 3] * inv};
                 const int col = head * DH + d * 32 + 8 * g + 4 * h;
+                if (d * 32 + 8 * g + 4 * h >= DH) continue;
                 if (p.o) *reinterpret_cast<float4*>(p.o + m * p.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
                 if (p.o_tp3) tp3::store4(p.o_tp3, p.o_kb, m, col, v);   // the two lane halves fill one 16-byte chunk per row
             }
@@ -256,6 +273,7 @@ __device__ __forceinline__ void row_frags(const float* __restrict__ src, float s
     out[2] = frag_of(p2[0], p2[1], p2[2], p2[3]);
 }
 // row fragments of k16-step s from an LDS tile [3][32][LDKB]
+template <int LDKB>
 __device__ __forceinline__ void lds_row_frags(const __bf16* __restrict__ t, int l31, int h, int s, bf16x8 (&out)[S]) {
 #pragma unroll
     for (int pl = 0; pl < S; ++pl) out[pl] = *reinterpret_cast<const bf16x8*>(&t[(pl * 32 + l31) * LDKB + 16 * s + 8 * h]);
@@ -280,7 +298,10 @@ __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[S], const bf16x8 (&b)[S
     return acc;
 }
 
+template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16s_kernel(BwdParams p) {
+    constexpr int LDKB = Geo<DH>::LDKB, LDVB = Geo<DH>::LDVB, KS = Geo<DH>::KS, NDB = Geo<DH>::NDB;
+    (void)LDVB;
     constexpr int TSZ = S * 32 * LDKB;
     __shared__ __attribute__((aligned(16))) __bf16 Ks[2][TSZ];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[2][TSZ];
@@ -296,9 +317,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16s_kernel(BwdParams p) 
     const float* vb = p.v + b * p.v_bs + head * DH;
     const float* dob = p.d_o + ((long)b * T) * p.ldo + head * DH;
 
-    bf16x8 qf[4][S], dof[4][S];
+    bf16x8 qf[KS][S], dof[KS][S];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
         row_frags(qb + (long)qrow * p.q_ts + 16 * s + 8 * h, p.scale * LOG2E, qf[s]);
         row_frags(dob + (long)qrow * p.ldo + 16 * s + 8 * h, 1.0f, dof[s]);
     }
@@ -306,20 +327,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16s_kernel(BwdParams p) 
     const float lse2 = p.lse[stat] * LOG2E;
     const float dl = p.delta[stat];
 
-    f32x16 acc_dq[2];
+    f32x16 acc_dq[NDB];
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_dq[d][r] = 0.f;
     const int li = lane & 15;
     const int tr_row = li >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (li & 3);
 
     const int nkt = (T + 31) / 32;
-    TileRegs sk, sv;
+    TileRegs<DH> sk, sv;
     tile_gload(sk, kb, p.k_ts, 0, T);
     tile_gload(sv, vb, p.v_ts, 0, T);
-    tile_sstore<LDKB>(sk, Ks[0]);
-    tile_sstore<LDKB>(sv, Vs[0]);
+    tile_sstore<DH, LDKB>(sk, Ks[0]);
+    tile_sstore<DH, LDKB>(sv, Vs[0]);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
@@ -333,10 +354,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16s_kernel(BwdParams p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KS; ++s) {
             bf16x8 kf[S], vf[S];
-            lds_row_frags(ks, l31, h, s, kf);
-            lds_row_frags(vs, l31, h, s, vf);
+            lds_row_frags<LDKB>(ks, l31, h, s, kf);
+            lds_row_frags<LDKB>(vs, l31, h, s, vf);
             sc = mma6(kf, qf[s], sc);
             dp = mma6(vf, dof[s], dp);
         }
@@ -356,34 +377,38 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16s_kernel(BwdParams p) 
                                   frag_of(d1[4 * s2], d1[4 * s2 + 1], d1[4 * s2 + 2], d1[4 * s2 + 3]),
                                   frag_of(d2[4 * s2], d2[4 * s2 + 1], d2[4 * s2 + 2], d2[4 * s2 + 3])};
 #pragma unroll
-            for (int d = 0; d < 2; ++d) {
+            for (int d = 0; d < NDB; ++d) {
                 bf16x8 ktf[S];
                 lds_tr_frags<LDKB>(ks, tr_row, tr_col, h, s2, d, ktf);
                 acc_dq[d] = mma6(ktf, df, acc_dq[d]);
             }
         }
         if (kt + 1 < nkt) {
-            tile_sstore<LDKB>(sk, Ks[cur ^ 1]);
-            tile_sstore<LDKB>(sv, Vs[cur ^ 1]);
+            tile_sstore<DH, LDKB>(sk, Ks[cur ^ 1]);
+            tile_sstore<DH, LDKB>(sv, Vs[cur ^ 1]);
         }
         __syncthreads();
     }
     if (qi < T) {
         const long m = (long)b * T + qi;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+        for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float v[4] = {acc_dq[d][4 * g] * p.scale, acc_dq[d][4 * g + 1] * p.scale, acc_dq[d][4 * g + 2] * p.scale,
                                     acc_dq[d][4 * g + 3] * p.scale};
                 const int col = head * DH + d * 32 + 8 * g + 4 * h;
+                if (d * 32 + 8 * g + 4 * h >= DH) continue;
                 if (p.dq) *reinterpret_cast<float4*>(p.dq + b * p.dq_bs + (long)qi * p.dq_ts + col) = make_float4(v[0], v[1], v[2], v[3]);
                 if (p.g_tp3) tp3::store4(p.g_tp3, p.g_kb, m, col, v);
             }
     }
 }
 
+template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p) {
+    constexpr int LDKB = Geo<DH>::LDKB, LDVB = Geo<DH>::LDVB, KS = Geo<DH>::KS, NDB = Geo<DH>::NDB;
+    (void)LDVB;
     constexpr int TSZ = S * 32 * LDKB;
     __shared__ __attribute__((aligned(16))) __bf16 Qs[2][TSZ];
     __shared__ __attribute__((aligned(16))) __bf16 Ds[2][TSZ];
@@ -404,22 +429,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p
     const float* lseb = p.lse + ((long)b * p.H + head) * T;
     const float* delb = p.delta + ((long)b * p.H + head) * T;
 
-    bf16x8 kf[4][S], vf[4][S];
+    bf16x8 kf[KS][S], vf[KS][S];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
         row_frags(kb + (long)krow * p.k_ts + 16 * s + 8 * h, p.scale * LOG2E, kf[s]);
         row_frags(vb + (long)krow * p.v_ts + 16 * s + 8 * h, 1.0f, vf[s]);
     }
-    f32x16 acc_dk[2], acc_dv[2];
+    f32x16 acc_dk[NDB], acc_dv[NDB];
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc_dk[d][r] = 0.f; acc_dv[d][r] = 0.f; }
     const int li = lane & 15;
     const int tr_row = li >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (li & 3);
 
     const int nqt = (T + 31) / 32;
-    TileRegs sq, sd;
+    TileRegs<DH> sq, sd;
     float lse_reg = 0.f, del_reg = 0.f;
     auto gload = [&](int qt) {
         tile_gload(sq, qb, p.q_ts, qt * 32, T);
@@ -432,8 +457,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p
         }
     };
     auto sstore = [&](int buf) {
-        tile_sstore<LDKB>(sq, Qs[buf]);
-        tile_sstore<LDKB>(sd, Ds[buf]);
+        tile_sstore<DH, LDKB>(sq, Qs[buf]);
+        tile_sstore<DH, LDKB>(sd, Ds[buf]);
         if (threadIdx.x < 32) { lse_s[buf][threadIdx.x] = lse_reg; del_s[buf][threadIdx.x] = del_reg; }
     };
     gload(0);
@@ -448,10 +473,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KS; ++s) {
             bf16x8 qrf[S], drf[S];
-            lds_row_frags(qs, l31, h, s, qrf);
-            lds_row_frags(ds_t, l31, h, s, drf);
+            lds_row_frags<LDKB>(qs, l31, h, s, qrf);
+            lds_row_frags<LDKB>(ds_t, l31, h, s, drf);
             sc = mma6(qrf, kf[s], sc);
             dp = mma6(drf, vf[s], dp);
         }
@@ -479,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p
                                   frag_of(a1[4 * s2], a1[4 * s2 + 1], a1[4 * s2 + 2], a1[4 * s2 + 3]),
                                   frag_of(a2[4 * s2], a2[4 * s2 + 1], a2[4 * s2 + 2], a2[4 * s2 + 3])};
 #pragma unroll
-            for (int d = 0; d < 2; ++d) {
+            for (int d = 0; d < NDB; ++d) {
                 bf16x8 dtf[S];
                 lds_tr_frags<LDKB>(ds_t, tr_row, tr_col, h, s2, d, dtf);
                 acc_dv[d] = mma6(dtf, pf, acc_dv[d]);
@@ -492,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p
                                   frag_of(a1[4 * s2], a1[4 * s2 + 1], a1[4 * s2 + 2], a1[4 * s2 + 3]),
                                   frag_of(a2[4 * s2], a2[4 * s2 + 1], a2[4 * s2 + 2], a2[4 * s2 + 3])};
 #pragma unroll
-            for (int d = 0; d < 2; ++d) {
+            for (int d = 0; d < NDB; ++d) {
                 bf16x8 qtf[S];
                 lds_tr_frags<LDKB>(qs, tr_row, tr_col, h, s2, d, qtf);
                 acc_dk[d] = mma6(qtf, sf, acc_dk[d]);
@@ -505,10 +530,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p
         const long m = (long)b * T + ki;
         const int D = p.H * DH;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+        for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int col = head * DH + d * 32 + 8 * g + 4 * h;
+                if (d * 32 + 8 * g + 4 * h >= DH) continue;
                 const float vk[4] = {acc_dk[d][4 * g] * p.scale, acc_dk[d][4 * g + 1] * p.scale, acc_dk[d][4 * g + 2] * p.scale,
                                      acc_dk[d][4 * g + 3] * p.scale};
                 const float vv[4] = {acc_dv[d][4 * g], acc_dv[d][4 * g + 1], acc_dv[d][4 * g + 2], acc_dv[d][4 * g + 3]};
@@ -563,30 +589,38 @@ __global__ __launch_bounds__(256) void attn_delta_tp3_kernel(const unsigned char
 // internal entry (dispatched from tvl_attn_fwd): d_h = 64, no causal / key mask
 int tvl_attn_fwd_bf16s_impl(const tvlAttnFwdArgs* a, void* o_tp3, hipStream_t s) {
     Params p;
-    p.o_tp3 = reinterpret_cast<unsigned char*>(o_tp3); p.o_kb = a->H * DH / 16;
+    p.o_tp3 = reinterpret_cast<unsigned char*>(o_tp3); p.o_kb = a->H * a->dh / 16;
+    if (a->dh != 64 && (a->dh != 16 || o_tp3)) return 1;
     p.q = a->q; p.k = a->k; p.v = a->v; p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs;
     p.q_ts = a->q_ts; p.k_ts = a->k_ts; p.v_ts = a->v_ts; p.o = a->o; p.ldo = a->ldo; p.lse = a->lse;
     p.B = a->B; p.H = a->H; p.T = a->T; p.scale = a->scale;
     dim3 grid((a->T + 127) / 128, a->H, a->B);
-    hipLaunchKernelGGL(attn_fwd_bf16s_kernel, grid, dim3(256), 0, s, p);
+    if (a->dh == 64) hipLaunchKernelGGL(attn_fwd_bf16s_kernel<64>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_fwd_bf16s_kernel<16>, grid, dim3(256), 0, s, p);
     return 0;
 }
 
 // dQ + dK/dV kernels (delta is computed by the caller's pre-pass)
 int tvl_attn_bwd_bf16s_impl(const tvlAttnBwdArgs* a, const void* o_tp3, void* dqkv_tp3, hipStream_t s) {
     BwdParams p;
-    p.g_tp3 = reinterpret_cast<unsigned char*>(dqkv_tp3); p.g_kb = 3 * a->H * DH / 16;
+    p.g_tp3 = reinterpret_cast<unsigned char*>(dqkv_tp3); p.g_kb = 3 * a->H * a->dh / 16;
+    if (a->dh != 64 && (a->dh != 16 || o_tp3 || dqkv_tp3)) return 1;
     if (o_tp3) {  // delta from the tp3 image of O (the fp32 O was never written)
         const long items = (((long)a->B * a->T + 31) / 32) * a->H;
         hipLaunchKernelGGL(attn_delta_tp3_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const unsigned char*>(o_tp3),
-                           a->H * DH / 16, a->d_o, a->ldo, a->delta, a->B, a->H, a->T);
+                           a->H * 64 / 16, a->d_o, a->ldo, a->delta, a->B, a->H, a->T);
     }
     p.q = a->q; p.k = a->k; p.v = a->v; p.q_bs = a->q_bs; p.k_bs = a->k_bs; p.v_bs = a->v_bs;
     p.q_ts = a->q_ts; p.k_ts = a->k_ts; p.v_ts = a->v_ts; p.d_o = a->d_o; p.ldo = a->ldo; p.lse = a->lse; p.delta = a->delta;
     p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.dq_bs = a->dq_bs; p.dk_bs = a->dk_bs; p.dv_bs = a->dv_bs;
     p.dq_ts = a->dq_ts; p.dk_ts = a->dk_ts; p.dv_ts = a->dv_ts; p.B = a->B; p.H = a->H; p.T = a->T; p.scale = a->scale;
     dim3 grid((a->T + 127) / 128, a->H, a->B);
-    hipLaunchKernelGGL(attn_bwd_dq_bf16s_kernel, grid, dim3(256), 0, s, p);
-    hipLaunchKernelGGL(attn_bwd_dkdv_bf16s_kernel, grid, dim3(256), 0, s, p);
+    if (a->dh == 64) {
+        hipLaunchKernelGGL(attn_bwd_dq_bf16s_kernel<64>, grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(attn_bwd_dkdv_bf16s_kernel<64>, grid, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_bf16s_kernel<16>, grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(attn_bwd_dkdv_bf16s_kernel<16>, grid, dim3(256), 0, s, p);
+    }
     return 0;
 }
