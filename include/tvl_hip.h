@@ -28,7 +28,7 @@ typedef void* tvlStream_t; /* hipStream_t */
 
 /* Bumped on every incompatible change of a signature or struct below.  3: tvl_dicece_stats gained `work`, tvl_split_planes /
  * tvl_gemm_planes removed (round 2).  4: tvl_text_assemble gained `vocab` (rows of the embedding table: ids outside it give NaN rows
- * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  5: tvl_dicece_loss, tvl_mlp64_*, tvl_h2_zero_rows added;
+ * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  5: tvl_dicece_loss, tvl_mlp64_*, tvl_h2_zero_rows added; tvl_upconv_taps_fwd gained `work`;
  * tvl_layernorm_fwd_h2 / _bwd_h2 gained max_slot / tag (largest row norm by tagged atomicMax).  The Python binding refuses a library whose tvl_abi_version() differs. */
 #define TVL_ABI_VERSION 5
 
@@ -185,7 +185,7 @@ int tvl_pixel_unshuffle_bwd(const float* dlogits, float a, float* dcols, int32_t
  * taps[(b,i,j), ky*k+kx] = sum_c feat[b,i,j,c] * w[c,ky,kx]   ([B*G*G, ldg]); then
  *   out[b,y,x] = bias + sum_{ky,kx} bilinear(taps[b,:,:,ky,kx])(clamp(y+ky-pl), clamp(x+kx-pl))
  * so the C x (G*ps)^2 upsampled map is never materialised. k <= 7. */
-int tvl_upconv_taps_fwd(const float* taps, int32_t ldg, const float* bias, float* out,
+int tvl_upconv_taps_fwd(const float* taps, int32_t ldg, const float* bias, float* out, float* work /* B*G*k*G*ps floats: two separable passes; or null: one gathering pass */,
                         int32_t B, int32_t G, int32_t ps, int32_t k, tvlStream_t stream);
 /* dtaps [B*G*G, ldg] (first k*k columns written); work: [B*k*G*ps*G] floats */
 int tvl_upconv_taps_bwd(const float* dout, float* dtaps, int32_t ldg, float* work,

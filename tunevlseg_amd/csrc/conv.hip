@@ -49,18 +49,31 @@ __global__ void im2col3x3_kernel(const float* __restrict__ x, long sb, long sy, 
 }
 
 // ---- nn.AvgPool2d(k) -------------------------------------------------------------------------------------------------
-__global__ void avgpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int H, int W, int C, int k) {
-    const int Ho = H / k, Wo = W / k;
-    const long total = (long)B * Ho * Wo * C;
+// V = channels per thread (4: float4 over the channel dimension of the NHWC map; 1: any C / alignment)
+template <int V>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int H, int W, int C, int k) {
+    const int Ho = H / k, Wo = W / k, CV = C / V;
+    const long total = (long)B * Ho * Wo * CV;
     const float inv = 1.0f / (float)(k * k);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long r = i / C;
+        const int c = (int)(i % CV) * V;
+        const long r = i / CV;
         const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), b = (int)(r / ((long)Wo * Ho));
-        float acc = 0.f;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
         for (int dy = 0; dy < k; ++dy)
-            for (int dx = 0; dx < k; ++dx) acc += x[(((long)b * H + oy * k + dy) * W + ox * k + dx) * ldx + c];
-        y[r * ldy + c] = acc * inv;
+            for (int dx = 0; dx < k; ++dx) {
+                const float* src = x + (((long)b * H + oy * k + dy) * W + ox * k + dx) * ldx + c;
+                if constexpr (V == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src);
+                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                } else {
+                    acc[0] += src[0];
+                }
+            }
+        if constexpr (V == 4) *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+        else y[r * ldy + c] = acc[0] * inv;
     }
 }
 __global__ void avgpool_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx, int B, int H, int W, int C, int k) {
@@ -482,8 +495,12 @@ extern "C" int tvl_avgpool_fwd(const float* x, int32_t ldx, float* y, int32_t ld
     TVL_REQUIRE(x && y, "tvl_avgpool_fwd: null pointer");
     TVL_REQUIRE(B > 0 && C > 0 && k > 0 && H >= k && W >= k && H % k == 0 && W % k == 0, "tvl_avgpool_fwd: H=%d W=%d not divisible by k=%d", H, W, k);
     TVL_REQUIRE(ldx >= C && ldy >= C, "tvl_avgpool_fwd: leading dimension too small");
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(nblk((long)B * (H / k) * (W / k) * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, y,
-                       ldy, B, H, W, C, k);
+    if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && tvl_aligned16(x) && tvl_aligned16(y))
+        hipLaunchKernelGGL(avgpool_fwd_kernel<4>, dim3(nblk((long)B * (H / k) * (W / k) * (C / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, y,
+                           ldy, B, H, W, C, k);
+    else
+        hipLaunchKernelGGL(avgpool_fwd_kernel<1>, dim3(nblk((long)B * (H / k) * (W / k) * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, y,
+                           ldy, B, H, W, C, k);
     TVL_LAUNCH_CHECK("tvl_avgpool_fwd");
     return 0;
 }

@@ -61,6 +61,45 @@ __global__ __launch_bounds__(256) void upconv_fwd_kernel(const float* __restrict
     }
 }
 
+// The same sum in two separable passes (work != null): the x pass folds the k column taps and the bilinear x weights once per
+// (source row i, ky, x) -- B * G * k * S values -- and the y pass reads 2 k of them per output pixel, coalesced along x: 10 + 10 loads
+// per pixel row / pixel instead of 100 gathered loads per pixel (179 -> ~40 us at B = 32, 352^2).
+//   R[b][i][ky][x] = sum_kx sum_j wx(clamp(x + kx - pl), j) taps[b, i, j, ky * k + kx]
+__global__ __launch_bounds__(256) void upconv_fwd_x_kernel(const float* __restrict__ taps, int ldg, float* __restrict__ work, int B, int G, int ps, int k) {
+    const int S = G * ps;
+    const int pl = (k - 1) / 2;
+    const float inv_scale = 1.0f / (float)ps;
+    const long total = (long)B * G * k * S;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int x = (int)(idx % S), ky = (int)((idx / S) % k), i = (int)((idx / ((long)S * k)) % G), b = (int)(idx / ((long)S * k * G));
+        const float* tb = taps + ((long)b * G + i) * G * ldg + ky * k;
+        float acc = 0.f;
+        for (int kx = 0; kx < k; ++kx) {
+            const Lerp l = lerp_of(clampi(x + kx - pl, 0, S - 1), G, inv_scale);
+            acc += l.w0 * tb[(long)l.i0 * ldg + kx] + l.w1 * tb[(long)l.i1 * ldg + kx];
+        }
+        work[idx] = acc;
+    }
+}
+//   out[b][y][x] = bias + sum_ky sum_i wy(clamp(y + ky - pl), i) R[b][i][ky][x]
+__global__ __launch_bounds__(256) void upconv_fwd_y_kernel(const float* __restrict__ work, const float* __restrict__ bias, float* __restrict__ out,
+                                                           int B, int G, int ps, int k) {
+    const int S = G * ps;
+    const int pl = (k - 1) / 2;
+    const float inv_scale = 1.0f / (float)ps;
+    const long total = (long)B * S * S;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int x = (int)(idx % S), y = (int)((idx / S) % S), b = (int)(idx / ((long)S * S));
+        const float* wb = work + (long)b * G * k * S + x;
+        float acc = bias ? bias[0] : 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            const Lerp l = lerp_of(clampi(y + ky - pl, 0, S - 1), G, inv_scale);
+            acc += l.w0 * wb[((long)l.i0 * k + ky) * S] + l.w1 * wb[((long)l.i1 * k + ky) * S];
+        }
+        out[idx] = acc;
+    }
+}
+
 // weight that U-coordinate X (already clamped) puts on source cell j
 __device__ __forceinline__ float cell_weight(int X, int j, int G, float inv_scale) {
     const Lerp l = lerp_of(X, G, inv_scale);
@@ -103,14 +142,24 @@ __global__ __launch_bounds__(256) void upconv_bwd_y_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int tvl_upconv_taps_fwd(const float* taps, int32_t ldg, const float* bias, float* out, int32_t B, int32_t G, int32_t ps,
+extern "C" int tvl_upconv_taps_fwd(const float* taps, int32_t ldg, const float* bias, float* out, float* work, int32_t B, int32_t G, int32_t ps,
                                    int32_t k, tvlStream_t stream) {
     TVL_REQUIRE(taps && out && B > 0 && G > 0 && ps > 0, "tvl_upconv_taps_fwd: bad arguments");
     TVL_REQUIRE(k >= 1 && k <= KMAX && ldg >= k * k, "tvl_upconv_taps_fwd: kernel size %d unsupported (1..%d) or ldg too small", k, KMAX);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long total = (long)B * G * ps * G * ps;
     long grid = (total + 255) / 256;
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(upconv_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), taps, ldg, bias, out, B, G, ps, k);
+    if (work) {   // two separable passes through work [B, G, k, G * ps]
+        const long tx = (long)B * G * k * G * ps;
+        long gx = (tx + 255) / 256;
+        if (gx > 16384) gx = 16384;
+        hipLaunchKernelGGL(upconv_fwd_x_kernel, dim3((unsigned)gx), dim3(256), 0, s, taps, ldg, work, B, G, ps, k);
+        TVL_LAUNCH_CHECK("tvl_upconv_taps_fwd(x)");
+        hipLaunchKernelGGL(upconv_fwd_y_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const float*)work, bias, out, B, G, ps, k);
+    } else {
+        hipLaunchKernelGGL(upconv_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, s, taps, ldg, bias, out, B, G, ps, k);
+    }
     TVL_LAUNCH_CHECK("tvl_upconv_taps_fwd");
     return 0;
 }

@@ -118,7 +118,7 @@ _SIGS = {
     "tvl_film_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "tvl_pixel_shuffle_fwd": [_P, _P, _P, _F, _F, _P, _I, _I, _I],
     "tvl_pixel_unshuffle_bwd": [_P, _F, _P, _I, _I, _I],
-    "tvl_upconv_taps_fwd": [_P, _I, _P, _P, _I, _I, _I, _I],
+    "tvl_upconv_taps_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I],
     "tvl_upconv_taps_bwd": [_P, _P, _I, _P, _I, _I, _I, _I],
     "tvl_dicece_stats": [_P, _P, _P, _P, _P, _P, _I, _L, _F],
     "tvl_dicece_bwd": [_P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _P],
@@ -1161,7 +1161,8 @@ def pixel_unshuffle_bwd(dlogits, a: float, B: int, G: int, ps: int):
 
 def upconv_taps_fwd(taps, bias, B: int, G: int, ps: int, k: int):
     out = torch.empty((B, G * ps, G * ps), device=taps.device, dtype=torch.float32)
-    _call("tvl_upconv_taps_fwd", _p(taps), taps.shape[1], _p(bias), _p(out), B, G, ps, k)
+    work = torch.empty(B * G * k * G * ps, device=taps.device, dtype=torch.float32)   # x pass -> y pass
+    _call("tvl_upconv_taps_fwd", _p(taps), taps.shape[1], _p(bias), _p(out), _p(work), B, G, ps, k)
     return out
 
 
