@@ -536,7 +536,9 @@ extern "C" int tvl_attn_h2_fwd(const void* qkv_h2, const float* qkv_inv, void* o
     p.o_tp3 = reinterpret_cast<unsigned char*>(o_tp3); p.o_kb = H * DH / 16; p.o_h2 = o_as_h2; p.lse = lse;
     p.B = B; p.H = H; p.T = T; p.scale = scale;
     dim3 grid((unsigned)((T + 127) / 128 * H * B));
-    hipLaunchKernelGGL(attn_fwd_h2_kernel, grid, dim3(256), FWD_LDS, reinterpret_cast<hipStream_t>(stream), p);
+    // occupancy experiment knob: extra dynamic LDS (KiB, <= 64 KiB in total without an opt-in) lowers the workgroups per CU
+    static const int lds_pad_f = getenv("TVL_ATTN_LDS_PAD_KB") ? atoi(getenv("TVL_ATTN_LDS_PAD_KB")) * 1024 : 0;
+    hipLaunchKernelGGL(attn_fwd_h2_kernel, grid, dim3(256), FWD_LDS + lds_pad_f, reinterpret_cast<hipStream_t>(stream), p);
     TVL_LAUNCH_CHECK("tvl_attn_h2_fwd");
     return 0;
 }
@@ -561,8 +563,9 @@ extern "C" int tvl_attn_h2_bwd(const void* qkv_h2, const float* qkv_inv, const v
     p.g_h2 = g_as_h2; p.g_kscale = g_kscale;
     p.B = B; p.H = H; p.T = T; p.scale = scale;
     dim3 grid((unsigned)((T + 127) / 128 * H * B));
-    hipLaunchKernelGGL(attn_bwd_dq_h2_kernel, grid, dim3(256), BWD_LDS, s, p);      // writes delta and dnorm_max ...
-    hipLaunchKernelGGL(attn_bwd_dkdv_h2_kernel, grid, dim3(256), BWD_LDS, s, p);    // ... which this one reads (same stream)
+    static const int lds_pad_b = getenv("TVL_ATTN_LDS_PAD_KB") ? atoi(getenv("TVL_ATTN_LDS_PAD_KB")) * 1024 : 0;
+    hipLaunchKernelGGL(attn_bwd_dq_h2_kernel, grid, dim3(256), BWD_LDS + lds_pad_b, s, p);      // writes delta and dnorm_max ...
+    hipLaunchKernelGGL(attn_bwd_dkdv_h2_kernel, grid, dim3(256), BWD_LDS + lds_pad_b, s, p);    // ... which this one reads (same stream)
     TVL_LAUNCH_CHECK("tvl_attn_h2_bwd");
     return 0;
 }
