@@ -484,6 +484,12 @@ def main():
                                   intermediate_dim=64, use_proj_norm=True, use_lora_proj=False, norm_image_features=False,
                                   context_initializer="a photo of a", _init_ids=[320, 1125, 539, 320]), net_kw=base_new,
                   compact=True)
+    # ... and at the BASELINE batch itself, B = 32 (compact)
+    run_cris_case("cris_rn50_cocoop_n4_d1_newlast_b32", preset="rn50", wseed=41, learner_kind="cocoop", iseed=2, B=32, L=8,
+                  learner_kw=dict(prompt_depth=1, num_context=4, vector_std=0.02, use_unified_projection=False,
+                                  intermediate_dim=64, use_proj_norm=True, use_lora_proj=False, norm_image_features=False,
+                                  context_initializer="a photo of a", _init_ids=[320, 1125, 539, 320]), net_kw=base_new,
+                  compact=True)
 
 
 if __name__ == "__main__":
