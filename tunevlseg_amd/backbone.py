@@ -70,6 +70,7 @@ class CLIPSegBackbone(_Node):
             "position_ids", torch.arange(config.text_config.max_position_embeddings).expand((1, -1)), persistent=False)
         self._prep: dict[str, Any] | None = None
         self._prep_key = None
+        self._plist: list | None = None
         self._pos_cache: dict[tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ construction helpers
@@ -122,7 +123,10 @@ class CLIPSegBackbone(_Node):
     def prepared(self) -> dict[str, Any]:
         """Packed, device-resident views of the frozen weights; rebuilt if any parameter changed or moved."""
         dev = self.clip.logit_scale.device
-        key = (dev, sum(p._version for p in self.parameters()))
+        # (the flat parameter list is cached: walking the module tree for it cost ~1 ms per call, several calls per step)
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        key = (dev, sum(p._version for p in self._plist))
         if self._prep is None or self._prep_key != key:
             if any(p.requires_grad for n, p in self.named_parameters() if not n.startswith("decoder.transposed_convolution")):
                 raise NotImplementedError(
@@ -165,11 +169,13 @@ class CLIPSegBackbone(_Node):
 
     def _apply(self, fn, *a, **k):
         self._prep = None
+        self._plist = None
         self._pos_cache = {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._prep = None
+        self._plist = None
         self._pos_cache = {}
         return super().load_state_dict(*a, **k)
 

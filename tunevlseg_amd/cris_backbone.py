@@ -90,6 +90,7 @@ class CRISWeights(_Node):
         self.proj.in_dim = config.vis_dim // 2
         self._prep: dict[str, Any] | None = None
         self._prep_key = None
+        self._plist: list | None = None   # flat parameter list (walking the module tree per prepared() call cost ~1 ms)
         self._const: dict[tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ construction
@@ -159,7 +160,9 @@ class CRISWeights(_Node):
         dev = self.backbone.logit_scale.device
         # the projector head may train (no_freeze_last_layer, coop_cris.py:88-94): the net reads those four tensors from the parameter
         # tree, so they neither invalidate nor enter the prepared matrices
-        key = (dev, sum(p._version for p in self.parameters() if not p.requires_grad))
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        key = (dev, sum(p._version for p in self._plist if not p.requires_grad))
         if self._prep is not None and self._prep_key == key:
             return self._prep
         loose = [n for n, p in self.named_parameters() if p.requires_grad and n not in TRAINABLE_HEAD]
@@ -320,11 +323,13 @@ class CRISWeights(_Node):
 
     def _apply(self, fn, *a, **k):
         self._prep = None
+        self._plist = None
         self._const = {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._prep = None
+        self._plist = None
         self._const = {}
         return super().load_state_dict(*a, **k)
 

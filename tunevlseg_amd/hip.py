@@ -236,12 +236,17 @@ def const_i32(values, device) -> torch.Tensor:
     return t
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the current stream's handle without building a Stream object
+
+
 def _stream():
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
 def _call(name: str, *args):
-    lib = load()
+    lib = _lib if _lib is not None else load()
     rc = getattr(lib, name)(*args, _stream())
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.tvl_last_error().decode()}")
