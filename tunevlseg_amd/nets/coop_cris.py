@@ -155,7 +155,7 @@ class COOPCRIS(nn.Module):
         n, depth = learner.num_context, learner.prompt_depth
         tmap_list = learner.splice_map(L, self.max_length)
         T = len(tmap_list)
-        tmap = torch.tensor(tmap_list, dtype=torch.int32, device=dev)
+        tmap = hip.const_i32(tmap_list, dev)   # cached: a per-step torch.tensor(list, device=...) is a pageable copy the host blocks on
         ctx0 = learner.get_textual_context(image_features=image_features, index=0)
         x = ops.TextAssembleFn.apply(text.contiguous(), tmap, bb.token_embedding.weight.detach(), ctx0, bb.positional_embedding.detach(), n)
         key_mask = None
