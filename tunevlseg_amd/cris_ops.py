@@ -400,7 +400,7 @@ class MixFn(Fn):
     @staticmethod
     def forward(ctx, main, extra, ratio):
         main, extra = _c(main), _c(extra)
-        ratio = ratio.detach() if isinstance(ratio, torch.Tensor) else torch.tensor(float(ratio), device=main.device)
+        ratio = ratio.detach() if isinstance(ratio, torch.Tensor) else hip.const_f32(float(ratio), main.device)
         ctx.save_for_backward(main, extra, ratio)
         return hip.mix(main, extra, ratio)
 

@@ -239,6 +239,20 @@ def const_i32(values, device) -> torch.Tensor:
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the current stream's handle without building a Stream object
 
 
+_CONST_F32: dict = {}
+
+
+def const_f32(value: float, device) -> torch.Tensor:
+    """One-element device fp32 tensor of a host scalar, built once per (value, device) -- see const_i32."""
+    key = (float(value), str(device))
+    t = _CONST_F32.get(key)
+    if t is None:
+        if len(_CONST_F32) > 4096:
+            _CONST_F32.clear()
+        t = _CONST_F32[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+    return t
+
+
 def _stream():
     if _raw_stream is not None:
         return _raw_stream(torch.cuda.current_device())

@@ -562,7 +562,7 @@ class SegHeadFn(Fn):
             hip.gemm(hip.NN, Mrows, k * k, Cc, tok2d, Cc, w2, k * k, taps, k * k, a_map=amap)
             extra = hip.upconv_taps_fwd(taps, conv_b, B, G, ps, k)
         if mix == 2:
-            rdev = ratio.detach().to(torch.float32) if isinstance(ratio, torch.Tensor) else torch.tensor(float(ratio), device=tokens.device)
+            rdev = ratio.detach().to(torch.float32) if isinstance(ratio, torch.Tensor) else hip.const_f32(float(ratio), tokens.device)
             tconv = hip.pixel_shuffle_fwd(cols, bt, None, 1.0, 0.0, B, G, ps)
             logits = hip.mix(tconv, extra, rdev)
         else:

@@ -107,13 +107,16 @@ class Trainer:
     # ------------------------------------------------------------------ loops
     def _run_eval(self, module, loader: Iterable, stage: str) -> dict[str, float]:
         step = module.validation_step if stage == "val" else module.test_step
-        total, n = 0.0, 0
+        total_dev, n = None, 0
         with evaluation_mode(module):
             for i, batch in enumerate(loader):
                 loss = step(batch, i)
-                total += float(torch.nan_to_num(loss.detach(), nan=float("inf")).item()) * len(batch["image"])
+                # accumulated on the device: a .item() per batch would make the host wait for the GPU before it may enqueue the next batch
+                term = torch.nan_to_num(loss.detach().double(), nan=float("inf")) * len(batch["image"])
+                total_dev = term if total_dev is None else total_dev + term
                 n += len(batch["image"])
             out = module.epoch_metrics(stage)
+        total = float(total_dev.item()) if total_dev is not None else 0.0
         # every rank sees its own shard of the data: the scheduler, the early-stopping test and the logs must all read ONE number,
         # the sample-weighted mean over ranks (Lightning syncs the stopping decision; a rank-local loss desynchronises the LR)
         total, n = tdist.reduce_sums([total, float(n)])
@@ -133,7 +136,7 @@ class Trainer:
             if hasattr(train_loader, "set_epoch"):   # per-rank shard order and augmentation draws of this epoch (DistributedSampler.set_epoch)
                 train_loader.set_epoch(epoch)
             opt.zero_grad()
-            running, n_batches, pending = 0.0, 0, 0
+            running, n_batches, pending = None, 0, 0   # running: device-side sum of the step losses (no host synchronisation per step)
             n_train = len(train_loader) if hasattr(train_loader, "__len__") else None
             for i, batch in enumerate(train_loader):
                 boundary = (i + 1) % self.accumulate == 0 or (n_train is not None and i + 1 == n_train)
@@ -145,14 +148,14 @@ class Trainer:
                     opt.step()
                     opt.zero_grad()
                     pending = 0
-                running += float(loss.detach().item())
+                running = loss.detach().double() if running is None else running + loss.detach().double()
                 n_batches += 1
             if pending:  # loader without a length: the leftover micro-batches of the epoch still make a step
                 arm(True)
                 opt.step()
                 opt.zero_grad()
             metrics = module.epoch_metrics("train")
-            metrics["train_loss"] = running / max(n_batches, 1)
+            metrics["train_loss"] = (float(running.item()) if running is not None else 0.0) / max(n_batches, 1)
             stop = False
             if val_loader is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
                 metrics.update(self._run_eval(module, val_loader, "val"))
