@@ -183,12 +183,18 @@ class DeviceBatchPrep:
     def __init__(self, mean: Sequence[float], std: Sequence[float], device="cuda") -> None:
         self.mean, self.std, self.device = tuple(mean), tuple(std), torch.device(device)
 
+    def _h2d(self, t: torch.Tensor) -> torch.Tensor:
+        # pageable -> device copies are synchronous (the host waits for the stream to drain: the previous train step); pinned ones are not
+        if self.device.type == "cuda" and not t.is_cuda and not t.is_pinned():
+            t = t.pin_memory()
+        return t.to(self.device, non_blocking=True)
+
     def __call__(self, batch: Mapping[str, Any]) -> dict[str, Any]:
         out = dict(batch)
-        img = batch["image"].to(self.device, non_blocking=True)
-        msk = batch["mask"].to(self.device, non_blocking=True)
+        img = self._h2d(batch["image"])
+        msk = self._h2d(batch["mask"])
         out["image"] = hip.normalize_u8(img.contiguous(), self.mean, self.std)
         out["mask"] = hip.mask_u8(msk.contiguous())
         for k in ("input_ids", "attention_mask"):
-            out[k] = batch[k].to(self.device, non_blocking=True)
+            out[k] = self._h2d(batch[k])
         return out

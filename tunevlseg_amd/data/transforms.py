@@ -160,6 +160,15 @@ class DeviceTransform:
     def set_epoch(self, epoch: int, seed: int = 0, rank: int = 0) -> None:
         self.rng = np.random.default_rng([seed, rank, epoch])
 
+    @staticmethod
+    def _h2d(t: torch.Tensor, dev) -> torch.Tensor:
+        """Small host tensor -> device without stalling the host: from pageable memory the copy is synchronous, i.e. the host waits until
+        the stream has drained (the whole previous train step) and host enqueue stops overlapping GPU execution; from pinned memory it is
+        one more asynchronous operation in stream order."""
+        if torch.device(dev).type == "cuda" and not t.is_cuda and not t.is_pinned():
+            t = t.pin_memory()
+        return t.to(dev, non_blocking=True)
+
     def __call__(self, batch: Mapping[str, Any]) -> dict[str, Any]:
         out = {k: v for k, v in batch.items() if k not in ("image_bytes", "mask_bytes", "image_hw")}
         hw = batch["image_hw"]
@@ -168,10 +177,10 @@ class DeviceTransform:
         px = hw[:, 0].long() * hw[:, 1].long()
         m_offs = torch.cat([torch.zeros(1, dtype=torch.int64), px.cumsum(0)[:-1]])
         dev = self.device
-        img_b, msk_b = batch["image_bytes"].to(dev, non_blocking=True), batch["mask_bytes"].to(dev, non_blocking=True)
-        hw_d = hw.to(dev, non_blocking=True)
-        img = hip.resize_u8(img_b, (3 * m_offs).to(dev), hw_d, 3, H, W, hip.INTER_CUBIC)
-        msk = hip.resize_u8(msk_b, m_offs.to(dev), hw_d, 1, H, W, hip.INTER_NEAREST).view(B, H, W)
+        img_b, msk_b = self._h2d(batch["image_bytes"], dev), self._h2d(batch["mask_bytes"], dev)
+        hw_d = self._h2d(hw, dev)
+        img = hip.resize_u8(img_b, self._h2d(3 * m_offs, dev), hw_d, 3, H, W, hip.INTER_CUBIC)
+        msk = hip.resize_u8(msk_b, self._h2d(m_offs, dev), hw_d, 1, H, W, hip.INTER_NEAREST).view(B, H, W)
         params = np.zeros((B, 8), np.float32)
         params[:, [0, 4, 6]] = 1.0
         flags = np.zeros(B, np.int32)
@@ -184,8 +193,8 @@ class DeviceTransform:
                 params[b, 6], params[b, 7] = bc.sample(self.rng)
                 flags[b] |= 2
         nz = self.plan["normalize"]
-        image, mask = hip.augment_u8(img, msk, torch.from_numpy(params).to(dev), torch.from_numpy(flags).to(dev), nz.mean, nz.std)
+        image, mask = hip.augment_u8(img, msk, self._h2d(torch.from_numpy(params), dev), self._h2d(torch.from_numpy(flags), dev), nz.mean, nz.std)
         out["image"], out["mask"] = image, mask
         for k in ("input_ids", "attention_mask"):
-            out[k] = batch[k].to(dev, non_blocking=True)
+            out[k] = self._h2d(batch[k], dev)
         return out
