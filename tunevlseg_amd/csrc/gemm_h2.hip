@@ -251,7 +251,7 @@ static int h2_pack_impl(const float* x, int64_t ldx, const float* mask, int64_t 
         hipError_t e = hipMemsetAsync(work, 0, 4, s);
         TVL_REQUIRE(e == hipSuccess, "tvl_h2_pack: memset failed: %s", hipGetErrorString(e));
         long nb = (rows * (K / 4) + 1023) / 1024;
-        nb = nb > 4096 ? 4096 : nb;
+        nb = nb > 1024 ? 1024 : nb;   // (every workgroup ends in an atomicMax on ONE address: 4096 of them serialised for ~25 us)
         unsigned* bits = reinterpret_cast<unsigned*>(work);
         if (mask) hipLaunchKernelGGL(h2_absmax_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, bits, mask, (long)ldm);
         else hipLaunchKernelGGL(h2_absmax_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, bits, mask, (long)ldm);
@@ -297,7 +297,7 @@ extern "C" int tvl_h2_zero_rows(void* img, int32_t K, int32_t B, int32_t T, int3
     TVL_REQUIRE(img && K > 0 && K % 16 == 0 && B > 0 && T > 0 && n > 0 && row0 >= 0 && row0 + n <= T, "tvl_h2_zero_rows: bad arguments (K=%d B=%d T=%d row0=%d n=%d)", K, B, T, row0, n);
     const long total = (long)B * n * (K / 8);
     long nb = (total + 255) / 256;
-    nb = nb > 4096 ? 4096 : nb;
+    nb = nb > 1024 ? 1024 : nb;   // (every workgroup ends in an atomicMax on ONE address: 4096 of them serialised for ~25 us)
     hipLaunchKernelGGL(h2_zero_rows_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<unsigned char*>(img), K, B, T, row0, n);
     TVL_LAUNCH_CHECK("tvl_h2_zero_rows");
     return 0;
@@ -312,7 +312,7 @@ extern "C" int tvl_h2_absmax(const float* x, int64_t ldx, int64_t rows, int32_t 
     hipError_t e = hipMemsetAsync(bits, 0, 4, s);
     TVL_REQUIRE(e == hipSuccess, "tvl_h2_absmax: memset failed: %s", hipGetErrorString(e));
     long nb = (rows * (K / 4) + 1023) / 1024;
-    nb = nb > 4096 ? 4096 : nb;
+    nb = nb > 1024 ? 1024 : nb;   // (every workgroup ends in an atomicMax on ONE address: 4096 of them serialised for ~25 us)
     hipLaunchKernelGGL(h2_absmax_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, x, (long)ldx, (long)rows, K, reinterpret_cast<unsigned*>(bits), (const float*)nullptr, 0L);
     TVL_LAUNCH_CHECK("tvl_h2_absmax");
     return 0;
