@@ -140,7 +140,8 @@ class CLIPSegBackbone(_Node):
                 "decoder_layers": [self._layer_weights(l) for l in self.decoder.layers],
                 # the decoder's reduce Linears (768 -> 64) with their transposes: the data gradient into the tower runs as an NT GEMM
                 "reduces": [(r.weight.detach().contiguous(), r.bias.detach().contiguous(), r.weight.detach().t().contiguous()) for r in self.decoder.reduces],
-                "patch_w": v.embeddings.patch_embedding.weight.detach().reshape(self.config.vision_config.hidden_size, -1).contiguous(),
+                # (marked frozen: at M >= 2048 rows the patch GEMM packs its im2col rows and runs on two fp16 pieces, hip._gemm_takes_h2)
+                "patch_w": hip.mark_frozen(v.embeddings.patch_embedding.weight.detach().reshape(self.config.vision_config.hidden_size, -1).contiguous()),
                 "patch_size": ps,
             }
             self._prep_key = key
