@@ -365,8 +365,8 @@ def main():
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": (("f32 (fp32-equivalent: operands split into 2 fp16 pieces with exact power-of-two scales [3x3 convs with C_in % 32 == 0 and C_out >= 128, "
                        "Linears / 1x1 convs with N, K >= 256] or 3 bf16 pieces [the rest]; piece products exact on the 16-bit MFMA, fp32 accumulate)" if cris else
-                       "f32 (fp32-equivalent: operands split into 2 fp16 pieces with exact power-of-two scales [the 8 GEMMs and the attention of a vision layer] or "
-                       "3 bf16 pieces [text tower, decoder]; piece products exact on the 16-bit MFMA, fp32 accumulate)")
+                       "f32 (fp32-equivalent: operands split into 2 fp16 pieces with exact power-of-two scales [the 8 GEMMs and the attention of a vision layer, the decoder's "
+                       "feed-forward block] or 3 bf16 pieces [text tower, decoder attention and small GEMMs]; piece products exact on the 16-bit MFMA, fp32 accumulate)")
                       if hip.GEMM_MODE == "bf16x6" and hip.GEMM_H2 else MODE_DTYPE[hip.GEMM_MODE]),
             "gemm_mode": hip.GEMM_MODE,
             "data": "synthetic", "per_gpu": round(value / world, 2),
