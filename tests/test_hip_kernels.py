@@ -793,3 +793,18 @@ def test_mlp64_block_forward_and_backward_match_float64(hip, M, F):
     assert rel.max().item() < 2e-5, rel.max()   # row by row: small-gradient rows keep their own precision
     out_nostat, t2n, _, _ = H.mlp64_fwd(dev(x), w, dev(b1), dev(b2), dev(gamma), dev(beta), 1e-5, want_stats=False)
     assert t2n is None and torch.equal(out_nostat, out)
+
+
+def test_h2_zero_rows_cuts_the_image_like_the_matrix(hip):
+    """tvl_h2_zero_rows: rows b*T + row0 .. + n - 1 of an h2 image become exact zeros, every other row keeps both pieces."""
+    from tunevlseg_amd import hip as H
+
+    B, T, D, row0, n = 3, 45, 128, 41, 4
+    x = rnd(B * T, D, seed=77) * torch.logspace(-2, 2, B * T)[:, None]
+    img = H.h2_pack(dev(x), per_row=True)
+    before = img.float().clone()
+    H.h2_zero_rows(img, B, T, row0, n)
+    after = img.float()
+    want = before.clone().view(B, T, D)
+    want[:, row0:row0 + n] = 0
+    assert torch.equal(after, want.view(B * T, D))
