@@ -28,7 +28,7 @@ typedef void* tvlStream_t; /* hipStream_t */
 
 /* Bumped on every incompatible change of a signature or struct below.  3: tvl_dicece_stats gained `work`, tvl_split_planes /
  * tvl_gemm_planes removed (round 2).  4: tvl_text_assemble gained `vocab` (rows of the embedding table: ids outside it give NaN rows
- * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  5: tvl_dicece_loss, tvl_mlp64_*, tvl_h2_zero_rows added; tvl_upconv_taps_fwd gained `work`;
+ * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  5: tvl_dicece_loss, tvl_mlp64_*, tvl_h2_zero_rows added; tvl_upconv_taps_fwd gained `work`; tvl_attn_h2_bwd gained `only_block`, tvl_h2k_gather_rows added;
  * tvl_layernorm_fwd_h2 / _bwd_h2 gained max_slot / tag (largest row norm by tagged atomicMax).  The Python binding refuses a library whose tvl_abi_version() differs. */
 #define TVL_ABI_VERSION 5
 
@@ -380,7 +380,12 @@ int tvl_attn_h2_fwd(const void* qkv_h2, const float* qkv_inv, void* o_img, int32
                     float* lse, int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream);
 int tvl_attn_h2_bwd(const void* qkv_h2, const float* qkv_inv, const void* o_img, int32_t o_is_h2, const void* do_h2, const float* do_inv, const float* lse,
                     float* delta, void* dnorm_ws, void* dqkv_img, int32_t g_as_h2 /* h2 image + g_kscale [B*T, 3*H], else tp3 */, float* g_kscale,
-                    int32_t B, int32_t H, int32_t T, float scale, tvlStream_t stream);
+                    int32_t B, int32_t H, int32_t T, float scale,
+                    int32_t only_block /* -1: all rows; >= 0: dQ | dK | dV only for rows 128*only_block .. +127 of every sample (the other rows of the image stay
+                                          unwritten): the layer under the visual prompts needs the gradient of the prompt rows alone */,
+                    tvlStream_t stream);
+/* rows b*T + row0 .. + n - 1 (b < B) of such an h2 gradient image back to fp32: out [B*n, K] */
+int tvl_h2k_gather_rows(const void* img, const float* kscale, int32_t K, int32_t B, int32_t T, int32_t row0, int32_t n, float* out, tvlStream_t stream);
 /* LayerNorm forward / backward writing their result as an h2 operand (+ inv_scale[rows]); otherwise as tvl_layernorm_fwd_tp3 / _bwd_tp3.
  * max_slot (or null; needs row_norm): 8 bytes of device memory that receive max_m row_norm[m] without being cleared first -- every
  * workgroup does ONE atomicMax of (tag << 32 | float bits of its largest row norm) on the 64-bit word, so the value of the call with

@@ -711,6 +711,17 @@ def test_attention_on_h2_operands(hip, B, T, H):
     den = g2.abs().double().cpu() @ w.abs().double().cpu().T
     got = hip.gemm_h2_ks(gk, hip.weight_h2(w)).cpu().double()
     assert ((got - ref).abs() / (den + 1e-300)).max().item() < 5e-6
+    # one 128-row block only (the layer under the visual prompts): those rows are the full call's rows bit for bit, run after run
+    full = gk.float()
+    for blk in sorted({0, (T - 1) // 128}):
+        row0 = blk * 128
+        n = min(128, T - row0)
+        for _ in range(3):
+            part = hip.attn_h2_bwd(qh, o2, dh_, lse, B, T, H, dh**-0.5, out_h2=True, only_block=blk)
+            rows = hip.h2k_gather_rows(part, B, T, row0, n)
+            assert torch.equal(rows.view(B, n, 3 * D), full.view(B, T, 3 * D)[:, row0:row0 + n])
+    with pytest.raises(RuntimeError):
+        hip.attn_h2_bwd(qh, o2, dh_, lse, B, T, H, dh**-0.5, out_h2=True, only_block=(T + 127) // 128)
 
 
 def test_gemm_h2_persistent_tile_walk_equals_one_workgroup_per_tile(hip):

@@ -284,6 +284,8 @@ struct BwdP {
     unsigned char* g_img;          // image of dQ | dK | dV [B*T, 3*H*64]: tp3, or (g_h2 != 0) h2 with one scale per (row, 64-column block):
     int g_h2; float* g_kscale;     // g_kscale[m * 3H + part * H + head] = that block's inverse scale (exact: the writer holds the block)
     int B, H, T; float scale;
+    int only_blk;                  // >= 0: only the 128-row block `only_blk` of every sample gets its dQ / dK / dV (the caller needs no other rows: the
+                                   // first layer under the prompts); the dQ kernel's other workgroups still leave delta and the dO norms behind
 };
 
 constexpr int BWD_STAGE = 16 * PIECE + 256;   // two 8-piece tiles + 64 floats (log-sum-exp | delta of a query tile; dK/dV kernel only)
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_h2_kernel(BwdP p) {
         for (int o = 16; o > 0; o >>= 1) w = fmaxf(w, __shfl_xor(w, o, 64));
         if (lane == 0) atomicMax(p.dnorm_max + (long)b * p.H + head, __builtin_bit_cast(unsigned, w));
     }
+    if (p.only_blk >= 0 && qb != p.only_blk) return;   // (workgroup-uniform, before any barrier) delta and dnorm_max are all this block owed
     const float sc2 = p.scale * LOG2E * inv_q * inv_q;
     const float nlse2 = -p.lse[stat] * LOG2E;
     const float dp_unscale = inv_q * inv_do;
@@ -427,6 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_h2_kernel(BwdP p) {
     const int nkb = (T + 127) / 128;
     const int vid = xcd_vid();
     const int kblk = vid % nkb, head = (vid / nkb) % p.H, b = vid / (nkb * p.H);
+    if (p.only_blk >= 0 && kblk != p.only_blk) return;
     const int ki = kblk * 128 + wave * 32 + l31;
     const bool key_ok = ki < T;
     const long m_k = (long)b * T + (key_ok ? ki : T - 1);
@@ -521,7 +525,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_h2_kernel(BwdP p) {
     }
 }
 
+// rows b*T + row0 .. + n - 1 of the packed-gradient image (two fp16 pieces, one scale per (row, 64-column block)) back to fp32 [B*n, K]
+__global__ __launch_bounds__(256) void h2k_gather_rows_kernel(const unsigned char* __restrict__ img, const float* __restrict__ kscale, int K, int B, int T,
+                                                              int row0, int n, float* __restrict__ out) {
+    const int units = K >> 3;
+    const long total = (long)B * n * units;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int u = (int)(i % units);
+        const long rj = i / units;
+        const long m = (rj / n) * T + row0 + (rj % n);
+        const unsigned char* src = img + ((m >> 5) * (K >> 4) + (u >> 1)) * (long)BLK2 + (((u & 1) * 32 + (int)(m & 31)) * 16);
+        const f16x8 h0 = *reinterpret_cast<const f16x8*>(src), h1 = *reinterpret_cast<const f16x8*>(src + PIECE);
+        const float inv = kscale[m * (K >> 6) + (u >> 3)];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ((float)h0[e] + (float)h1[e]) * inv;
+        float* o = out + rj * K + u * 8;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 }  // namespace
+
+extern "C" int tvl_h2k_gather_rows(const void* img, const float* kscale, int32_t K, int32_t B, int32_t T, int32_t row0, int32_t n, float* out, tvlStream_t stream) {
+    TVL_REQUIRE(img && kscale && out && K > 0 && K % 64 == 0 && B > 0 && T > 0 && n > 0 && row0 >= 0 && row0 + n <= T, "tvl_h2k_gather_rows: bad arguments");
+    TVL_REQUIRE(tvl_aligned16(img) && tvl_aligned16(out), "tvl_h2k_gather_rows: operands must be 16-byte aligned");
+    const long total = (long)B * n * (K / 8);
+    long nb = (total + 255) / 256;
+    nb = nb > 4096 ? 4096 : nb;
+    hipLaunchKernelGGL(h2k_gather_rows_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned char*>(img), kscale,
+                       K, B, T, row0, n, out);
+    TVL_LAUNCH_CHECK("tvl_h2k_gather_rows");
+    return 0;
+}
 
 // O = softmax(Q K^T * scale) V on the h2 image of packed QKV (one tensor scale: qkv_inv[1]); O as a tp3 image or (o_as_h2 != 0) as an h2 image
 // that shares the QKV image's scale; lse [B, H, T].
@@ -547,7 +584,8 @@ extern "C" int tvl_attn_h2_fwd(const void* qkv_h2, const float* qkv_inv, void* o
 // block) in g_kscale [B*T, 3*H] (the A operand of tvl_gemm_h2_ks).  delta: [B, H, T] fp32 workspace; dnorm_ws: [B, H] 4-byte workspace.
 extern "C" int tvl_attn_h2_bwd(const void* qkv_h2, const float* qkv_inv, const void* o_tp3, int32_t o_is_h2, const void* do_h2, const float* do_inv, const float* lse,
                                float* delta, void* dnorm_ws, void* dqkv_tp3, int32_t g_as_h2, float* g_kscale, int32_t B, int32_t H, int32_t T, float scale,
-                               tvlStream_t stream) {
+                               int32_t only_block, tvlStream_t stream) {
+    TVL_REQUIRE(only_block < (T + 127) / 128, "tvl_attn_h2_bwd: only_block %d beyond the %d row blocks of a sample", only_block, (T + 127) / 128);
     TVL_REQUIRE(qkv_h2 && qkv_inv && o_tp3 && do_h2 && do_inv && lse && delta && dnorm_ws && dqkv_tp3, "tvl_attn_h2_bwd: null pointer");
     TVL_REQUIRE(B > 0 && H > 0 && T > 0 && scale > 0.f, "tvl_attn_h2_bwd: bad shape / scale");
     TVL_REQUIRE(tvl_aligned16(qkv_h2) && tvl_aligned16(o_tp3) && tvl_aligned16(do_h2) && tvl_aligned16(dqkv_tp3), "tvl_attn_h2_bwd: images must be 16-byte aligned");
@@ -556,7 +594,8 @@ extern "C" int tvl_attn_h2_bwd(const void* qkv_h2, const float* qkv_inv, const v
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(dnorm_ws, 0, sizeof(unsigned) * (size_t)B * H, s);
     TVL_REQUIRE(e == hipSuccess, "tvl_attn_h2_bwd: memset failed: %s", hipGetErrorString(e));
-    BwdP p;
+    BwdP p{};
+    p.only_blk = only_block < 0 ? -1 : only_block;
     p.qkv = reinterpret_cast<const unsigned char*>(qkv_h2); p.kb = 3 * H * DH / 16; p.qkv_inv = qkv_inv;
     p.o_img = reinterpret_cast<const unsigned char*>(o_tp3); p.o_h2 = o_is_h2; p.do_img = reinterpret_cast<const unsigned char*>(do_h2); p.o_kb = H * DH / 16; p.do_inv = do_inv;
     p.lse = lse; p.delta = delta; p.dnorm_max = reinterpret_cast<unsigned*>(dnorm_ws); p.g_img = reinterpret_cast<unsigned char*>(dqkv_tp3);

@@ -160,7 +160,8 @@ _SIGS = {
     "tvl_h2_pack_masked": [_P, _L, _P, _L, _L, _I, _P, _P, _P, _I, _P],
     "tvl_gemm_h2_out": [C.POINTER(GemmTp3Args), _P, _P, _P, _F, _F, _P, _I],
     "tvl_attn_h2_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _F],
-    "tvl_attn_h2_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _F],
+    "tvl_attn_h2_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _F, _I],
+    "tvl_h2k_gather_rows": [_P, _P, _I, _I, _I, _I, _I, _P],
     "tvl_gemm_h2_ks": [C.POINTER(GemmTp3Args), _P],
     "tvl_conv3x3_h2": [C.POINTER(GemmTp3Args), C.POINTER(ConvGeom), _P],
     "tvl_gemm_h2": [C.POINTER(GemmTp3Args), _P],
@@ -1038,9 +1039,10 @@ def gemm_h2_ks(A: H2K, B: H2, out: torch.Tensor | None = None) -> torch.Tensor:
     return Cf
 
 
-def attn_h2_bwd(qkv_h: H2, o_t, do_h: H2, lse, B: int, T: int, H: int, scale: float, out_h2: bool = False):
+def attn_h2_bwd(qkv_h: H2, o_t, do_h: H2, lse, B: int, T: int, H: int, scale: float, out_h2: bool = False, only_block: int = -1):
     """Backward of attn_h2_fwd: QKV and dO as tensor-scaled H2 images, O as Tp3 or as the H2 image the forward wrote; returns
-    dQ | dK | dV as a Tp3 image, or (out_h2) as an H2K image with exact per-(row, head) scales."""
+    dQ | dK | dV as a Tp3 image, or (out_h2) as an H2K image with exact per-(row, head) scales.  ``only_block`` >= 0: only rows
+    128 * only_block .. + 127 of every sample are computed (the rest of the image stays unwritten)."""
     D = H * 64
     if qkv_h.per_row or do_h.per_row or do_h.rows != B * T or do_h.cols != D:
         raise RuntimeError("attn_h2_bwd: QKV / dO must be tensor-scaled H2 images of [B*T, 3D] / [B*T, D]")
@@ -1053,8 +1055,31 @@ def attn_h2_bwd(qkv_h: H2, o_t, do_h: H2, lse, B: int, T: int, H: int, scale: fl
     with _aux_span("attn_h2_bwd", 10.0 * B * H * T * T * 64, 4.0 * B * T * D * (2 * 4 + 1 + 3)):
         _call("tvl_attn_h2_bwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o_t.buf.data_ptr(), 1 if isinstance(o_t, H2) else 0, do_h.buf.data_ptr(),
               _p(do_h.inv_scale), _p(lse),
-              _p(delta), dn.data_ptr(), g.buf.data_ptr(), 1 if out_h2 else 0, _p(g.kscale) if out_h2 else None, B, H, T, float(scale))
+              _p(delta), dn.data_ptr(), g.buf.data_ptr(), 1 if out_h2 else 0, _p(g.kscale) if out_h2 else None, B, H, T, float(scale), int(only_block))
     return g
+
+
+def h2k_gather_rows(g: "H2K", B: int, T: int, row0: int, n: int) -> torch.Tensor:
+    """Rows ``b*T + row0 .. + n - 1`` of an H2K gradient image as an fp32 matrix [B*n, cols]."""
+    if g.rows != B * T:
+        raise RuntimeError(f"h2k_gather_rows: image has {g.rows} rows, expected {B * T}")
+    out = torch.empty((B * n, g.cols), device=g.buf.device, dtype=torch.float32)
+    _call("tvl_h2k_gather_rows", g.buf.data_ptr(), _p(g.kscale), g.cols, B, T, row0, n, _p(out))
+    return out
+
+
+_CONST_I64: dict = {}
+
+
+def const_i64(values, device) -> torch.Tensor:
+    """int64 twin of const_i32 (torch index ops want int64)."""
+    key = (tuple(int(v) for v in values), str(device))
+    t = _CONST_I64.get(key)
+    if t is None:
+        if len(_CONST_I64) > 1024:
+            _CONST_I64.clear()
+        t = _CONST_I64[key] = torch.tensor(key[0], dtype=torch.int64, device=device)
+    return t
 
 
 def attn_bwd_packed_tp3(qkv, o_tp3: Tp3, d_o, lse, B: int, T: int, H: int, dh: int, scale: float) -> Tp3:
@@ -1195,6 +1220,7 @@ def upconv_taps_bwd(dout, B: int, G: int, ps: int, k: int):
 # --------------------------------------------------------------------------------------
 # loss / metrics / optimiser / misc
 # --------------------------------------------------------------------------------------
+GRAD_ROWS = os.environ.get("TVL_GRAD_ROWS", "1") != "0"   # first vision layer: input gradient for the prompt rows only (ops.EncoderLayerTp3Fn); 0 = all rows (A/B switch)
 MLP64 = os.environ.get("TVL_MLP64", "1") != "0"   # the decoder's feed-forward block as one kernel (csrc/mlp64.hip); 0 = op by op (A/B switch)
 
 

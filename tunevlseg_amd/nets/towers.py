@@ -114,8 +114,11 @@ def vision_tower(model: CLIPSegBackbone, pixel_values: torch.Tensor, learner=Non
     spec = ops.AttnSpec(v.num_attention_heads, _ACT[v.hidden_act], v.layer_norm_eps)
     max_idx = max(model.extract_layers)
     states = [x]
+    T_all = x.shape[1]
     for idx in range(1, v.num_hidden_layers + 1):
-        x = ops.encoder_layer(x, prep["vision_layers"][idx - 1], spec)
+        # the first layer's input is LayerNorm(frozen patches | CLS | positions, prompts): only the prompt rows (the last n) carry a gradient
+        first_rows = (T_all - learner.num_context, learner.num_context) if (idx == 1 and prompts is not None) else None
+        x = ops.encoder_layer(x, prep["vision_layers"][idx - 1], spec, first_rows)
         if prompts is not None and idx < depth:
             if visual_contexts is not None:   # learner.mutate_image_hidden_states with the context computed ahead
                 x = ops.RowsOverwriteFn.apply(x, visual_contexts[idx], x.shape[1] - learner.num_context)

@@ -107,13 +107,14 @@ class EncoderLayerTp3Fn(Fn):
     only a GEMM would read."""
 
     @staticmethod
-    def forward(ctx, h, lw: LayerWeights, spec: AttnSpec):
+    def forward(ctx, h, lw: LayerWeights, spec: AttnSpec, grad_rows=None):
         h = _c(h)
         B, T, D = h.shape
         M = B * T
         H = spec.heads
         dh = D // H
         need = ctx.needs_input_grad[0]
+        ctx.grad_rows = grad_rows
         W = lw.tp3()
         h2d = h.view(M, D)
         # the GEMMs whose A operand a LayerNorm kernel writes run on two fp16 pieces (3 MFMAs per product instead of 6): that producer has
@@ -190,6 +191,28 @@ class EncoderLayerTp3Fn(Fn):
         dh2, dh2_t = ln_bwd(dx2, h2, lw.ln2_w, mean2, rstd2, dres=dout2d)
         del dx2
         o_t = hip.H2.wrap(M, D, o_buf, qkv_inv, per_row=False) if qkv_inv is not None else hip.Tp3(M, D, o_buf.device, o_buf)
+        rows = ctx.grad_rows
+        if rows is not None and not (qkv_inv is not None and hip.DQKV_H2 and hip.GRAD_ROWS and rows[1] > 0 and rows[0] // 128 == (rows[0] + rows[1] - 1) // 128):
+            rows = None
+        if rows is not None:
+            # Only rows [row0, row0 + n) of every sample of this layer's input gradient have a consumer (the first layer under the visual
+            # prompts: patches, CLS and positions are frozen).  Those rows need dQ, dK, dV of the prompt tokens only -- one 128-row block of
+            # the attention backward instead of four -- a [B*n, 3D] x [3D, D] data gradient instead of [M, 3D] x [3D, D], and n rows of
+            # LayerNorm backward per sample.  Everything above (MLP, LayerNorm 2, dO) is still needed for all rows: every query's dO
+            # reaches the prompt keys.  Same gradients, less dead work.
+            row0, n = rows
+            _, do = hip.gemm_h2(dh2_t, WL["wo_t"], want_f32=False, want_h2=True, out_per_tensor=True)
+            dqkv = hip.attn_h2_bwd(hip.H2.wrap(M, 3 * D, qkv, qkv_inv, per_row=False), o_t, do, lse, B, T, H, dh**-0.5, out_h2=True, only_block=row0 // 128)
+            del dh2_t, do
+            g_rows = hip.h2k_gather_rows(dqkv, B, T, row0, n)                      # [B*n, 3D] fp32
+            del dqkv
+            dx1_rows = hip.linear_dgrad(g_rows, lw.wqkv, Wt=lw.wqkv_t)              # [B*n, D]
+            ridx = hip.const_i64([b * T + row0 + j for b in range(B) for j in range(n)], h2d.device)
+            dh_rows = hip.layernorm_bwd(dx1_rows, h2d.index_select(0, ridx), lw.ln1_w, mean1.index_select(0, ridx), rstd1.index_select(0, ridx),
+                                        dres=dh2.index_select(0, ridx))
+            dh_in = torch.zeros((M, D), device=h2d.device, dtype=torch.float32)
+            dh_in.index_copy_(0, ridx, dh_rows)
+            return dh_in.view(B, T, D), None, None, None
         if qkv_inv is not None:   # the forward ran the attention on two fp16 pieces: dO as a one-scale h2 image too
             _, do = hip.gemm_h2(dh2_t, WL["wo_t"], want_f32=False, want_h2=True, out_per_tensor=True)
             dqkv = hip.attn_h2_bwd(hip.H2.wrap(M, 3 * D, qkv, qkv_inv, per_row=False), o_t, do, lse, B, T, H, dh**-0.5, out_h2=hip.DQKV_H2)
@@ -208,14 +231,15 @@ class EncoderLayerTp3Fn(Fn):
         dh_in, dh_in_t = ln_bwd(dx1, h2d, lw.ln1_w, mean1, rstd1, dres=dh2)
         g = dh_in.view(B, T, D)
         g._tvl_tp3 = ((g.data_ptr(), g._version, g.numel()), dh_in_t)  # the layer below starts its backward with a tp3 GEMM on this
-        return g, None, None
+        return g, None, None, None
 
 
-def encoder_layer(h, lw: LayerWeights, spec: AttnSpec):
-    """One pre-LN encoder layer; picks the tp3 kernels when the shape qualifies."""
+def encoder_layer(h, lw: LayerWeights, spec: AttnSpec, grad_rows=None):
+    """One pre-LN encoder layer; picks the tp3 kernels when the shape qualifies.  ``grad_rows`` = (row0, n): the caller guarantees that
+    only rows [row0, row0 + n) of every sample of ``h`` have a gradient consumer (see EncoderLayerTp3Fn.backward)."""
     B, T, D = h.shape
     if hip.tp3_path_ok(B * T, D, lw.w1.shape[0], D // spec.heads, spec.causal, spec.key_mask):
-        return EncoderLayerTp3Fn.apply(h, lw, spec)
+        return EncoderLayerTp3Fn.apply(h, lw, spec, grad_rows)
     return EncoderLayerFn.apply(h, lw, spec)
 
 
