@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="forward + backward of the step replayed as a hipGraph (tunevlseg_amd/graph.py); opt-in: the eager step is what the default line measures")
     ap.add_argument("--cond-cache", action="store_true",
                     help="vpt only: keep the frozen text tower's conditional embeddings per distinct token row (skips work: NOT the headline number; "
                          "the line is marked cond_cache=true)")
@@ -232,6 +234,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     hip.load()
+    if args.graph:
+        from tunevlseg_amd.graph import GraphedStep, use_private_stream
+
+        use_private_stream(device)   # before the parameters exist
 
     cris, maple, vit640 = args.workload == "cris", args.workload == "maple", args.workload == "vit640"
     if vit640:
@@ -266,10 +272,19 @@ def main():
         batch = make_batch(args.batch, 416 if cris else 352, 100 + rank, device, pad_id=0 if cris else 1)
         gflop_per_image = 212.8 if cris else (167.8 if maple else GFLOP_PER_IMAGE_TRAIN)  # SURVEY.md §8d (FlopCounterMode on the reference)
 
-        def step():
+        stepper = GraphedStep(module, opt) if args.graph else None
+
+        def eager_step():
             opt.zero_grad()
             loss = module.training_step(batch, 0)
             loss.backward()
+            opt.step()
+            return loss
+
+        def step():
+            if stepper is None:
+                return eager_step()
+            loss = stepper(batch)
             opt.step()
             return loss
 
@@ -297,7 +312,7 @@ def main():
     # 2 extra, untimed steps.  achieved = algorithmic FLOPs (2*M*N*K per launch) / summed launch time.
     hip.gemm_profile_start()
     for _ in range(2):
-        step()
+        (step if (module is None or not args.graph) else eager_step)()   # per-launch events need the launches: the profiled steps run eagerly
     prof = hip.gemm_profile_stop()
     roofline = None
     if prof:
@@ -368,7 +383,7 @@ def main():
                        "f32 (fp32-equivalent: operands split into 2 fp16 pieces with exact power-of-two scales [the 8 GEMMs and the attention of a vision layer, the decoder's "
                        "feed-forward block] or 3 bf16 pieces [text tower, decoder attention and small GEMMs]; piece products exact on the 16-bit MFMA, fp32 accumulate)")
                       if hip.GEMM_MODE == "bf16x6" and hip.GEMM_H2 else MODE_DTYPE[hip.GEMM_MODE]),
-            "gemm_mode": hip.GEMM_MODE,
+            "gemm_mode": hip.GEMM_MODE, "step_graph": bool(args.graph and module is not None),
             "data": "synthetic", "per_gpu": round(value / world, 2),
             "config": {"workload": ("CRIS (CLIP-RN50 + cross-attn decoder) + CoCoOp meta-net, 416x416, bs=32/GPU (BASELINE configs[2])" if cris else
                                     "CLIPSeg ViT-B/16 + MaPLe (coupled V+L prompts, depth=9), 352x352, bs=32/GPU (BASELINE configs[3])" if maple else

@@ -1,0 +1,107 @@
+"""Forward + backward of a train step as a hipGraph (``torch.cuda.graph``): one graph launch instead of 340 (VPT) - 820 (CRIS) kernel launches.
+
+Opt-in (``bench.py --graph``, ``Trainer(graph_step=True)``): the step is GPU-bound on one device, the graph frees the host
+(CRIS: 33 -> 12 ms of Python per step) for the input pipeline and for eight ranks sharing one node's cores.
+
+What makes the capture legal (the two failed attempts of rounds 2 and 3 are in DESIGN.md §7):
+
+* every launch of the library goes to torch's current stream (``hip._stream``), side streams fork from and join it with events
+  (``nets.towers.SideStream``) -- all of it capturable as it stands;
+* the AccumulateGrad nodes of the flat parameter views are created when the optimiser registers its gradient-exchange hooks, and autograd
+  runs each node on the stream that was current THEN.  Built on the default stream, they drag the default stream into the capture, nothing
+  joins it back and ``hipStreamEndCapture`` dies.  Hence :func:`use_private_stream` -- call it before building the module and the optimiser;
+  :class:`GraphedStep` refuses to capture on the default stream;
+* the optimiser update stays outside the graph (its bias correction takes the step count as a launch argument), so does the gradient
+  exchange of a multi-GPU job (``opt.step()`` launches the buckets the disarmed hooks did not);
+* the slot pool of the tagged ``atomicMax`` hand-over (``hip._max_slot``) is cleared inside the captured region: a replay re-uses the slots
+  and tags of the capture.
+"""
+from __future__ import annotations
+
+from typing import Any, Mapping
+
+import torch
+
+from . import hip
+
+
+def use_private_stream(device=None) -> "torch.cuda.Stream":
+    """Make a fresh non-default stream the current one for this thread (idempotent per call site: call once, before the module exists)."""
+    cur = torch.cuda.current_stream(device)
+    if cur != torch.cuda.default_stream(device):
+        return cur
+    s = torch.cuda.Stream(device)
+    s.wait_stream(cur)
+    torch.cuda.set_stream(s)
+    return s
+
+
+def _key(batch: Mapping[str, Any]):
+    return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if isinstance(v, torch.Tensor))
+
+
+class GraphedStep:
+    """``loss = stepper(batch)`` == ``opt.zero_grad(); loss = module.training_step(batch, 0); loss.backward()``; the caller then runs
+    ``opt.step()``.  The first batch of a shape runs eagerly (it fills the caches: position tables, constant index tensors, workspaces), the
+    second is captured, later ones copy their tensors into the captured step's inputs and replay.  Ragged text batches give several shapes:
+    at most ``max_graphs`` are kept (each holds a private pool with a step's activations); other shapes stay eager.
+    The returned loss of a replay is the captured step's output tensor: it is overwritten by the next replay (add it to a running sum, as
+    ``Trainer.fit`` does, before calling again)."""
+
+    def __init__(self, module, opt, max_graphs: int = 2):
+        self.module, self.opt, self.max_graphs = module, opt, max_graphs
+        self._seen: set = set()
+        self._graphs: dict = {}
+        self.replays = 0
+
+    def _eager(self, batch):
+        self.opt.zero_grad()   # (an eager step keeps its backward-overlapped gradient exchange: the hooks are armed outside a capture)
+        loss = self.module.training_step(batch, 0)
+        loss.backward()
+        return loss
+
+    def __call__(self, batch: Mapping[str, Any]):
+        key = _key(batch)
+        entry = self._graphs.get(key)
+        if entry is None:
+            if key not in self._seen or len(self._graphs) >= self.max_graphs:
+                self._seen.add(key)
+                return self._eager(batch)
+            entry = self._graphs[key] = self._capture(batch)
+        g, static, loss, appended = entry
+        for k, v in static.items():
+            v.copy_(batch[k], non_blocking=True)
+        g.replay()
+        for metric, attr, tensors in appended:   # what the step's Python appended to the metric states (the batch's confusion counts): a copy per replay
+            getattr(metric, attr).extend(t.clone() for t in tensors)   # (looked up now: reset() installs a new list every epoch)
+        self.replays += 1
+        return loss
+
+    def _capture(self, batch):
+        dev = next(v for v in batch.values() if isinstance(v, torch.Tensor)).device
+        stream = torch.cuda.current_stream(dev)
+        if stream == torch.cuda.default_stream(dev):
+            raise RuntimeError("GraphedStep: the current stream is the default stream -- call tunevlseg_amd.graph.use_private_stream() before building "
+                               "the module and its optimiser (the AccumulateGrad nodes must live on the capture stream)")
+        static = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+        step_in = {**batch, **static}
+        # metric states are python lists of per-batch count tensors (task.DiceSamples / JaccardBinary): note what the captured step appends
+        lists = [(m, a) for m in getattr(self.module, "metrics", {}).values() for a, lst in vars(m).items() if isinstance(lst, list)]
+        before = [len(getattr(m, a)) for m, a in lists]
+        arm = getattr(self.opt, "set_exchange_armed", lambda armed: None)
+        arm(False)   # no collective inside the graph: opt.step() -> exchange.finish() launches every bucket after the replay
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                for pool in hip._MAX_SLOTS.values():
+                    pool[0].zero_()
+                loss = self._eager(step_in)
+        finally:
+            arm(True)
+        appended = []
+        for (m, a), n0 in zip(lists, before):   # the capture did not run: its appends come back per replay, as copies of the captured step's outputs
+            lst = getattr(m, a)
+            if len(lst) > n0:
+                appended.append((m, a, lst[n0:]))
+                del lst[n0:]
+        return g, static, loss, appended

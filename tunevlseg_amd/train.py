@@ -23,8 +23,12 @@ def train(cfg: dict[str, Any], train_loader=None, val_loader=None, test_loader=N
     device = torch.device("cuda", local_rank)
     if cfg.get("seed") is not None:
         torch.manual_seed(int(cfg["seed"]))  # L.seed_everything (src/train.py:67-68)
-    module = CL.instantiate(CL.select(cfg, "model")).to(device)
     tcfg = CL.resolve(cfg, cfg.get("trainer", {})) or {}
+    if tcfg.get("graph_step"):   # +trainer.graph_step=true: the capture stream must be current before the parameters exist (tunevlseg_amd/graph.py)
+        from .graph import use_private_stream
+
+        use_private_stream(device)
+    module = CL.instantiate(CL.select(cfg, "model")).to(device)
     trainer = Trainer(**{k: v for k, v in tcfg.items() if k != "_target_"},
                       default_root_dir=CL.resolve(cfg, cfg.get("paths", {}).get("output_dir")) if cfg.get("paths") else None)
     if train_loader is None:

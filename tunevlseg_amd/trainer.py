@@ -37,9 +37,13 @@ def evaluation_mode(module: torch.nn.Module):
 class Trainer:
     def __init__(self, max_epochs: int = 10, min_epochs: int = 1, accumulate_grad_batches: int = 1, check_val_every_n_epoch: int = 1,
                  default_root_dir: str | None = None, early_stopping_patience: int | None = 12, early_stopping_min_delta: float = 1e-4,
-                 monitor: str = "val_dice", monitor_mode: str = "max", log_fn=print, **_ignored: Any) -> None:
+                 monitor: str = "val_dice", monitor_mode: str = "max", log_fn=print, graph_step: bool = False, **_ignored: Any) -> None:
         self.max_epochs, self.min_epochs = max_epochs, min_epochs
         self.accumulate = max(1, int(accumulate_grad_batches))
+        # forward + backward of a train step replayed as a hipGraph (tunevlseg_amd/graph.py; opt-in, +trainer.graph_step=true)
+        self.graph_step = bool(graph_step)
+        if self.graph_step and self.accumulate != 1:
+            raise ValueError("graph_step captures zero_grad + forward + backward as one unit: accumulate_grad_batches must be 1")
         self.check_val_every_n_epoch = check_val_every_n_epoch
         self.root = Path(default_root_dir) if default_root_dir else None
         # EarlyStopping(monitor=val_loss, patience=12, min_delta=1e-4, mode=min) -- configs/callbacks/default.yaml:17-21
@@ -132,6 +136,11 @@ class Trainer:
         if ckpt_path:
             start_epoch = self.load(module, ckpt_path, opt, sched)["epoch"] + 1
         arm = getattr(opt, "set_exchange_armed", lambda armed: None)
+        stepper = None
+        if self.graph_step:
+            from .graph import GraphedStep
+
+            stepper = GraphedStep(module, opt)
         for epoch in range(start_epoch, self.max_epochs):
             if hasattr(train_loader, "set_epoch"):   # per-rank shard order and augmentation draws of this epoch (DistributedSampler.set_epoch)
                 train_loader.set_epoch(epoch)
@@ -141,8 +150,11 @@ class Trainer:
             for i, batch in enumerate(train_loader):
                 boundary = (i + 1) % self.accumulate == 0 or (n_train is not None and i + 1 == n_train)
                 arm(boundary)  # the gradient all-reduce rides on the backward of the micro-step that ends in step()
-                loss = module.training_step(batch, i)
-                (loss / self.accumulate).backward()
+                if stepper is not None:
+                    loss = stepper(batch)   # zero_grad + forward + backward: eager the first time a shape is seen, a graph replay from its third batch on
+                else:
+                    loss = module.training_step(batch, i)
+                    (loss / self.accumulate).backward()
                 pending += 1
                 if boundary:
                     opt.step()
