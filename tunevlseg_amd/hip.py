@@ -1052,7 +1052,8 @@ def attn_h2_bwd(qkv_h: H2, o_t, do_h: H2, lse, B: int, T: int, H: int, scale: fl
     dn = torch.empty(B * H, device=dev, dtype=torch.int32)
     # 10 T^2 d_h FLOP per (b, h) (five products; the recomputed S of the second kernel is not counted); bytes: both kernels read QKV + dO,
     # the dQ one also O, together they write dQ | dK | dV
-    with _aux_span("attn_h2_bwd", 10.0 * B * H * T * T * 64, 4.0 * B * T * D * (2 * 4 + 1 + 3)):
+    part = min(128, T) / T if only_block >= 0 else 1.0   # one 128-row block of queries (dQ) and of keys (dK | dV) against all T of the other side
+    with _aux_span("attn_h2_bwd", 10.0 * B * H * T * T * 64 * part, 4.0 * B * T * D * (2 * 4 + 1 + 3)):
         _call("tvl_attn_h2_bwd", qkv_h.buf.data_ptr(), _p(qkv_h.inv_scale), o_t.buf.data_ptr(), 1 if isinstance(o_t, H2) else 0, do_h.buf.data_ptr(),
               _p(do_h.inv_scale), _p(lse),
               _p(delta), dn.data_ptr(), g.buf.data_ptr(), 1 if out_h2 else 0, _p(g.kscale) if out_h2 else None, B, H, T, float(scale), int(only_block))
