@@ -38,8 +38,9 @@ class BaseMultimodalCLIPSeg(BaseCLIPSeg):
                 learner = self.context_learner
                 vis = [learner.get_visual_context(index=i) for i in range(learner.prompt_depth)] if side.on else None
                 ready = side.mark()
-                conditional_embeddings = self.get_conditional_embeddings(pixel_values.shape[0], input_ids, attention_mask)
             activations = self.get_vision_outputs(pixel_values, vis, ready)
+            with side:   # the text tower: enqueued after the vision tower (whose kernels go first when the host is not ahead), replayed before it in the backward
+                conditional_embeddings = self.get_conditional_embeddings(pixel_values.shape[0], input_ids, attention_mask)
             side.join(conditional_embeddings)
             out = self.decoder_forward(activations, conditional_embeddings)
             out.conditional_embeddings = conditional_embeddings

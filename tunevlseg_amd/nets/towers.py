@@ -39,18 +39,25 @@ class SideStream:
     on the current one); ``s.join(y)`` makes the current stream wait for it and tells the allocator that ``y`` lives on.  The text tower
     (M = B * L rows: launch-latency-bound kernels on a fraction of the CUs) and the vision tower (chip-filling kernels with bubbles at
     every round's tail) share nothing until the decoder; autograd replays each node on its forward stream, so the backward overlaps too.
+    The fork point is where the object is CREATED: the side stream waits for what the current stream held then, not for what is enqueued
+    between creation and ``with`` -- so the caller may enqueue the vision tower first and the text tower after it (the big kernels start at
+    once when the host is not ahead of the GPU -- first step after a synchronisation, profiled runs, a busy host; and autograd, which
+    replays nodes in reverse creation order, then enqueues the text tower's backward BEFORE the vision tower's).  The block may be
+    entered more than once (MaPLe: prompt projections before the vision tower, text tower after it).
     No-op on CPU tensors or with TVL_TEXT_STREAM=0."""
 
     def __init__(self, device):
         self.on = TEXT_SIDE_STREAM and torch.device(device).type == "cuda"
         self.device = device
         self._ctx = None
-
-    def __enter__(self):
         if self.on:
             self.cur = torch.cuda.current_stream(self.device)
             self.side = side_stream(self.device)
-            self.side.wait_stream(self.cur)
+            self.fork = self.cur.record_event()
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_event(self.fork)
             self._ctx = torch.cuda.stream(self.side)
             self._ctx.__enter__()
         return self
@@ -58,6 +65,7 @@ class SideStream:
     def __exit__(self, *exc):
         if self._ctx is not None:
             self._ctx.__exit__(*exc)
+            self._ctx = None
         return False
 
     def join(self, *tensors):

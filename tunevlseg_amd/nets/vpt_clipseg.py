@@ -90,15 +90,16 @@ class VPTCLIPSeg(BaseCLIPSeg):
                 conditional_embeddings = self.cached_conditional_embeddings(input_ids, attention_mask)
             else:
                 # the frozen text tower (84 launch-latency-bound kernels at M = B * L rows, no gradient) shares nothing with the vision
-                # tower until the decoder's FiLM: it runs on a side stream, in the bubbles of the vision tower's chip-filling kernels
+                # tower until the decoder's FiLM: it runs on a side stream, in the bubbles of the vision tower's chip-filling kernels.
+                # Forked HERE, enqueued after the vision tower: the chip-filling kernels go first when the host is not ahead of the GPU
                 side = towers.SideStream(pixel_values.device)
-                with side, torch.no_grad():
-                    conditional_embeddings = towers.text_tower(self.model, input_ids, attention_mask)
         elif conditional_embeddings.shape[0] != pixel_values.shape[0]:
             raise ValueError("Make sure to pass as many conditional embeddings as there are query images in the batch")
         # step 2: vision tower with the visual prompts appended
         activations = self.get_vision_outputs(pixel_values)
         if side is not None:   # the decoder is the first consumer of the side stream's result
+            with side, torch.no_grad():
+                conditional_embeddings = towers.text_tower(self.model, input_ids, attention_mask)
             side.join(conditional_embeddings)
         # step 3: decoder
         out = self.decoder_forward(activations, conditional_embeddings)
