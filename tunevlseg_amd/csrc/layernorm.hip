@@ -187,7 +187,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // kernel ran at 8 waves per CU and a third of the HBM rate.
 // NP = 3: tp3 output (three bf16 pieces).  NP = 2: h2 output (two fp16 pieces of the row scaled by a power of two, tp3.h): phase 1 also
 // finds the row's largest |y| and writes the inverse scale to inv_scale[row] for the consuming GEMM's epilogue.
-template <int LN_MAXV, int NW, int NP = 3>
+// STAGE (NP = 2, cols <= 1024): phase 1 leaves the block's y rows in LDS (32 rows x (cols + 4) floats, dynamic) and phase 2 reads its fragments
+// from there instead of re-reading x through L2 in 32-byte pieces and recomputing y.
+extern __shared__ __attribute__((aligned(16))) float s_stage[];
+template <int LN_MAXV, int NW, int NP = 3, bool STAGE = false>
 __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, unsigned char* __restrict__ out,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows, int cols,
@@ -196,10 +199,13 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
     __shared__ float s_mean[32], s_rstd[32], s_scale[32], s_norm[32];
     __shared__ float4 s_gb[2][LN_MAXV * 64];   // gamma | beta for the second phase (every lane of a half-wave reads the same 32 bytes there)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long rb = blockIdx.x;
+    constexpr int ROWS = STAGE ? 16 : 32;            // staged: 16 rows per workgroup (three 49 KB workgroups per CU at 768 columns)
+    const long row0 = (long)blockIdx.x * ROWS;
+    const long rb = row0 >> 5;                       // 32-row block of the image
+    const int r_off = (int)(row0 & 31);
     const float inv_n = 1.0f / (float)cols;
     const int nv = cols >> 2;
-    constexpr int RPW = 32 / NW;   // rows per wave
+    constexpr int RPW = ROWS / NW;   // rows per wave
     for (int c = threadIdx.x; c < 2 * nv; c += 64 * NW)
         s_gb[c >= nv][c >= nv ? c - nv : c] = c < nv ? reinterpret_cast<const float4*>(gamma)[c]
                                                      : (beta ? reinterpret_cast<const float4*>(beta)[c - nv] : make_float4(0.f, 0.f, 0.f, 0.f));
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
     // per chunk made hipcc wait for each 16-byte load on its own -- eight HBM latencies in a row per wave, 31 us for a 97 MB pass).
     auto row_stats = [&](int rr) {
         const int rl = wave * RPW + rr;
-        const long row = rb * 32 + rl;
+        const long row = row0 + rl;
         const bool live_row = row < rows;   // wave-uniform
         const float4* xr = reinterpret_cast<const float4*>(x + (live_row ? row : rows - 1) * cols);
         float4 v[LN_MAXV];
@@ -242,6 +248,9 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
                 const float y2 = ln_y(v[i].z, mean, rstd, g4.z, b4.z), y3 = ln_y(v[i].w, mean, rstd, g4.w, b4.w);
                 amax = c < nv ? fmaxf(fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1))), fmaxf(fabsf(y2), fabsf(y3))) : amax;
                 ss += c < nv ? (y0 * y0 + y1 * y1) + (y2 * y2 + y3 * y3) : 0.f;
+                if constexpr (STAGE) {
+                    if (c < nv) *reinterpret_cast<float4*>(s_stage + rl * (cols + 4) + 4 * c) = make_float4(y0, y1, y2, y3);
+                }
             }
             amax = wave_max(amax);
             ss = wave_sum(ss);
@@ -267,37 +276,47 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
     __syncthreads();
     if constexpr (NP == 2) {   // largest row norm of the call: one tagged atomicMax per workgroup (include/tvl_hip.h)
         if (max_slot && wave == 0) {
-            const float m = wave_max(lane < 32 ? s_norm[lane] : 0.f);
+            const float m = wave_max(lane < ROWS ? s_norm[lane] : 0.f);
             if (lane == 0) atomicMax(max_slot, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(m));
         }
     }
-    const int r = lane & 31, h = lane >> 5;
-    const long row = rb * 32 + r;
+    const int r = lane & (ROWS - 1), h = (lane / ROWS) & 1, ks = lane / (2 * ROWS);   // ks: which of the wave's KPW k-blocks (ROWS = 16: two per pass)
+    constexpr int KPW = 32 / ROWS;
+    const long row = row0 + r;
     const bool live = row < rows;
     const float mean = s_mean[r], rstd = s_rstd[r];
     const int KB = cols >> 4;
     const float* xr = x + (live ? row : 0) * cols;
-    constexpr int NIT = (LN_MAXV * 16 + NW - 1) / NW;   // k-blocks of this wave (cols <= 256 LN_MAXV)
+    constexpr int NIT = (LN_MAXV * 16 + NW * KPW - 1) / (NW * KPW);   // passes of this wave over its k-blocks (cols <= 256 LN_MAXV)
     constexpr int GRP = NIT < 4 ? NIT : 4;
 #pragma unroll 1
-    for (int it0 = 0; it0 < NIT && wave + NW * it0 < KB; it0 += GRP) {
+    for (int it0 = 0; it0 < NIT && (wave + NW * it0) * KPW < KB; it0 += GRP) {
     float4 pa[GRP], pb[GRP];
 #pragma unroll
     for (int it = 0; it < GRP; ++it) {   // the rows of a group of the wave's blocks first (L2 hits: this workgroup has just read these rows)
-        const int kb = wave + NW * (it0 + it), c0 = (kb < KB ? kb : KB - 1) * 16 + h * 8;
-        pa[it] = *reinterpret_cast<const float4*>(xr + c0); pb[it] = *reinterpret_cast<const float4*>(xr + c0 + 4);
+        const int kb = (wave + NW * (it0 + it)) * KPW + ks, c0 = (kb < KB ? kb : KB - 1) * 16 + h * 8;
+        if constexpr (STAGE) {
+            pa[it] = *reinterpret_cast<const float4*>(s_stage + r * (cols + 4) + c0); pb[it] = *reinterpret_cast<const float4*>(s_stage + r * (cols + 4) + c0 + 4);
+        } else {
+            pa[it] = *reinterpret_cast<const float4*>(xr + c0); pb[it] = *reinterpret_cast<const float4*>(xr + c0 + 4);
+        }
     }
 #pragma unroll
     for (int it = 0; it < GRP; ++it) {
-        const int kb = wave + NW * (it0 + it);
-        if (kb >= KB) break;
+        const int kb = (wave + NW * (it0 + it)) * KPW + ks;
+        if ((wave + NW * (it0 + it)) * KPW >= KB) break;   // wave-uniform
+        if (kb >= KB) continue;                             // (ROWS = 16, odd number of k-blocks: the upper half-wave's last block)
         const int c4 = kb * 4 + h * 2;
         const float4 a = pa[it], b = pb[it], g0 = s_gb[0][c4], g1 = s_gb[0][c4 + 1], b0 = s_gb[1][c4], b1 = s_gb[1][c4 + 1];
         float v8[8];
+        if constexpr (STAGE) {   // the staged rows ARE y (the same ln_y values phase 1 took the row maximum of)
+            v8[0] = a.x; v8[1] = a.y; v8[2] = a.z; v8[3] = a.w; v8[4] = b.x; v8[5] = b.y; v8[6] = b.z; v8[7] = b.w;
+        } else {
         v8[0] = ln_y(a.x, mean, rstd, g0.x, b0.x); v8[1] = ln_y(a.y, mean, rstd, g0.y, b0.y);
         v8[2] = ln_y(a.z, mean, rstd, g0.z, b0.z); v8[3] = ln_y(a.w, mean, rstd, g0.w, b0.w);
         v8[4] = ln_y(b.x, mean, rstd, g1.x, b1.x); v8[5] = ln_y(b.y, mean, rstd, g1.y, b1.y);
         v8[6] = ln_y(b.z, mean, rstd, g1.z, b1.z); v8[7] = ln_y(b.w, mean, rstd, g1.w, b1.w);
+        }
         if (!live) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v8[e] = 0.f;
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
         if constexpr (NP == 3) {
             uint4 pl[3];
             tp3::split8(v8, pl);
-            unsigned char* o = out + (rb * KB + kb) * (long)tp3::BLK + lane * 16;
+            unsigned char* o = out + (rb * KB + kb) * (long)tp3::BLK + (h * 32 + r_off + r) * 16;
 #pragma unroll
             for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(o + s * tp3::PIECE) = pl[s];
         } else {
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
             for (int e = 0; e < 8; ++e) v8[e] *= sc;
             uint4 pl[2];
             h2::split8(v8, pl);
-            unsigned char* o = out + (rb * KB + kb) * (long)h2::BLK + lane * 16;
+            unsigned char* o = out + (rb * KB + kb) * (long)h2::BLK + (h * 32 + r_off + r) * 16;
             *reinterpret_cast<uint4*>(o) = pl[0];
             *reinterpret_cast<uint4*>(o + h2::PIECE) = pl[1];
         }
@@ -325,7 +344,7 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
 // LayerNorm backward (+ residual gradient) writing dx twice: fp32 (the residual stream's gradient, read by the next
 // LayerNorm backward) and tp3 (the A operand of the next data-gradient GEMM).  Phase 1 = ln_bwd_kernel's row pass; phase 2
 // re-reads the block's fresh dx rows (this CU's own stores, drained and fenced) in fragment order.
-template <int LN_MAXV, int NW, int NP = 3>
+template <int LN_MAXV, int NW, int NP = 3, bool STAGE = false>
 __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const float* __restrict__ dres, float* __restrict__ dx, unsigned char* __restrict__ out,
@@ -334,15 +353,18 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
     __shared__ float s_scale[32], s_norm[32];
     __shared__ float4 s_g[LN_MAXV * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long rb = blockIdx.x;
+    constexpr int ROWS = STAGE ? 16 : 32;            // staged: 16 rows per workgroup (three 49 KB workgroups per CU at 768 columns)
+    const long row0 = (long)blockIdx.x * ROWS;
+    const long rb = row0 >> 5;                       // 32-row block of the image
+    const int r_off = (int)(row0 & 31);
     const float inv_n = 1.0f / (float)cols;
     const int nv = cols >> 2;
-    constexpr int RPW = 32 / NW;
+    constexpr int RPW = ROWS / NW;
     for (int c = threadIdx.x; c < nv; c += 64 * NW) s_g[c] = reinterpret_cast<const float4*>(gamma)[c];
     __syncthreads();
     auto row_grad = [&](int rr) {
         const int rl = wave * RPW + rr;
-        const long row = rb * 32 + rl;
+        const long row = row0 + rl;
         const bool live_row = row < rows;   // wave-uniform
         const long rowc = live_row ? row : rows - 1;
         // all of the row's loads before the first use (see ln_fwd_tp3_kernel)
@@ -372,6 +394,9 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
             float4 o = ln_dx4(d[i], xv[i], m1, m2, rstd);
             if (dres) { o.x += r4[i].x; o.y += r4[i].y; o.z += r4[i].z; o.w += r4[i].w; }
             if (c < nv && live_row) reinterpret_cast<float4*>(dx + row * cols)[c] = o;
+            if constexpr (STAGE) {
+                if (c < nv) *reinterpret_cast<float4*>(s_stage + rl * (cols + 4) + 4 * c) = o;
+            }
             if constexpr (NP == 2) {
                 const bool in = c < nv;
                 amax = in ? fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w))) : amax;
@@ -401,36 +426,45 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
     }
     // the block's dx rows are re-read by other waves of this workgroup: drain the stores, then make them visible (the lines
     // were never in this CU's L1, but the order store -> load across waves still needs the fence + barrier)
-    __threadfence_block();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!STAGE) {   // (staged: phase 2 reads the rows from LDS -- nothing to drain, the fp32 stores leave in the background)
+        __threadfence_block();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     if constexpr (NP == 2) {
         if (max_slot && wave == 0) {
-            const float m = wave_max(lane < 32 ? s_norm[lane] : 0.f);
+            const float m = wave_max(lane < ROWS ? s_norm[lane] : 0.f);
             if (lane == 0) atomicMax(max_slot, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(m));
         }
     }
-    const int r = lane & 31, h = lane >> 5;
-    const long row = rb * 32 + r;
+    const int r = lane & (ROWS - 1), h = (lane / ROWS) & 1, ks = lane / (2 * ROWS);   // ks: which of the wave's KPW k-blocks (ROWS = 16: two per pass)
+    constexpr int KPW = 32 / ROWS;
+    const long row = row0 + r;
     const bool live = row < rows;
     const int KB = cols >> 4;
     const float* dxr = dx + (live ? row : 0) * cols;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    constexpr int NIT = (LN_MAXV * 16 + NW - 1) / NW;
+    constexpr int NIT = (LN_MAXV * 16 + NW * KPW - 1) / (NW * KPW);
     constexpr int GRP = NIT < 4 ? NIT : 4;
 #pragma unroll 1
-    for (int it0 = 0; it0 < NIT && wave + NW * it0 < KB; it0 += GRP) {
+    for (int it0 = 0; it0 < NIT && (wave + NW * it0) * KPW < KB; it0 += GRP) {
     f32x4 pa[GRP], pb[GRP];
 #pragma unroll
     for (int it = 0; it < GRP; ++it) {
-        const int kb = wave + NW * (it0 + it), c0 = (kb < KB ? kb : KB - 1) * 16 + h * 8;
-        pa[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dxr + c0));  // past this CU's L1
-        pb[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dxr + c0 + 4));
+        const int kb = (wave + NW * (it0 + it)) * KPW + ks, c0 = (kb < KB ? kb : KB - 1) * 16 + h * 8;
+        if constexpr (STAGE) {
+            pa[it] = *reinterpret_cast<const f32x4*>(s_stage + r * (cols + 4) + c0);
+            pb[it] = *reinterpret_cast<const f32x4*>(s_stage + r * (cols + 4) + c0 + 4);
+        } else {
+            pa[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dxr + c0));  // past this CU's L1
+            pb[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dxr + c0 + 4));
+        }
     }
 #pragma unroll
     for (int it = 0; it < GRP; ++it) {
-        const int kb = wave + NW * (it0 + it);
-        if (kb >= KB) break;
+        const int kb = (wave + NW * (it0 + it)) * KPW + ks;
+        if ((wave + NW * (it0 + it)) * KPW >= KB) break;   // wave-uniform
+        if (kb >= KB) continue;
         const f32x4 a = pa[it], b = pb[it];
         float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         if (!live) {
@@ -440,7 +474,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
         if constexpr (NP == 3) {
             uint4 pl[3];
             tp3::split8(v, pl);
-            unsigned char* o = out + (rb * KB + kb) * (long)tp3::BLK + lane * 16;
+            unsigned char* o = out + (rb * KB + kb) * (long)tp3::BLK + (h * 32 + r_off + r) * 16;
 #pragma unroll
             for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(o + s * tp3::PIECE) = pl[s];
         } else {
@@ -449,7 +483,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
             for (int e = 0; e < 8; ++e) v[e] *= sc;
             uint4 pl[2];
             h2::split8(v, pl);
-            unsigned char* o = out + (rb * KB + kb) * (long)h2::BLK + lane * 16;
+            unsigned char* o = out + (rb * KB + kb) * (long)h2::BLK + (h * 32 + r_off + r) * 16;
             *reinterpret_cast<uint4*>(o) = pl[0];
             *reinterpret_cast<uint4*>(o + h2::PIECE) = pl[1];
         }
@@ -530,7 +564,18 @@ extern "C" int tvl_layernorm_fwd_h2(const float* x, const float* gamma, const fl
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(y_h2);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm, slot, (unsigned)tag);
+    static const bool stage = !(getenv("TVL_LN_STAGE") && atoi(getenv("TVL_LN_STAGE")) == 0);
+    if (cols <= 1024 && stage) {
+        const size_t lds = 16 * (size_t)(cols + 4) * sizeof(float);   // 16 rows per workgroup of 8 waves
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_fwd_tp3_kernel<4, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (1024 + 4) * 4);
+        TVL_REQUIRE(attr == hipSuccess, "tvl_layernorm_fwd_h2: cannot reserve %zu bytes of LDS", lds);
+        hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 8, 2, true>), dim3(2 * grid) /* both halves of the last 32-row image block: rows past the end are written as zeros */, dim3(512), lds, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm, slot, (unsigned)tag);
+    } else if (stage) {   // wide rows: one 131 KB workgroup per CU
+        const size_t lds = 16 * (size_t)(cols + 4) * sizeof(float);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_fwd_tp3_kernel<8, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (2048 + 4) * 4);
+        TVL_REQUIRE(attr == hipSuccess, "tvl_layernorm_fwd_h2: cannot reserve %zu bytes of LDS", lds);
+        hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 8, 2, true>), dim3(2 * grid), dim3(512), lds, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm, slot, (unsigned)tag);
+    } else if (cols <= 1024) hipLaunchKernelGGL((ln_fwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm, slot, (unsigned)tag);
     else hipLaunchKernelGGL((ln_fwd_tp3_kernel<8, 8, 2>), dim3(grid), dim3(512), 0, s, x, gamma, beta, out, mean, rstd, (long)rows, cols, eps, inv_scale, row_norm, slot, (unsigned)tag);
     TVL_LAUNCH_CHECK("tvl_layernorm_fwd_h2");
     return 0;
@@ -548,7 +593,18 @@ extern "C" int tvl_layernorm_bwd_h2(const float* dy, const float* x, const float
     const unsigned grid = (unsigned)((rows + 31) / 32);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* out = reinterpret_cast<unsigned char*>(dx_h2);
-    if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm, slot, (unsigned)tag);
+    static const bool stage = !(getenv("TVL_LN_STAGE") && atoi(getenv("TVL_LN_STAGE")) == 0);
+    if (cols <= 1024 && stage) {
+        const size_t lds = 16 * (size_t)(cols + 4) * sizeof(float);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_tp3_kernel<4, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (1024 + 4) * 4);
+        TVL_REQUIRE(attr == hipSuccess, "tvl_layernorm_bwd_h2: cannot reserve %zu bytes of LDS", lds);
+        hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 8, 2, true>), dim3(2 * grid) /* both halves of the last 32-row image block: rows past the end are written as zeros */, dim3(512), lds, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm, slot, (unsigned)tag);
+    } else if (stage) {
+        const size_t lds = 16 * (size_t)(cols + 4) * sizeof(float);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_tp3_kernel<8, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (2048 + 4) * 4);
+        TVL_REQUIRE(attr == hipSuccess, "tvl_layernorm_bwd_h2: cannot reserve %zu bytes of LDS", lds);
+        hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 8, 2, true>), dim3(2 * grid), dim3(512), lds, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm, slot, (unsigned)tag);
+    } else if (cols <= 1024) hipLaunchKernelGGL((ln_bwd_tp3_kernel<4, 16, 2>), dim3(grid), dim3(1024), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm, slot, (unsigned)tag);
     else hipLaunchKernelGGL((ln_bwd_tp3_kernel<8, 8, 2>), dim3(grid), dim3(512), 0, s, dy, x, gamma, mean, rstd, dres, dx, out, (long)rows, cols, inv_scale, row_norm, slot, (unsigned)tag);
     TVL_LAUNCH_CHECK("tvl_layernorm_bwd_h2");
     return 0;
