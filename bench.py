@@ -310,9 +310,15 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events (on torch's current stream = the launch stream) around every GEMM launch of
     # 2 extra, untimed steps.  achieved = algorithmic FLOPs (2*M*N*K per launch) / summed launch time.
+    # The profiled steps run on ONE stream (text tower on the main stream): a launch's event pair then brackets that kernel alone -- with the side
+    # stream on, the events of the small text-tower GEMMs also count the time they wait for compute units the vision tower's kernels hold.
+    from tunevlseg_amd.nets import towers as _towers
+
+    side_was, _towers.TEXT_SIDE_STREAM = _towers.TEXT_SIDE_STREAM, False
     hip.gemm_profile_start()
     for _ in range(2):
         (step if (module is None or not args.graph) else eager_step)()   # per-launch events need the launches: the profiled steps run eagerly
+    _towers.TEXT_SIDE_STREAM = side_was
     prof = hip.gemm_profile_stop()
     roofline = None
     if prof:
