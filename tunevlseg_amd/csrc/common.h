@@ -35,10 +35,23 @@ int tvl_attn_mode_bf16s(void);
 static inline bool tvl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 __device__ __forceinline__ bool tvl_dev_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Wave-wide float reductions on the DPP path (v_add_f32_dpp ...: ~10 cycles a step) instead of __shfl_xor, which hipcc lowers to
+// ds_bpermute_b32 -- a trip through the LDS crossbar per step, six dependent trips per reduction, and a LayerNorm row needs four of them.
+// Steps: xor 1, xor 2 (quad_perm), i <-> 7 - i (row_half_mirror), i <-> 15 - i (row_mirror) leave every lane of a 16-lane row with the row's
+// total; row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 leave the wave's total in row 3; lane 63 hands it to everyone
+// through an SGPR.  A fixed association ((quads) halves) rows -- the same in every kernel that reduces a row, run to run.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<0xB1, 0xf>(0.f, v);    // quad_perm [1, 0, 3, 2]
+    v += dpp_f<0x4E, 0xf>(0.f, v);    // quad_perm [2, 3, 0, 1]
+    v += dpp_f<0x141, 0xf>(0.f, v);   // row_half_mirror
+    v += dpp_f<0x140, 0xf>(0.f, v);   // row_mirror
+    v += dpp_f<0x142, 0xa>(0.f, v);   // row_bcast:15 -> rows 1, 3
+    v += dpp_f<0x143, 0xc>(0.f, v);   // row_bcast:31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -50,10 +63,14 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+__device__ __forceinline__ float wave_max(float v) {   // (lanes a masked step does not reach take their own value: max(v, v) = v)
+    v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v));
+    v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v));
+    v = fmaxf(v, dpp_f<0x141, 0xf>(v, v));
+    v = fmaxf(v, dpp_f<0x140, 0xf>(v, v));
+    v = fmaxf(v, dpp_f<0x142, 0xa>(v, v));
+    v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float quick_gelu_f(float z) {

@@ -206,10 +206,23 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
     const float inv_n = 1.0f / (float)cols;
     const int nv = cols >> 2;
     constexpr int RPW = ROWS / NW;   // rows per wave
-    for (int c = threadIdx.x; c < 2 * nv; c += 64 * NW)
-        s_gb[c >= nv][c >= nv ? c - nv : c] = c < nv ? reinterpret_cast<const float4*>(gamma)[c]
-                                                     : (beta ? reinterpret_cast<const float4*>(beta)[c - nv] : make_float4(0.f, 0.f, 0.f, 0.f));
-    __syncthreads();   // gamma | beta staged
+    // gamma | beta: staged in LDS for phase 2 of the unstaged kernel (every lane of a half-wave reads the same 32 bytes there); the staged kernel
+    // needs them in phase 1 only, where a lane's columns are fixed: straight into registers, issued with the first row's loads -- no staging
+    // loop and no barrier in front of the rows (one memory latency less per workgroup)
+    float4 gq[STAGE ? LN_MAXV : 1], bq[STAGE ? LN_MAXV : 1];
+    if constexpr (STAGE) {
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i, cc = c < nv ? c : nv - 1;
+            gq[i] = reinterpret_cast<const float4*>(gamma)[cc];
+            bq[i] = beta ? reinterpret_cast<const float4*>(beta)[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+        for (int c = threadIdx.x; c < 2 * nv; c += 64 * NW)
+            s_gb[c >= nv][c >= nv ? c - nv : c] = c < nv ? reinterpret_cast<const float4*>(gamma)[c]
+                                                         : (beta ? reinterpret_cast<const float4*>(beta)[c - nv] : make_float4(0.f, 0.f, 0.f, 0.f));
+        __syncthreads();   // gamma | beta staged
+    }
     // Every load of a row is issued before the first use of any of them (clamped indices instead of branches around the loads: a branch
     // per chunk made hipcc wait for each 16-byte load on its own -- eight HBM latencies in a row per wave, 31 us for a 97 MB pass).
     auto row_stats = [&](int rr) {
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
 #pragma unroll
             for (int i = 0; i < LN_MAXV; ++i) {
                 const int c = lane + 64 * i, cc = c < nv ? c : nv - 1;
-                const float4 g4 = s_gb[0][cc], b4 = s_gb[1][cc];
+                const float4 g4 = STAGE ? gq[STAGE ? i : 0] : s_gb[0][cc], b4 = STAGE ? bq[STAGE ? i : 0] : s_gb[1][cc];
                 const float y0 = ln_y(v[i].x, mean, rstd, g4.x, b4.x), y1 = ln_y(v[i].y, mean, rstd, g4.y, b4.y);
                 const float y2 = ln_y(v[i].z, mean, rstd, g4.z, b4.z), y3 = ln_y(v[i].w, mean, rstd, g4.w, b4.w);
                 amax = c < nv ? fmaxf(fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1))), fmaxf(fabsf(y2), fabsf(y3))) : amax;
