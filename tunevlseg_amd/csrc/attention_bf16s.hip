@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
             sc[r] = v;
             mx = fmaxf(mx, v);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor32_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float pv[16];
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
         __syncthreads();
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xor32_sum(l_run);
     const float inv = 1.0f / l_tot;
     if (qi < T) {
         const long m = (long)b * T + qi;
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void attn_delta_tp3_kernel(const unsigned char
             acc += (ov[0] * a.x + ov[1] * a.y) + (ov[2] * a.z + ov[3] * a.w) + (ov[4] * c.x + ov[5] * c.y) + (ov[6] * c.z + ov[7] * c.w);
         }
     }
-    acc += __shfl_xor(acc, 32, 64);
+    acc = xor32_sum(acc);
     if (m < M && hh == 0) {
         const long bb = m / T, t = m % T;
         delta[(bb * H + head) * T + t] = acc;

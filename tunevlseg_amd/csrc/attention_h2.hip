@@ -122,7 +122,7 @@ __device__ __forceinline__ int xcd_vid() {
     const int total = (int)gridDim.x, L = (int)blockIdx.x, per = total / 8;
     return L < per * 8 ? (L % 8) * per + L / 8 : L;
 }
-__device__ __forceinline__ float half_sum(float x) { return x + __shfl_xor(x, 32, 64); }
+__device__ __forceinline__ float half_sum(float x) { return xor32_sum(x); }
 
 // A . B accumulated over the four 16-k steps of d_h = 64: A fragments double-buffered out of LDS (piece blocks BLK2 apart), B in registers
 __device__ __forceinline__ f32x16 mma_rows(unsigned a_rd, const f16x8 (&bq)[4][2]) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_h2_kernel(FwdP p) {
 #pragma unroll
         for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
         mx = fmaxf(mx, sc[15]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor32_max(mx);
         const bool grew = mx > m_run;
         if (__builtin_amdgcn_ballot_w64(grew)) {       // wave-uniform: some query of this wave has a new maximum
             const float m_new = fmaxf(m_run, mx);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_h2_kernel(FwdP p) {
     issue(0);
     for (int kt = 0; kt < nkt - 1; ++kt) tile(std::false_type{}, kt);
     tile(std::true_type{}, nkt - 1);
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xor32_sum(l_run);
     // P's scale and the softmax denominator; V's scale is undone for a tp3 image and KEPT for an h2 image: O is a convex combination of
     // V rows, so |O s| <= max |V s| < 2^14 -- the QKV image's scale is a valid scale for O as well
     const float inv = (p.o_h2 ? 1.0f : inv_q) * P_INV / l_tot;
@@ -299,7 +299,7 @@ __device__ __forceinline__ void store_block(const BwdP& p, long m, int col0, int
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(acc[d][r] * f));
-        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        amax = xor32_max(amax);
         const float inv = h2::inv_scale_of(amax);
         if (h == 0) p.g_kscale[m * (3L * p.H) + chunk] = inv;
         f *= 1.0f / inv;

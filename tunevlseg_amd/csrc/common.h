@@ -63,6 +63,12 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// x of lane i combined with x of lane i ^ 32.  (v_permlane32_swap would do it in one VALU instruction, but this hipcc returns the FIRST result of
+// __builtin_amdgcn_permlane32_swap for both elements -- measured on the device: both halves come back as the lower half's values -- so the
+// exchange stays on __shfl_xor = ds_bpermute_b32.)
+__device__ __forceinline__ float xor32_max(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
+__device__ __forceinline__ float xor32_sum(float x) { return x + __shfl_xor(x, 32, 64); }
+
 __device__ __forceinline__ float wave_max(float v) {   // (lanes a masked step does not reach take their own value: max(v, v) = v)
     v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v));
     v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v));

@@ -131,10 +131,7 @@ __global__ __launch_bounds__(256) void h2_rowpack_kernel(const float* __restrict
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { m[i] = fmaxf(m[i], __shfl_xor(m[i], o, 64)); ss[i] += __shfl_xor(ss[i], o, 64); }
-    }
+    for (int i = 0; i < 8; ++i) { m[i] = wave_max(m[i]); ss[i] = wave_sum(ss[i]); }   // DPP path (common.h): no LDS crossbar trips
     if (lane < 8 && row0 + lane < rows) {
         float mm = m[0], s2 = ss[0];
 #pragma unroll

@@ -85,8 +85,8 @@ __device__ __forceinline__ void row_amax_ss(const float (&v)[4][8], float& amax,
     for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { m = fmaxf(m, fabsf(v[s][j])); q += v[s][j] * v[s][j]; }
-    amax = fmaxf(m, __shfl_xor(m, 32, 64));
-    ss = q + __shfl_xor(q, 32, 64);
+    amax = xor32_max(m);
+    ss = xor32_sum(q);
 }
 
 __device__ __forceinline__ void to_frags(const float (&v)[4][8], float scale, f16x8 (&out)[4][2]) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void mlp64_fwd_kernel(Mlp64P p) {
         if (p.t2 && live) *reinterpret_cast<float4*>(p.t2 + row * 64 + c) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
         s1 += (t[4 * g] + t[4 * g + 1]) + (t[4 * g + 2] + t[4 * g + 3]);
     }
-    s1 += __shfl_xor(s1, 32, 64);
+    s1 = xor32_sum(s1);
     if (h == 0) stat[nb][cb][r] = s1;
     __syncthreads();
     const float mean = (stat[nb][0][r] + stat[nb][1][r]) * (1.0f / 64.0f);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void mlp64_fwd_kernel(Mlp64P p) {
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { const float d = t[i] - mean; q += d * d; }
-    q += __shfl_xor(q, 32, 64);
+    q = xor32_sum(q);
     if (h == 0) stat[nb][cb][r] = q;
     __syncthreads();
     const float rstd = rsqrtf((stat[nb][0][r] + stat[nb][1][r]) * (1.0f / 64.0f) + p.eps);
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(256) void mlp64_bwd_kernel(Mlp64P p) {
                 a2 += dy[s][j] * tt[s][j];
             }
         }
-        a1 += __shfl_xor(a1, 32, 64);
-        a2 += __shfl_xor(a2, 32, 64);
+        a1 = xor32_sum(a1);
+        a2 = xor32_sum(a2);
         m1[nb] = a1 * (1.0f / 64.0f);
         m2[nb] = a2 * (1.0f / 64.0f);
 #pragma unroll
