@@ -1,19 +1,27 @@
 #!/usr/bin/env python
-"""Timeline of the LAST train step inside a rocprofv3 --kernel-trace CSV (steps are delimited by the AdamW launch): per queue busy time,
+"""Timeline of one train step inside a rocprofv3 --kernel-trace CSV (steps are delimited by the AdamW launch): per queue busy time,
 union busy time, idle time, and one line per kernel (start offset us, duration us, queue, name).
 
-    python tools/timeline.py gpurun_out/<tag>/kernel_trace [out.txt]
+    python tools/timeline.py gpurun_out/<tag>/kernel_trace [out.txt] [--back N]
+
+--back N: the step N before the last one (default 0 = the last).  bench.py ends with two event-profiled steps that run on ONE stream
+(text tower on the main stream): --back 2 is the last TIMED step, with the side stream on.
 """
 import csv
 import glob
 import re
 import sys
 
+back = 0
+if "--back" in sys.argv:
+    k = sys.argv.index("--back")
+    back = int(sys.argv[k + 1])
+    del sys.argv[k:k + 2]
 f = glob.glob(f"{sys.argv[1]}/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
-a, b = idx[-2] + 1, idx[-1] + 1
+a, b = idx[-2 - back] + 1, idx[-1 - back] + 1
 step = rows[a:b]
 t0 = int(step[0]["Start_Timestamp"])
 t1 = max(int(r["End_Timestamp"]) for r in step)
