@@ -54,13 +54,15 @@ __global__ __launch_bounds__(256) void dicece_stats_kernel(const float* __restri
     }
 }
 
-__global__ void dicece_finish_kernel(const double* __restrict__ part, double* __restrict__ fsum, int B, int chunks) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (b, k)
-    if (i >= B * 4) return;
-    const int b = i >> 2, k = i & 3;
+// one wave per (sample, quantity): the chunks side by side on the lanes, then a fixed-order wave reduction (a thread per output walked up to 256
+// partial sums one dependent add after the other: 18.5 us for 128 outputs)
+__global__ __launch_bounds__(64) void dicece_finish_kernel(const double* __restrict__ part, double* __restrict__ fsum, int B, int chunks) {
+    const int i = blockIdx.x;  // (b, k)
+    const int b = i >> 2, k = i & 3, lane = threadIdx.x;
     double s = 0.0;
-    for (int c = 0; c < chunks; ++c) s += part[((long)b * chunks + c) * 4 + k];
-    fsum[i] = s;
+    for (int c = lane; c < chunks; c += 64) s += part[((long)b * chunks + c) * 4 + k];
+    s = wave_sum_d(s);
+    if (lane == 0) fsum[i] = s;
 }
 
 __global__ __launch_bounds__(256) void dicece_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ target,
@@ -127,7 +129,7 @@ extern "C" int tvl_dicece_stats(const float* logits, const float* target, double
     const long chunks = dicece_chunks((long)N);
     hipLaunchKernelGGL(dicece_stats_kernel, dim3((unsigned)chunks, B), dim3(256), 0, s, logits, target, work,
                        reinterpret_cast<long long*>(isum), label, (long)N, thr);
-    hipLaunchKernelGGL(dicece_finish_kernel, dim3((unsigned)((B * 4 + 63) / 64)), dim3(64), 0, s, (const double*)work, fsum, B, (int)chunks);
+    hipLaunchKernelGGL(dicece_finish_kernel, dim3((unsigned)(B * 4)), dim3(64), 0, s, (const double*)work, fsum, B, (int)chunks);
     TVL_LAUNCH_CHECK("tvl_dicece_stats");
     return 0;
 }
