@@ -204,3 +204,21 @@ def test_projection_plan_builds_reference_shaped_holders():
     torch.manual_seed(0)
     a = ProjectionPlan.mlp(64, 10, 256, False).build()
     assert abs(a[0].weight.std().item() - (2.0 / 64) ** 0.5) < 0.02  # kaiming_normal_(nonlinearity="relu"): std = sqrt(2 / fan_in)
+
+
+def test_graphed_step_keys_batches_by_tensor_shapes_only():
+    """tunevlseg_amd/graph.py: one captured graph per padded text length -- the key is (name, shape, dtype) of the tensors, nothing else."""
+    from tunevlseg_amd.graph import _key
+
+    def batch(L, extra=None):
+        b = {"image": torch.zeros(2, 3, 8, 8), "input_ids": torch.zeros(2, L, dtype=torch.long), "attention_mask": torch.ones(2, L, dtype=torch.long),
+             "mask": torch.zeros(2, 1, 8, 8)}
+        if extra is not None:
+            b["mask_name"] = extra
+        return b
+
+    assert _key(batch(6)) == _key(batch(6, extra=["a", "b"]))        # non-tensor entries do not count
+    assert _key(batch(6)) != _key(batch(7))                            # another padded length, another graph
+    other = batch(6)
+    other["image"] = other["image"].double()
+    assert _key(batch(6)) != _key(other)
