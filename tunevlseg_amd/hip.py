@@ -14,6 +14,23 @@ from pathlib import Path
 
 import torch
 
+if os.environ.get("TVL_POISON") == "1":
+    # Debug mode: every buffer this package asks torch for uninitialised comes back full of NaN patterns (fp32 NaN; bytes
+    # 0x7E = fp16 / bf16 NaN pairs in the operand images), so a kernel that reads a location its producer did not write shows up in the
+    # single-process parity suite instead of only when another process's leftovers happen to sit there.  `python -m pytest tests -m gpu` under it.
+    _torch_empty, _torch_empty_like = torch.empty, torch.empty_like
+
+    def _poisoned(t):
+        if t.is_cuda:
+            if t.dtype in (torch.float32, torch.float64, torch.float16, torch.bfloat16):
+                t.fill_(float("nan"))
+            elif t.dtype == torch.uint8:
+                t.fill_(0x7E)
+        return t
+
+    torch.empty = lambda *a, **k: _poisoned(_torch_empty(*a, **k))
+    torch.empty_like = lambda *a, **k: _poisoned(_torch_empty_like(*a, **k))
+
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["TVL_HIP_LIB"]) if os.environ.get("TVL_HIP_LIB") else _HERE / "csrc" / "libtvl_hip.so"   # (override: a `make DIAG=1` build for the tools)
 
