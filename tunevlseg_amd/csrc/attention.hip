@@ -71,6 +71,7 @@ __device__ __forceinline__ void tile_sstore(const TileRegs<DH>& s, float* __rest
 // ------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+    TVL_KERNEL_ENTRY();
     constexpr int LD = DH + 4;
     constexpr int NC = DH / 8;            // k-chunks of 8
     constexpr int NDB = (DH + 31) / 32;   // 32-wide d blocks
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 template <int DH>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, int ldo,
                                                          float* __restrict__ delta, int B, int H, int T) {
+    TVL_KERNEL_ENTRY();
     constexpr int G = DH / 4;  // lanes per (row, head)
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long pair = gid / G;
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+    TVL_KERNEL_ENTRY();
     constexpr int LD = DH + 4;
     constexpr int NC = DH / 8;
     constexpr int NDB = (DH + 31) / 32;
@@ -379,6 +382,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
+    TVL_KERNEL_ENTRY();
     constexpr int LD = DH + 4;
     constexpr int NC = DH / 8;
     constexpr int NDB = (DH + 31) / 32;

@@ -96,6 +96,7 @@ __device__ __forceinline__ void tile_sstore(const TileRegs<DH>& s, __bf16* __res
 
 template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_bf16s_kernel(Params p) {
+    TVL_KERNEL_ENTRY();
     constexpr int LDKB = Geo<DH>::LDKB, LDVB = Geo<DH>::LDVB, KS = Geo<DH>::KS, NDB = Geo<DH>::NDB;
     (void)LDVB;
     constexpr int KSZ = S * 32 * LDKB, VSZ = S * 32 * LDVB;
@@ -300,6 +301,7 @@ __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[S], const bf16x8 (&b)[S
 
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16s_kernel(BwdParams p) {
+    TVL_KERNEL_ENTRY();
     constexpr int LDKB = Geo<DH>::LDKB, LDVB = Geo<DH>::LDVB, KS = Geo<DH>::KS, NDB = Geo<DH>::NDB;
     (void)LDVB;
     constexpr int TSZ = S * 32 * LDKB;
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16s_kernel(BwdParams p) 
 
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p) {
+    TVL_KERNEL_ENTRY();
     constexpr int LDKB = Geo<DH>::LDKB, LDVB = Geo<DH>::LDVB, KS = Geo<DH>::KS, NDB = Geo<DH>::NDB;
     (void)LDVB;
     constexpr int TSZ = S * 32 * LDKB;
@@ -552,6 +555,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p
 // of 4 k-blocks (32 of the head's 64 columns), the two lane halves are summed by one cross-half shuffle
 __global__ __launch_bounds__(256) void attn_delta_tp3_kernel(const unsigned char* __restrict__ o_tp3, int o_kb, const float* __restrict__ d_o,
                                                              int ldo, float* __restrict__ delta, int B, int H, int T) {
+    TVL_KERNEL_ENTRY();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long M = (long)B * T;
     const long rbs = (M + 31) / 32;

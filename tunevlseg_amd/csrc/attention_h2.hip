@@ -157,6 +157,7 @@ constexpr int K_STAGE = 8 * PIECE, V_STAGE = 4 * VCH;
 constexpr int FWD_LDS = 2 * K_STAGE + 2 * V_STAGE;
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_h2_kernel(FwdP p) {
+    TVL_KERNEL_ENTRY();
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int lane = threadIdx.x & 63;
@@ -316,6 +317,7 @@ __device__ __forceinline__ void store_block(const BwdP& p, long m, int col0, int
 }
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_h2_kernel(BwdP p) {
+    TVL_KERNEL_ENTRY();
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int lane = threadIdx.x & 63;
@@ -421,6 +423,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_h2_kernel(BwdP p) {
 }
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_h2_kernel(BwdP p) {
+    TVL_KERNEL_ENTRY();
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int lane = threadIdx.x & 63;
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_h2_kernel(BwdP p) {
 // rows b*T + row0 .. + n - 1 of the packed-gradient image (two fp16 pieces, one scale per (row, 64-column block)) back to fp32 [B*n, K]
 __global__ __launch_bounds__(256) void h2k_gather_rows_kernel(const unsigned char* __restrict__ img, const float* __restrict__ kscale, int K, int B, int T,
                                                               int row0, int n, float* __restrict__ out) {
+    TVL_KERNEL_ENTRY();
     const int units = K >> 3;
     const long total = (long)B * n * units;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {

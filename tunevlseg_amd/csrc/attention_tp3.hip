@@ -149,6 +149,7 @@ constexpr int FWD_LDS = 2 * K_STAGE + 2 * V_STAGE;
 constexpr int FWD_THREADS = 256, FWD_Q = 128;
 template <int V>
 __global__ __launch_bounds__(FWD_THREADS, 2) void attn_fwd_tp3_kernel(FwdP p) {
+    TVL_KERNEL_ENTRY();
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int lane = threadIdx.x & 63;
@@ -382,6 +383,7 @@ constexpr int BWD_LDS = 2 * BWD_STAGE;
 // dQ: query-stationary.  Per key tile: S^T = K.Q^T, dP^T = V.dO^T (K, V fragments straight out of the DMA image), dS^T on the
 // accumulators, dQ^T += K^T . dS^T (K^T by transposed reads of the same K pieces).  Also writes delta for the dK/dV kernel.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tp3_kernel(BwdP p) {
+    TVL_KERNEL_ENTRY();
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int lane = threadIdx.x & 63;
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tp3_kernel(BwdP p) {
 // S = Q.K^T, dP = dO.V^T (Q, dO fragments straight out of the DMA image; query on the register, key on the lane),
 // dV^T += dO^T . P, dK^T += Q^T . dS (transposed reads of the same pieces).
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_tp3_kernel(BwdP p) {
+    TVL_KERNEL_ENTRY();
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int lane = threadIdx.x & 63;

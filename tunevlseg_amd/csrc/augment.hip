@@ -50,6 +50,7 @@ __device__ __forceinline__ void axis_taps(int d, int dst, int src, int (&idx)[4]
 __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restrict__ packed, const int64_t* __restrict__ offs,
                                                         const int32_t* __restrict__ hw, int B, int C, int H, int W, int cubic,
                                                         uint8_t* __restrict__ out) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * H * W;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int x = (int)(t % W), y = (int)((t / W) % H), b = (int)(t / ((long)W * H));
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void augment_u8_kernel(const uint8_t* __restri
                                                          const float* __restrict__ params, const int32_t* __restrict__ flags, float m0, float m1,
                                                          float m2, float s0, float s1, float s2, float* __restrict__ out_img,
                                                          float* __restrict__ out_mask, int B, int H, int W) {
+    TVL_KERNEL_ENTRY();
     const long hwp = (long)H * W, total = (long)B * hwp;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int x = (int)(t % W), y = (int)((t / W) % H), b = (int)(t / hwp);

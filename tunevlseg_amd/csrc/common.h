@@ -32,6 +32,23 @@ int tvl_attn_mode_bf16s(void);
         }                                                                             \
     } while (0)
 
+// Debug build (make POISON=1): every workgroup fills its whole LDS allocation with NaN patterns (fp32, fp16-pair and bf16-pair
+// NaNs at once) before its first instruction of substance, so a kernel that reads an LDS location it did not write fails the parity suite in a
+// single process instead of only when another process's leftovers sit there.  Expands to nothing in the product build.
+#ifdef TVL_POISON_LDS
+__device__ __forceinline__ void tvl_poison_lds() {
+    const auto* pkt = (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_dispatch_ptr();
+    const unsigned bytes = pkt[6];   // hsa_kernel_dispatch_packet_t.group_segment_size (byte 24)
+    auto* lds = (__attribute__((address_space(3))) unsigned*)0;
+    const unsigned nthreads = blockDim.x * blockDim.y * blockDim.z, tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    for (unsigned i = tid; i < bytes / 4; i += nthreads) lds[i] = 0x7FC07FC0u;
+    __syncthreads();
+}
+#define TVL_KERNEL_ENTRY() tvl_poison_lds()
+#else
+#define TVL_KERNEL_ENTRY() ((void)0)
+#endif
+
 static inline bool tvl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 __device__ __forceinline__ bool tvl_dev_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -17,6 +17,7 @@ inline unsigned nblk(long n, int per = 256) {
 template <bool VEC>
 __global__ void im2col3x3_kernel(const float* __restrict__ x, long sb, long sy, long sx, long sc, float* __restrict__ cols, int ldc,
                                  int B, int H, int W, int C, int stride, int Ho, int Wo) {
+    TVL_KERNEL_ENTRY();
     if (VEC) {  // NHWC, C % 4 == 0: one float4 of channels per thread
         const int c4 = C >> 2;
         const long total = (long)B * Ho * Wo * 9 * c4;
@@ -52,6 +53,7 @@ __global__ void im2col3x3_kernel(const float* __restrict__ x, long sb, long sy, 
 // V = channels per thread (4: float4 over the channel dimension of the NHWC map; 1: any C / alignment)
 template <int V>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int H, int W, int C, int k) {
+    TVL_KERNEL_ENTRY();
     const int Ho = H / k, Wo = W / k, CV = C / V;
     const long total = (long)B * Ho * Wo * CV;
     const float inv = 1.0f / (float)(k * k);
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
     }
 }
 __global__ void avgpool_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx, int B, int H, int W, int C, int k) {
+    TVL_KERNEL_ENTRY();
     const int Ho = H / k, Wo = W / k;
     const long total = (long)B * H * W * C;
     const float inv = 1.0f / (float)(k * k);
@@ -119,6 +122,7 @@ __device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f,
 
 template <int V>
 __global__ void bilinear_up_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int H, int W, int C, int s) {
+    TVL_KERNEL_ENTRY();
     typedef typename VecT<V>::type T;
     const int Ho = H * s, Wo = W * s;
     const int cv = C / V;
@@ -145,6 +149,7 @@ __global__ void bilinear_up_fwd_kernel(const float* __restrict__ x, int ldx, flo
 __global__ __launch_bounds__(256) void bilinear_up_h2_kernel(const float* __restrict__ x, int ldx, const unsigned* __restrict__ bits,
                                                              float* __restrict__ inv_scale, unsigned char* __restrict__ out, int B, int H, int W, int C,
                                                              int s, long rows_padded) {
+    TVL_KERNEL_ENTRY();
     const int Ho = H * s, Wo = W * s;
     const unsigned KB = (unsigned)(C >> 4);
     const float inv_s = 1.0f / (float)s;
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(256) void bilinear_up_h2_kernel(const float* __rest
 // gather form of the transpose: input pixel i receives from the outputs whose (i0, i1) touch it
 template <int V>
 __global__ void bilinear_up_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx, int B, int H, int W, int C, int s) {
+    TVL_KERNEL_ENTRY();
     typedef typename VecT<V>::type T;
     const int Ho = H * s, Wo = W * s;
     const int cv = C / V;
@@ -232,6 +238,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 __global__ void bicubic_ac_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ extra, float a, float r,
                                       int B, int Hi, int Wi, int Ho, int Wo, float sy, float sx) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * Ho * Wo;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho), b = (int)(i / ((long)Wo * Ho));
@@ -257,6 +264,7 @@ __global__ void bicubic_ac_fwd_kernel(const float* __restrict__ x, float* __rest
 }
 __global__ void bicubic_ac_bwd_kernel(const float* __restrict__ dy, float a, float* __restrict__ dx, int B, int Hi, int Wi, int Ho, int Wo,
                                       float sy, float sx) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * Hi * Wi;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int ix = (int)(i % Wi), iy = (int)((i / Wi) % Hi), b = (int)(i / ((long)Wi * Hi));
@@ -298,6 +306,7 @@ __global__ void bicubic_ac_bwd_kernel(const float* __restrict__ dy, float a, flo
 // (reference src/utils/save_utils.py:93-101)
 __global__ void bicubic_resize_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int Hi, int Wi, int Ho, int Wo,
                                          float sy, float sx) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)Ho * Wo;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int ox = (int)(i % Wo), oy = (int)(i / Wo);
@@ -328,6 +337,7 @@ constexpr int DC_PIX = 64;   // pixels per block (forward taps kernel)
 constexpr int DC_CH = 64;    // channel chunk staged through LDS
 __global__ __launch_bounds__(256) void dynconv_taps_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ word, int ldw,
                                                            float* __restrict__ taps, int HW, int C) {
+    TVL_KERNEL_ENTRY();
     __shared__ float xs[DC_PIX][DC_CH + 1];
     __shared__ float ws[DC_CH][9];
     const int b = blockIdx.y;
@@ -364,6 +374,7 @@ __global__ __launch_bounds__(256) void dynconv_taps_kernel(const float* __restri
 }
 __global__ void dynconv_gather_kernel(const float* __restrict__ taps, const float* __restrict__ word, int ldw, float* __restrict__ out,
                                       int B, int H, int W, int C) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * H * W;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int xx = (int)(i % W), yy = (int)((i / W) % H), b = (int)(i / ((long)W * H));
@@ -382,6 +393,7 @@ constexpr int DCB_PIX = 128;
 __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ word, int ldw, float* __restrict__ dx, int lddx,
                                                           float* __restrict__ work, int H, int W, int C, int nchunk) {
+    TVL_KERNEL_ENTRY();
     __shared__ float dts[DCB_PIX][9];
     __shared__ float red[256];
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -431,6 +443,7 @@ __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const float* __restric
     }
 }
 __global__ void dynconv_reduce_kernel(const float* __restrict__ work, float* __restrict__ dword, int ldw, int B, int n, int nchunk) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int j = (int)(i % n), b = (int)(i / n);
@@ -442,6 +455,7 @@ __global__ void dynconv_reduce_kernel(const float* __restrict__ work, float* __r
 
 // ---- strided matrix copy (channel concat / split of pixel matrices) --------------------------------------------------------
 __global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, long rows, int cols, int vec) {
+    TVL_KERNEL_ENTRY();
     if (vec) {
         const int c4 = cols >> 2;
         const long total = rows * c4;

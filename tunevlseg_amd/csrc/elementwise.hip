@@ -22,6 +22,7 @@ inline unsigned nblk(long n, int per = 256) { return (unsigned)((n + per - 1) / 
 
 // ---- im2col for the patch conv --------------------------------------------------------------
 __global__ void im2col_kernel(const float* __restrict__ img, float* __restrict__ cols, int B, int C, int H, int W, int ps) {
+    TVL_KERNEL_ENTRY();
     const int gh = H / ps, gw = W / ps;
     const int kdim = C * ps * ps;
     const int k4 = kdim >> 2;
@@ -39,6 +40,7 @@ __global__ void im2col_kernel(const float* __restrict__ img, float* __restrict__
 // ---- vision token assembly ------------------------------------------------------------------
 __global__ void vision_assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
                                        const float* __restrict__ ctx, long ctx_bs, float* __restrict__ x0, int B, int P, int n, int D) {
+    TVL_KERNEL_ENTRY();
     const int T = 1 + P + n;
     const long total = (long)B * T * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -57,6 +59,7 @@ __global__ void vision_assemble_kernel(const float* __restrict__ patch, const fl
 __global__ void text_assemble_kernel(const long long* __restrict__ ids, int L, const int* __restrict__ map,
                                      const float* __restrict__ table, const float* __restrict__ ctx, long ctx_bs,
                                      const float* __restrict__ pos, float* __restrict__ out, int B, int T, int D, long vocab) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * T * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % D);
@@ -77,6 +80,7 @@ __global__ void text_assemble_kernel(const long long* __restrict__ ids, int L, c
 // ---- generic row splice (API-compat learner.forward paths) -----------------------------------
 __global__ void splice_rows_kernel(const float* __restrict__ x, int L, const int* __restrict__ map, const float* __restrict__ ctx, long ctx_bs,
                                    float* __restrict__ out, int B, int T, int D) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * T * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % D);
@@ -89,6 +93,7 @@ __global__ void splice_rows_kernel(const float* __restrict__ x, int L, const int
 
 // ---- in-place row overwrite / its gradient --------------------------------------------------
 __global__ void rows_overwrite_kernel(float* __restrict__ x, const float* __restrict__ src, long src_bs, int B, int T, int D, int row0, int n) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * n * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % D);
@@ -99,6 +104,7 @@ __global__ void rows_overwrite_kernel(float* __restrict__ x, const float* __rest
 }
 __global__ void rows_grad_kernel(float* __restrict__ g, float* __restrict__ dst, int B, int T, int D, int row0, int n,
                                  int reduce_batch, int zero_src, int accumulate) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)n * D * (reduce_batch ? 1 : B);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % D);
@@ -123,6 +129,7 @@ __global__ void rows_grad_kernel(float* __restrict__ g, float* __restrict__ dst,
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ idx, float* __restrict__ out, int B, int T, int D) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % D), b = (int)(i / D);
@@ -130,6 +137,7 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int* __res
     }
 }
 __global__ void scatter_rows_add_kernel(const float* __restrict__ dout, const int* __restrict__ idx, float* __restrict__ dx, int B, int T, int D) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % D), b = (int)(i / D);
@@ -140,6 +148,7 @@ __global__ void scatter_rows_add_kernel(const float* __restrict__ dout, const in
 // ---- FiLM -----------------------------------------------------------------------------------
 __global__ void film_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mul, const float* __restrict__ add,
                                 float* __restrict__ y, int B, int T, int C) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * T * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -153,6 +162,7 @@ constexpr int FILM_TG = 16;
 __global__ __launch_bounds__(64 * FILM_TG) void film_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mul,
                                                                 float* __restrict__ dx, float* __restrict__ dmul, float* __restrict__ dadd,
                                                                 int B, int T, int C) {
+    TVL_KERNEL_ENTRY();
     __shared__ float s1[FILM_TG][64], s2[FILM_TG][64];
     const int b = blockIdx.x;
     const int cl = threadIdx.x & 63, tg = threadIdx.x >> 6;
@@ -184,6 +194,7 @@ __global__ __launch_bounds__(64 * FILM_TG) void film_bwd_kernel(const float* __r
 // ---- ConvTranspose2d(k = s = ps) tail: column block -> image --------------------------------
 __global__ void pixel_shuffle_kernel(const float* __restrict__ cols, const float* __restrict__ bias, const float* __restrict__ extra,
                                      float a, float r, float* __restrict__ logits, int B, int G, int ps) {
+    TVL_KERNEL_ENTRY();
     const int S = G * ps;
     const long total = (long)B * S * S;
     const float bv = bias ? bias[0] : 0.f;
@@ -196,6 +207,7 @@ __global__ void pixel_shuffle_kernel(const float* __restrict__ cols, const float
     }
 }
 __global__ void pixel_unshuffle_kernel(const float* __restrict__ dlogits, float a, float* __restrict__ dcols, int B, int G, int ps) {
+    TVL_KERNEL_ENTRY();
     const int S = G * ps;
     const long total = (long)B * S * S;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -211,6 +223,7 @@ __global__ void pixel_unshuffle_kernel(const float* __restrict__ dlogits, float 
 // image [B,H,W,3] uint8 -> [B,3,H,W] float, (x/255 - mean[c]) / std[c]; one thread = 4 consecutive pixels of one (b, c) plane row
 __global__ void normalize_u8_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, long pixels_per_image, int B,
                                     float m0, float m1, float m2, float s0, float s1, float s2) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * pixels_per_image;
     const float mean[3] = {m0, m1, m2}, inv[3] = {1.0f / (255.0f * s0), 1.0f / (255.0f * s1), 1.0f / (255.0f * s2)};
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -222,16 +235,19 @@ __global__ void normalize_u8_kernel(const uint8_t* __restrict__ img, float* __re
 }
 // mask [B,H,W] uint8 -> [B,1,H,W] float = x / 255 (image_text_mask_dataset.py:66-71); the metrics' mask.long() keeps only 255
 __global__ void mask_u8_kernel(const uint8_t* __restrict__ m, float* __restrict__ out, long n) {
+    TVL_KERNEL_ENTRY();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)m[i] / 255.0f;
 }
 
 // ---- (1 - r) * main + r * extra with r read on the device (trainable residual_ratio: no host round trip) ----
 __global__ void mix_kernel(const float* __restrict__ main_, const float* __restrict__ extra, const float* __restrict__ ratio,
                            float* __restrict__ out, long n) {
+    TVL_KERNEL_ENTRY();
     const float r = ratio[0], a = 1.0f - r;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a * main_[i] + r * extra[i];
 }
 __global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ ratio, int one_minus, float* __restrict__ y, long n) {
+    TVL_KERNEL_ENTRY();
     const float s = one_minus ? 1.0f - ratio[0] : ratio[0];
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = s * x[i];
 }
@@ -239,6 +255,7 @@ __global__ void scale_dev_kernel(const float* __restrict__ x, const float* __res
 // ---- optimiser / misc -----------------------------------------------------------------------
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                              float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    TVL_KERNEL_ENTRY();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gr = g[i] * gscale;
         float pv = p[i] * (1.0f - lr * wd);
@@ -252,13 +269,16 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 __global__ void fill_kernel(float* __restrict__ p, float val, long n) {
+    TVL_KERNEL_ENTRY();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = val;
 }
 __global__ void axpby_kernel(const float* __restrict__ x, float a, float* __restrict__ y, float b, long n) {
+    TVL_KERNEL_ENTRY();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
 }
 __global__ void bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y, long rows, int cols, int act) {
+    TVL_KERNEL_ENTRY();
     const long total = rows * cols;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float v = x[i];
@@ -268,6 +288,7 @@ __global__ void bias_act_kernel(const float* __restrict__ x, const float* __rest
 }
 // one wave per row
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv_norm, int rows, int cols) {
+    TVL_KERNEL_ENTRY();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -280,6 +301,7 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
 // y = x/||x||: dx = (dy - y * <dy,y>) / ||x||
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ inv_norm,
                                                          float* __restrict__ dx, int rows, int cols) {
+    TVL_KERNEL_ENTRY();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -291,6 +313,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 }
 // column sums; grid (ceil(cols/64), row_chunks); 256 threads = 64 columns x 4 row groups; atomics across chunks
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int cols, long rows_per_chunk) {
+    TVL_KERNEL_ENTRY();
     __shared__ float s[4][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -305,10 +328,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 
 __global__ void dact_mul_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ out, long n, int act) {
+    TVL_KERNEL_ENTRY();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = dy[i] * dact_f(pre[i], act);
 }
 // out[b,j,:] = bias[b,:] + cvec[j,:]
 __global__ void outer_add_kernel(const float* __restrict__ bias, const float* __restrict__ cvec, float* __restrict__ out, int B, int n, int D) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)B * n * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % D), j = (int)((i / D) % n), b = (int)(i / ((long)D * n));
@@ -317,6 +342,7 @@ __global__ void outer_add_kernel(const float* __restrict__ bias, const float* __
 }
 // dbias[b,:] = sum_j dout[b,j,:] ; dcvec[j,:] = sum_b dout[b,j,:]
 __global__ void outer_add_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dbias, float* __restrict__ dcvec, int B, int n, int D) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)(B + n) * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % D);
@@ -341,6 +367,7 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
     return z ^ (z >> 31);
 }
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p, float scale, unsigned long long seed) {
+    TVL_KERNEL_ENTRY();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const unsigned long long r = mix64(seed ^ mix64((unsigned long long)i));
         const float u = (float)(r >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0,1)
@@ -350,6 +377,7 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 
 // out[0] (+)= sum_i x[i]*y[i]  (double accumulation inside the block, one float atomic per block)
 __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, long n) {
+    TVL_KERNEL_ENTRY();
     __shared__ double s[4];
     double a = 0.0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a += (double)x[i] * (double)(y ? y[i] : 1.0f);

@@ -119,6 +119,7 @@ __device__ __forceinline__ void sstore_mnmajor(const StageRegs<COLS>& s, float* 
 
 template <int BM, int BN, int WGM, bool A_KMAJOR, bool B_KMAJOR, bool VEC>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
+    TVL_KERNEL_ENTRY();
     constexpr int WGN = 4 / WGM;  // 4 waves arranged WGM x WGN over the tile
     constexpr int WM = BM / WGM, WN = BN / WGN;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");

@@ -493,6 +493,7 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmParams& p) {
 // applies the epilogue.
 template <int S, bool VEC>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_splitk_kernel(GemmParams p, float* __restrict__ ws, int kchunk) {
+    TVL_KERNEL_ENTRY();
     constexpr int BM = 64, BN = 64, BK = 32, WGN = 2, WM = 32, WN = 32;
     constexpr int LDB = BK + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_splitk_kernel(GemmParams 
 
 // C[map(m), n] = epilogue(alpha * sum_s ws[s][m][n]): same epilogue order as the GEMM kernels
 __global__ void splitk_reduce_kernel(GemmParams p, const float* __restrict__ ws, int splits) {
+    TVL_KERNEL_ENTRY();
     const long total = (long)p.M * p.N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % p.N);
@@ -598,6 +600,7 @@ int launch_splitk(const GemmParams& p0, float* ws, int splits, hipStream_t s) {
 
 template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16s_kernel(GemmParams p) {
+    TVL_KERNEL_ENTRY();
     gemm_bf16s_body<BM, BN, WGM, S, VEC, BK, STAGES, CONV>(p);
 }
 template <int BM, int BN, int WGM, int S, bool VEC, int BK, int STAGES, bool CONV = false>

@@ -35,6 +35,7 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ x, const float* 
 template <bool MASK>
 __global__ __launch_bounds__(256) void h2_absmax_kernel(const float* __restrict__ x, long ldx, long rows, int K, unsigned* __restrict__ bits,
                                                         const float* __restrict__ mask, long ldm) {
+    TVL_KERNEL_ENTRY();
     float m = 0.f;
     const long total = rows * (K >> 2);
     const long stride = (long)gridDim.x * 256;
@@ -81,6 +82,7 @@ template <bool MASK>
 __global__ __launch_bounds__(256) void h2_pack_kernel(const float* __restrict__ x, long ldx, long rows, int K, const unsigned* __restrict__ bits,
                                                       float* __restrict__ inv_scale, unsigned char* __restrict__ out, long rows_padded,
                                                       const float* __restrict__ mask, long ldm) {
+    TVL_KERNEL_ENTRY();
     const unsigned KB = (unsigned)(K >> 4);
     const long total = rows_padded * (K >> 3);   // blocks * 64 < 2^31 * 64 (host check on the block count)
     const float inv_all = pow2_scale_inv(__builtin_bit_cast(float, bits[0]));
@@ -109,6 +111,7 @@ template <bool MASK>
 __global__ __launch_bounds__(256) void h2_rowpack_kernel(const float* __restrict__ x, long ldx, long rows, int K, float* __restrict__ inv_scale,
                                                          float* __restrict__ row_norm, unsigned char* __restrict__ out, const float* __restrict__ mask,
                                                          long ldm) {
+    TVL_KERNEL_ENTRY();
     __shared__ float s_mul[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rb = blockIdx.x;
@@ -278,6 +281,7 @@ extern "C" int tvl_h2_pack_masked(const float* x, int64_t ldx, const float* mask
 // rows b * T + row0 .. + n - 1 (b = 0 .. B - 1) of an h2 image := 0 (both pieces): the gradient cut of an in-place row overwrite
 // (tvl_rows_grad, zero_src) applied to the operand image that travels with the gradient, so the image need not be packed again
 __global__ __launch_bounds__(256) void h2_zero_rows_kernel(unsigned char* __restrict__ img, int K, int B, int T, int row0, int n) {
+    TVL_KERNEL_ENTRY();
     const int kb2 = K >> 3;                       // 16-byte units per row and piece
     const long total = (long)B * n * kb2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {

@@ -217,6 +217,7 @@ __device__ __forceinline__ void epilogue16_direct_f32(const Tp3Params& p, f32x4 
 // prologue beside the previous one's draining stores.  Kept as an opt-in experiment (TVL_GEMM_PERSIST=1), not on any default path.
 template <int BM, int EPI, bool KS = false, bool CONV = false, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
+    TVL_KERNEL_ENTRY();
     constexpr int NW = 8, BN = 256, NP = 2;
     constexpr int WM = BM / 2;
     constexpr int TMo = WM / 16;                    // 16-row A operands per wave (8 or 6)

@@ -6,6 +6,7 @@ namespace {
 
 // one thread = 8 consecutive k of one row -> one 16-byte store per piece; consecutive lanes write consecutive 16-byte slots
 __global__ void tp3_pack_kernel(const float* __restrict__ x, long ldx, long rows, int K, unsigned char* __restrict__ out, long rows_padded) {
+    TVL_KERNEL_ENTRY();
     const int KB = K >> 4;
     const long total = rows_padded * (K >> 3);
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -35,6 +36,7 @@ __global__ void tp3_pack_kernel(const float* __restrict__ x, long ldx, long rows
 }
 
 __global__ void tp3_unpack_kernel(const unsigned char* __restrict__ in, long rows, int K, float* __restrict__ y, long ldy) {
+    TVL_KERNEL_ENTRY();
     const int KB = K >> 4;
     const long rbs = (rows + 31) / 32;
     const long total = rbs * 32 * (K >> 3);

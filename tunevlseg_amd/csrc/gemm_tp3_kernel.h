@@ -247,6 +247,7 @@ __device__ __forceinline__ void read_all(Frags<TM, TN, NP>& f, unsigned a_addr, 
 // three bf16 pieces took, so the same two slabs in flight cover half the time (profiles/r3_gemm_experiments.md)
 template <int BM, int BN, int VARIANT, int EPI, int NP = 3, bool KS = false, bool CONV = false, int NW = NWAVE, int NS = 3>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_tp3_kernel(Tp3Params p_in) {
+    TVL_KERNEL_ENTRY();
     Tp3Params p = p_in;
     float* const stamp_buf = p_in.pre_out;
     if constexpr ((VARIANT & 32) != 0) p.pre_out = nullptr;

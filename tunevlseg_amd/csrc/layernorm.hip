@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      long rows, int cols, float eps) {
+    TVL_KERNEL_ENTRY();
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ rstd_in, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, long rows, int cols) {
+    TVL_KERNEL_ENTRY();
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(64 * NW) void ln_fwd_tp3_kernel(const float* __rest
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows, int cols,
                                                          float eps, float* __restrict__ inv_scale, float* __restrict__ row_norm,
                                                          unsigned long long* __restrict__ max_slot, unsigned tag) {
+    TVL_KERNEL_ENTRY();
     __shared__ float s_mean[32], s_rstd[32], s_scale[32], s_norm[32];
     __shared__ float4 s_gb[2][LN_MAXV * 64];   // gamma | beta for the second phase (every lane of a half-wave reads the same 32 bytes there)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -363,6 +366,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_tp3_kernel(const float* __rest
                                                          const float* __restrict__ dres, float* __restrict__ dx, unsigned char* __restrict__ out,
                                                          long rows, int cols, float* __restrict__ inv_scale, float* __restrict__ row_norm,
                                                          unsigned long long* __restrict__ max_slot, unsigned tag) {
+    TVL_KERNEL_ENTRY();
     __shared__ float s_scale[32], s_norm[32];
     __shared__ float4 s_g[LN_MAXV * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

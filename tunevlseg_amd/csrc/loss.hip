@@ -14,6 +14,7 @@ namespace {
 __global__ __launch_bounds__(256) void dicece_stats_kernel(const float* __restrict__ logits, const float* __restrict__ target,
                                                            double* __restrict__ part, long long* __restrict__ isum,
                                                            uint8_t* __restrict__ label, long N, float thr) {
+    TVL_KERNEL_ENTRY();
     __shared__ double sf[4][4];
     __shared__ long long si[4][4];
     const int b = blockIdx.y;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void dicece_stats_kernel(const float* __restri
 // one wave per (sample, quantity): the chunks side by side on the lanes, then a fixed-order wave reduction (a thread per output walked up to 256
 // partial sums one dependent add after the other: 18.5 us for 128 outputs)
 __global__ __launch_bounds__(64) void dicece_finish_kernel(const double* __restrict__ part, double* __restrict__ fsum, int B, int chunks) {
+    TVL_KERNEL_ENTRY();
     const int i = blockIdx.x;  // (b, k)
     const int b = i >> 2, k = i & 3, lane = threadIdx.x;
     double s = 0.0;
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(256) void dicece_bwd_kernel(const float* __restrict
                                                          const double* __restrict__ fsum, float* __restrict__ dlogits, int B, long N,
                                                          float lambda_dice, float lambda_ce, float snr, float sdr,
                                                          const float* __restrict__ gscale) {
+    TVL_KERNEL_ENTRY();
     const int b = blockIdx.y;
     const float gs = gscale ? gscale[0] : 1.0f;
     const double I = fsum[b * 4 + 0], D = fsum[b * 4 + 1] + fsum[b * 4 + 2];
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(256) void dicece_bwd_kernel(const float* __restrict
 // summation order (thread-strided partial sums, then a shared-memory tree): bitwise reproducible like fsum itself
 __global__ __launch_bounds__(256) void dicece_loss_kernel(const double* __restrict__ fsum, float* __restrict__ loss, int B, double n_pix,
                                                           double lambda_dice, double lambda_ce, double snr, double sdr) {
+    TVL_KERNEL_ENTRY();
     __shared__ double sd[256], sb[256];
     double d = 0.0, c = 0.0;
     for (int b = threadIdx.x; b < B; b += 256) {

@@ -132,6 +132,7 @@ __device__ __forceinline__ void reduce_quarters(Red& red, const f32x16 (&o)[2][2
 }
 
 __global__ __launch_bounds__(256) void mlp64_fwd_kernel(Mlp64P p) {
+    TVL_KERNEL_ENTRY();
     __shared__ Red red;
     __shared__ float stat[2][2][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(256) void mlp64_fwd_kernel(Mlp64P p) {
 
 // dx = dt2 + W1^T [ (W2^T dt2) * (W1 x + b1 > 0) ]   with   dt2 = LayerNorm2'(dout)   (per row: rstd (g - mean(g) - xhat mean(g xhat)), g = dout gamma)
 __global__ __launch_bounds__(256) void mlp64_bwd_kernel(Mlp64P p) {
+    TVL_KERNEL_ENTRY();
     __shared__ Red red;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(256) void mlp64_bwd_kernel(Mlp64P p) {
 // weight images: thread = (image, hidden block fb, sub-fragment, lane); writes both pieces (16 bytes each)
 __global__ __launch_bounds__(256) void mlp64_pack_kernel(const float* __restrict__ W1, const float* __restrict__ W2, int F, float s1, float s2,
                                                          unsigned char* __restrict__ img) {
+    TVL_KERNEL_ENTRY();
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int lane = gid & 63;
     const long frag = gid >> 6;                 // 0 .. 4 * (F / 32) * 4 - 1

@@ -28,6 +28,7 @@ constexpr int KMAX = 7;
 
 __global__ __launch_bounds__(256) void upconv_fwd_kernel(const float* __restrict__ taps, int ldg, const float* __restrict__ bias,
                                                          float* __restrict__ out, int B, int G, int ps, int k) {
+    TVL_KERNEL_ENTRY();
     const int S = G * ps;
     const int pl = (k - 1) / 2;
     const float inv_scale = 1.0f / (float)ps;
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void upconv_fwd_kernel(const float* __restrict
 // per pixel row / pixel instead of 100 gathered loads per pixel (179 -> ~40 us at B = 32, 352^2).
 //   R[b][i][ky][x] = sum_kx sum_j wx(clamp(x + kx - pl), j) taps[b, i, j, ky * k + kx]
 __global__ __launch_bounds__(256) void upconv_fwd_x_kernel(const float* __restrict__ taps, int ldg, float* __restrict__ work, int B, int G, int ps, int k) {
+    TVL_KERNEL_ENTRY();
     const int S = G * ps;
     const int pl = (k - 1) / 2;
     const float inv_scale = 1.0f / (float)ps;
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void upconv_fwd_x_kernel(const float* __restri
 //   out[b][y][x] = bias + sum_ky sum_i wy(clamp(y + ky - pl), i) R[b][i][ky][x]
 __global__ __launch_bounds__(256) void upconv_fwd_y_kernel(const float* __restrict__ work, const float* __restrict__ bias, float* __restrict__ out,
                                                            int B, int G, int ps, int k) {
+    TVL_KERNEL_ENTRY();
     const int S = G * ps;
     const int pl = (k - 1) / 2;
     const float inv_scale = 1.0f / (float)ps;
@@ -108,6 +111,7 @@ __device__ __forceinline__ float cell_weight(int X, int j, int G, float inv_scal
 
 // pass 1: work[b][kx][y][j] = sum_x dout[b][y][x] * wx(clamp(x+kx-pl), j)
 __global__ __launch_bounds__(256) void upconv_bwd_x_kernel(const float* __restrict__ dout, float* __restrict__ work, int B, int G, int ps, int k) {
+    TVL_KERNEL_ENTRY();
     const int S = G * ps;
     const int pl = (k - 1) / 2;
     const float inv_scale = 1.0f / (float)ps;
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(256) void upconv_bwd_x_kernel(const float* __restri
 }
 // pass 2: dtaps[b][i][j][ky*k+kx] = sum_y wy(clamp(y+ky-pl), i) * work[b][kx][y][j]
 __global__ __launch_bounds__(256) void upconv_bwd_y_kernel(const float* __restrict__ work, float* __restrict__ dtaps, int ldg, int B, int G, int ps, int k) {
+    TVL_KERNEL_ENTRY();
     const int S = G * ps;
     const int pl = (k - 1) / 2;
     const float inv_scale = 1.0f / (float)ps;
