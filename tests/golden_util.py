@@ -10,7 +10,8 @@ import torch
 
 from tunevlseg_amd.config import CLIPSegConfig
 from tunevlseg_amd.cris_config import CRISConfig
-from tunevlseg_amd.weights import init_clipseg_state_dict, init_cris_state_dict
+from tunevlseg_amd.denseclip_config import DenseCLIPConfig
+from tunevlseg_amd.weights import init_clipseg_state_dict, init_cris_state_dict, init_denseclip_state_dict
 
 GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
 
@@ -219,3 +220,45 @@ def check_compact_labels(fx, logits: torch.Tensor, isum: torch.Tensor, mask: tor
     assert ((isum.cpu() - ref_counts).abs().sum(1) <= 2 * (per_sample_flips + knife_edge)).all(), \
         "integer counts differ from the reference beyond the ambiguous pixels"
     return int(flips.numel())
+
+
+# ---- DenseCLIP fixtures (meta["family"] == "denseclip") ---------------------------------------------------------------
+def denseclip_config_of(fx) -> DenseCLIPConfig:
+    return DenseCLIPConfig.from_dict(fx["meta"]["config"])
+
+
+def denseclip_state_of(fx) -> dict[str, torch.Tensor]:
+    sd = init_denseclip_state_dict(denseclip_config_of(fx), fx["meta"]["weight_seed"])
+    chk = float(sum(v.double().abs().sum() for k, v in sd.items() if k not in ("contexts", "gamma")))
+    assert abs(chk - fx["meta"]["weights_checksum"]) <= 1e-6 * abs(chk), "seeded weight draw drifted from the fixture"
+    return sd
+
+
+def synth_denseclip_inputs(cfg: DenseCLIPConfig, B: int, H: int, seed: int):
+    """img N(0,1) [B, 3, H, H]; class-name token rows as the reference's ``tokenize(name, context_length)`` lays them out
+    (untils.py:173-221): [SOT, words, EOT, 0-pads] with EOT the highest id, 1 .. context_length - 2 words per class; the two seeded
+    cotangents of the fixture scalar  L = sum(score_map * Gs) + sum(text_embeddings * Gt)."""
+    g = torch.Generator().manual_seed(seed)
+    pix = torch.randn(B, 3, H, H, generator=g)
+    K, N1 = cfg.num_classes, cfg.context_length
+    sot, eot = cfg.vocab_size - 2, cfg.vocab_size - 1
+    texts = torch.zeros(K, N1, dtype=torch.long)
+    for k in range(K):
+        n_words = 1 + k % (N1 - 2)
+        row = [sot, *torch.randint(1, min(cfg.vocab_size - 2, 40000), (n_words,), generator=g).tolist(), eot]
+        texts[k, : len(row)] = torch.tensor(row)
+    G = H // cfg.patch_size
+    gs = torch.randn(B, K, G, G, generator=g)
+    gt = torch.randn(B, K, cfg.embed_dim, generator=g) * 0.1
+    return pix, texts, gs, gt
+
+
+def denseclip_subsample(name: str, t: torch.Tensor, compact: bool) -> torch.Tensor:
+    """What a compact (full-size) fixture keeps of an output: every ``DENSECLIP_STRIDE[name]``-th pixel of the large maps."""
+    if not compact or name not in DENSECLIP_STRIDE:
+        return t
+    s = DENSECLIP_STRIDE[name]
+    return t[..., ::s, ::s].contiguous()
+
+
+DENSECLIP_STRIDE = {"fpn1": 9, "fpn2": 5, "fpn3": 3, "fpn4": 2, "visual_embedding": 3}

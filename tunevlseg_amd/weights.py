@@ -284,3 +284,91 @@ def init_cris_state_dict(cfg: CRISConfig, seed: int = 0, dtype: torch.dtype = to
     ``num_batches_tracked``).  BatchNorm running statistics are non-trivial: the towers run in eval mode
     (reference coop_cris.py:66-68)."""
     return _draw(cris_param_specs(cfg), seed, dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DenseCLIP (reference src/models/components/denseclip/{models,denseclip}.py); key names = the reference module tree
+# ---------------------------------------------------------------------------------------------------------------------
+def _resblock_specs(prefix: str, d: int, n_layers: int):
+    """OpenAI-CLIP ``ResidualAttentionBlock`` (models.py:391-431): packed in-projection, QuickGELU MLP."""
+    yield from _mha_specs(f"{prefix}.attn", d, (2 * n_layers) ** -0.5 * 2.0)
+    yield from _ln_specs(f"{prefix}.ln_1", d)
+    yield f"{prefix}.mlp.c_fc.weight", (4 * d, d), "normal", (2 * d) ** -0.5 * 1.5
+    yield f"{prefix}.mlp.c_fc.bias", (4 * d,), "normal", 0.02
+    yield f"{prefix}.mlp.c_proj.weight", (d, 4 * d), "normal", (4 * d) ** -0.5 * (2 * n_layers) ** -0.5 * 2.0
+    yield f"{prefix}.mlp.c_proj.bias", (d,), "normal", 0.02
+    yield from _ln_specs(f"{prefix}.ln_2", d)
+
+
+def denseclip_param_specs(cfg) -> Iterator[tuple[str, tuple[int, ...], str, float]]:
+    """``DenseCLIP.state_dict()`` keys of the parts on the hot path (``backbone``, ``text_encoder``, ``context_decoder``,
+    ``contexts``, ``gamma``; denseclip.py:75-108) minus ``num_batches_tracked``.  The mmseg neck / decode head are not held."""
+    w, p = cfg.width, cfg.patch_size
+    b = "backbone"
+    yield f"{b}.conv1.weight", (w, 3, p, p), "normal", 0.02
+    yield f"{b}.class_embedding", (w,), "normal", w**-0.5 * 5
+    yield f"{b}.positional_embedding", (cfg.grid**2 + 1, w), "normal", 0.1
+    yield from _ln_specs(f"{b}.ln_pre", w)
+    for i in range(cfg.layers):
+        yield from _resblock_specs(f"{b}.transformer.resblocks.{i}", w, cfg.layers)
+    yield from _ln_specs(f"{b}.ln_post", w)
+    yield f"{b}.proj", (w, cfg.output_dim), "normal", w**-0.5
+    if p != 16:
+        raise NotImplementedError("DenseCLIP: the patch-16 FPN (models.py:582-600) is the one on the path; patch 8 (models.py:602-619) is not built")
+    # fpn1: GroupNorm(1) -> ConvTranspose2d(k2, s2) -> SyncBatchNorm -> GELU -> ConvTranspose2d(k2, s2)   (models.py:583-589)
+    yield from _ln_specs(f"{b}.fpn1.0", w)
+    yield f"{b}.fpn1.1.weight", (w, w, 2, 2), "normal", w**-0.5
+    yield f"{b}.fpn1.1.bias", (w,), "normal", 0.02
+    yield from _bn_specs(f"{b}.fpn1.2", w)
+    yield f"{b}.fpn1.4.weight", (w, w, 2, 2), "normal", w**-0.5 * 1.5
+    yield f"{b}.fpn1.4.bias", (w,), "normal", 0.02
+    # fpn2: GroupNorm(1) -> ConvTranspose2d ; fpn3: GroupNorm(1) ; fpn4: GroupNorm(1) -> MaxPool2d(2)   (models.py:591-600)
+    yield from _ln_specs(f"{b}.fpn2.0", w)
+    yield f"{b}.fpn2.1.weight", (w, w, 2, 2), "normal", w**-0.5
+    yield f"{b}.fpn2.1.bias", (w,), "normal", 0.02
+    yield from _ln_specs(f"{b}.fpn3", w)
+    yield from _ln_specs(f"{b}.fpn4.0", w)
+    # CLIPTextContextEncoder (models.py:805-841)
+    d, t = cfg.transformer_width, "text_encoder"
+    for i in range(cfg.transformer_layers):
+        yield from _resblock_specs(f"{t}.transformer.resblocks.{i}", d, cfg.transformer_layers)
+    yield f"{t}.token_embedding.weight", (cfg.vocab_size, d), "normal", 0.1
+    yield f"{t}.positional_embedding", (cfg.text_context_length, d), "normal", 0.05
+    yield from _ln_specs(f"{t}.ln_final", d)
+    yield f"{t}.text_projection", (d, cfg.embed_dim), "normal", d**-0.5
+    # ContextDecoder (models.py:907-946): memory_proj = LN, Linear, LN; text_proj = LN, Linear; out_proj = LN, Linear
+    c, dw, vd = "context_decoder", cfg.decoder_width, cfg.visual_dim
+    yield from _ln_specs(f"{c}.memory_proj.0", vd)
+    yield f"{c}.memory_proj.1.weight", (dw, vd), "normal", vd**-0.5
+    yield f"{c}.memory_proj.1.bias", (dw,), "normal", 0.02
+    yield from _ln_specs(f"{c}.memory_proj.2", dw)
+    yield from _ln_specs(f"{c}.text_proj.0", vd)
+    yield f"{c}.text_proj.1.weight", (dw, vd), "normal", vd**-0.5
+    yield f"{c}.text_proj.1.bias", (dw,), "normal", 0.02
+    for i in range(cfg.decoder_layers):
+        q = f"{c}.decoder.{i}"
+        for a in ("self_attn", "cross_attn"):   # models.py:448-486: q/k/v projections without bias, output projection with
+            for n in ("q_proj", "k_proj", "v_proj"):
+                yield f"{q}.{a}.{n}.weight", (dw, dw), "normal", dw**-0.5 * 1.5
+            yield f"{q}.{a}.proj.weight", (dw, dw), "normal", dw**-0.5
+            yield f"{q}.{a}.proj.bias", (dw,), "normal", 0.02
+        for n in ("norm1", "norm2", "norm3"):
+            yield from _ln_specs(f"{q}.{n}", dw)
+        yield f"{q}.mlp.0.weight", (4 * dw, dw), "normal", (2 * dw) ** -0.5 * 1.5
+        yield f"{q}.mlp.0.bias", (4 * dw,), "normal", 0.02
+        yield f"{q}.mlp.3.weight", (dw, 4 * dw), "normal", (4 * dw) ** -0.5
+        yield f"{q}.mlp.3.bias", (dw,), "normal", 0.02
+    yield from _ln_specs(f"{c}.out_proj.0", dw)
+    yield f"{c}.out_proj.1.weight", (vd, dw), "normal", dw**-0.5
+    yield f"{c}.out_proj.1.bias", (vd,), "normal", 0.02
+    # the segmentor's own parameters (denseclip.py:104-108); trainable on the prompt-tuning path
+    yield "contexts", (1, cfg.num_contexts, cfg.token_embed_dim), "normal", 0.1
+    yield "gamma", (cfg.text_dim,), "ln_w", 0.0   # placeholder value 1.0; fixtures / callers set it (reference init: 1e-4)
+
+
+def init_denseclip_state_dict(cfg, seed: int = 0, dtype: torch.dtype = torch.float32) -> dict[str, torch.Tensor]:
+    """Seeded CPU draw of every DenseCLIP tensor on the hot path under the reference's module names; ``gamma`` starts at the
+    reference's 1e-4 (denseclip.py:108).  BatchNorm running statistics are non-trivial: the frozen model runs in eval mode."""
+    sd = _draw(denseclip_param_specs(cfg), seed, dtype)
+    sd["gamma"] = torch.full_like(sd["gamma"], 1e-4)
+    return sd
