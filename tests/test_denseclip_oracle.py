@@ -44,6 +44,9 @@ def check(fx):
             s = float(fx[f"out.{k}_abs_sum"])
             assert abs(t.double().abs().sum().item() - s) <= 1e-5 * s, k
     for k, g in grads.items():
+        if "grad." + k not in fx:   # compact fixtures hold the context decoder's small gradients + three weight matrices only
+            assert fx["meta"]["compact"] and k.startswith("context_decoder.")
+            continue
         g_ref = torch.from_numpy(fx["grad." + k])
         scale = g_ref.abs().max().item() + 1e-12
         # the reference's own fp32 gradient vs its float64 run bounds what two fp32 evaluations can agree to
