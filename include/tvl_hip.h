@@ -29,8 +29,9 @@ typedef void* tvlStream_t; /* hipStream_t */
 /* Bumped on every incompatible change of a signature or struct below.  3: tvl_dicece_stats gained `work`, tvl_split_planes /
  * tvl_gemm_planes removed (round 2).  4: tvl_text_assemble gained `vocab` (rows of the embedding table: ids outside it give NaN rows
  * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  5: tvl_dicece_loss, tvl_mlp64_*, tvl_h2_zero_rows added; tvl_upconv_taps_fwd gained `work`; tvl_attn_h2_bwd gained `only_block`, tvl_h2k_gather_rows added;
- * tvl_layernorm_fwd_h2 / _bwd_h2 gained max_slot / tag (largest row norm by tagged atomicMax).  The Python binding refuses a library whose tvl_abi_version() differs. */
-#define TVL_ABI_VERSION 5
+ * tvl_layernorm_fwd_h2 / _bwd_h2 gained max_slot / tag (largest row norm by tagged atomicMax).  6 (round 4): TVL_ACT_GELU, the DenseCLIP entries
+ * (tvl_groupnorm_*, tvl_tconv2x2_unshuffle, tvl_colscale_*).  The Python binding refuses a library whose tvl_abi_version() differs. */
+#define TVL_ABI_VERSION 6
 
 const char* tvl_last_error(void);
 int tvl_abi_version(void);
@@ -39,7 +40,7 @@ int tvl_abi_version(void);
 typedef struct { int32_t div, mul, off; } tvlRowMap;
 
 enum { TVL_NT = 0, TVL_NN = 1, TVL_TN = 2 };
-enum { TVL_ACT_NONE = 0, TVL_ACT_QUICK_GELU = 1, TVL_ACT_RELU = 2, TVL_ACT_SIGMOID = 3 };
+enum { TVL_ACT_NONE = 0, TVL_ACT_QUICK_GELU = 1, TVL_ACT_RELU = 2, TVL_ACT_SIGMOID = 3, TVL_ACT_GELU = 4 /* erf form, nn.GELU() */ };
 /* OR into tvlGemmArgs.act: apply the activation AFTER the residual add (ResNet bottleneck tail relu(conv + identity),
  * reference cris_model/clip.py:75); default order is act first, then residual (transformer blocks) */
 enum { TVL_ACT_POST_RESIDUAL = 0x100 };
@@ -423,6 +424,26 @@ int tvl_dynconv_fwd(const float* x, int32_t ldx, const float* word, int32_t ldw,
 int64_t tvl_dynconv_bwd_work_floats(int32_t B, int32_t H, int32_t W, int32_t C);
 int tvl_dynconv_bwd(const float* dout, const float* x, int32_t ldx, const float* word, int32_t ldw, float* dx, int32_t lddx,
                     float* dword, float* work, int32_t B, int32_t H, int32_t W, int32_t C, tvlStream_t stream);
+
+/* ---- DenseCLIP (BASELINE configs[4]): reference src/models/components/denseclip/models.py:581-600,693-701 (the ViT-B/16 FPN taps of
+ * CLIPVisionTransformer) and denseclip.py:157.  Maps are NHWC pixel matrices [B, H*W, C] with row stride ld* and sample stride batch_stride
+ * (elements): a tap is the token matrix [B, 1 + H*W, C] minus its CLS row, read in place. */
+/* nn.GroupNorm(1, C): per-sample mean / rstd over all H*W*C elements -> stats[2*b] = mean, stats[2*b + 1] = rstd.  Two stages, double sums in a
+ * fixed order (bitwise reproducible); work: tvl_groupnorm_work_doubles(B, rows) doubles. */
+int64_t tvl_groupnorm_work_doubles(int32_t B, int32_t rows);
+int tvl_groupnorm_stats(const float* x, int64_t batch_stride, int32_t ldx, int32_t B, int32_t rows, int32_t C, float eps, float* stats, double* work,
+                        tvlStream_t stream);
+/* y = (x - mean_b) * rstd_b * gamma[c] + beta[c]; pool = 2: followed by nn.MaxPool2d(2, 2) in the same pass (fpn4, models.py:598-600); y is
+ * [B*(H/pool)*(W/pool), ldy] contiguous over samples */
+int tvl_groupnorm_apply(const float* x, int64_t batch_stride, int32_t ldx, const float* stats, const float* gamma, const float* beta, float* y, int32_t ldy,
+                        int32_t B, int32_t H, int32_t W, int32_t C, int32_t pool, tvlStream_t stream);
+/* nn.ConvTranspose2d(C, C, kernel_size=2, stride=2) is a GEMM [pixels, C] x [C, (dy, dx, co)] (kernel == stride: no overlap) whose output rows are the
+ * pixels in blocked order; `levels` such GEMMs in a row (fpn1: two, the per-pixel BatchNorm / GELU between them do not care about pixel order)
+ * leave [B*H*W*4^(levels-1), 4C]; this puts the result back in raster order: out [B, H*2^levels, W*2^levels, C], row stride ldo. */
+int tvl_tconv2x2_unshuffle(const float* in, float* out, int32_t ldo, int32_t B, int32_t H, int32_t W, int32_t C, int32_t levels, tvlStream_t stream);
+/* out[r, c] = a[r, c] + g[c] * b[r, c]  (text_embeddings + gamma * text_diff, denseclip.py:157); bwd: db = d * g (may be NULL), dg[c] = sum_r d * b (may be NULL) */
+int tvl_colscale_add(const float* a, const float* b, const float* g, float* out, int64_t rows, int32_t cols, tvlStream_t stream);
+int tvl_colscale_bwd(const float* d, const float* b, const float* g, float* db, float* dg, int64_t rows, int32_t cols, tvlStream_t stream);
 
 #ifdef __cplusplus
 }

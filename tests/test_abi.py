@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     from tunevlseg_amd import hip
 
     lib = hip.load()
-    assert lib.tvl_abi_version() == 5
+    assert lib.tvl_abi_version() == 6
     decl = declared_symbols()
     assert len(decl) >= 30
     missing = [s for s in decl if not hasattr(lib, s)]

@@ -120,6 +120,7 @@ __device__ __forceinline__ float act_f(float v, int act) {
         const float e = expf(-fabsf(v));
         return (v >= 0.f ? 1.0f : e) / (1.0f + e);
     }
+    if (act == TVL_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // nn.GELU(): the exact (erf) form
     return v;
 }
 __device__ __forceinline__ float dact_f(float z, int act) {
@@ -130,5 +131,6 @@ __device__ __forceinline__ float dact_f(float z, int act) {
         const float s = (z >= 0.f ? 1.0f : e) / (1.0f + e);
         return s * (1.0f - s);
     }
+    if (act == TVL_ACT_GELU) return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
     return 1.f;
 }

@@ -35,9 +35,9 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["TVL_HIP_LIB"]) if os.environ.get("TVL_HIP_LIB") else _HERE / "csrc" / "libtvl_hip.so"   # (override: a `make DIAG=1` build for the tools)
 
 NT, NN, TN = 0, 1, 2
-ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
 ACT_POST_RESIDUAL = 0x100  # OR into act: activation after the residual add
-ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "quick_gelu": ACT_QUICK_GELU, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID}
+ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "quick_gelu": ACT_QUICK_GELU, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "gelu": ACT_GELU}
 
 
 class RowMap(C.Structure):
@@ -197,12 +197,17 @@ _SIGS = {
     "tvl_bicubic_resize_u8": [_P, _P, _I, _I, _I, _I],
     "tvl_dynconv_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
     "tvl_dynconv_bwd": [_P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I],
+    "tvl_groupnorm_stats": [_P, _L, _I, _I, _I, _I, _F, _P, _P],
+    "tvl_groupnorm_apply": [_P, _L, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
+    "tvl_tconv2x2_unshuffle": [_P, _P, _I, _I, _I, _I, _I, _I],
+    "tvl_colscale_add": [_P, _P, _P, _P, _L, _I],
+    "tvl_colscale_bwd": [_P, _P, _P, _P, _P, _L, _I],
 }
 EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_h2_bytes", "tvl_dicece_work_doubles",
-           "tvl_gemm_aux_floats", "tvl_mlp64_image_bytes", *_SIGS]
+           "tvl_gemm_aux_floats", "tvl_mlp64_image_bytes", "tvl_groupnorm_work_doubles", *_SIGS]
 
 _lib = None
-ABI_VERSION = 5   # include/tvl_hip.h TVL_ABI_VERSION
+ABI_VERSION = 6   # include/tvl_hip.h TVL_ABI_VERSION
 
 
 def load():
@@ -229,6 +234,8 @@ def load():
     lib.tvl_dicece_work_doubles.restype = C.c_int64
     lib.tvl_gemm_aux_floats.argtypes = [_L, _L]
     lib.tvl_gemm_aux_floats.restype = C.c_int64
+    lib.tvl_groupnorm_work_doubles.argtypes = [_I, _I]
+    lib.tvl_groupnorm_work_doubles.restype = C.c_int64
     lib.tvl_tp3_bytes.argtypes = [_L, _I]
     lib.tvl_tp3_bytes.restype = C.c_int64
     for name, sig in _SIGS.items():
@@ -1666,3 +1673,49 @@ def bicubic_resize_u8(pred: torch.Tensor, Ho: int, Wo: int) -> torch.Tensor:
     out = torch.empty((Ho, Wo), device=pred.device, dtype=torch.uint8)
     _call("tvl_bicubic_resize_u8", _p(pred), out.data_ptr(), H, W, Ho, Wo)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# DenseCLIP (csrc/denseclip.hip): FPN taps of the ViT backbone over NHWC pixel matrices
+# --------------------------------------------------------------------------------------
+def groupnorm_nhwc(tokens: torch.Tensor, skip_rows: int, H: int, W: int, gamma, beta, eps: float, *, pool: int = 1, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``nn.GroupNorm(1, C)`` [+ ``nn.MaxPool2d(2, 2)``] over the map held by rows ``skip_rows ..`` of every sample of ``tokens`` [B, T, C]
+    (reference models.py:697-701: the tap drops the CLS row) -> pixel matrix [B*(H/pool)*(W/pool), C], or into ``out`` (a column range of a
+    wider matrix: the score map is concatenated behind fpn3, denseclip.py:166-168)."""
+    B, T, Cc = tokens.shape
+    if T != skip_rows + H * W or not tokens.is_contiguous():
+        raise RuntimeError(f"groupnorm_nhwc: tokens {tuple(tokens.shape)} do not hold a {H}x{W} map behind {skip_rows} rows")
+    lib = _lib if _lib is not None else load()
+    stats = torch.empty(2 * B, device=tokens.device, dtype=torch.float32)
+    work = torch.empty(int(lib.tvl_groupnorm_work_doubles(B, H * W)), device=tokens.device, dtype=torch.float64)
+    src = tokens.view(B * T, Cc)[skip_rows:]   # first pixel of sample 0; sample stride T*C
+    _call("tvl_groupnorm_stats", src.data_ptr(), T * Cc, Cc, B, H * W, Cc, float(eps), _p(stats), work.data_ptr())
+    rows = B * (H // pool) * (W // pool)
+    y = out if out is not None else torch.empty((rows, Cc), device=tokens.device, dtype=torch.float32)
+    if y.shape != (rows, Cc):
+        raise RuntimeError(f"groupnorm_nhwc: out {tuple(y.shape)} != {(rows, Cc)}")
+    _call("tvl_groupnorm_apply", src.data_ptr(), T * Cc, Cc, _p(stats), _p(gamma), _p(beta), _ps(y), y.stride(0), B, H, W, Cc, pool)
+    return y
+
+
+def tconv2x2_unshuffle(blocked: torch.Tensor, B: int, H: int, W: int, Cc: int, levels: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """[B*H*W*4^(levels-1), 4C] (the output of ``levels`` ConvTranspose2d(k=2, s=2)-as-GEMM steps) -> raster NHWC [B*(H*2^l)*(W*2^l), C]."""
+    f = 1 << levels
+    if blocked.numel() != B * H * W * f * f * Cc or not blocked.is_contiguous():
+        raise RuntimeError(f"tconv2x2_unshuffle: {tuple(blocked.shape)} is not B*H*W*4^levels x C = {B * H * W * f * f} x {Cc}")
+    y = out if out is not None else torch.empty((B * H * f * W * f, Cc), device=blocked.device, dtype=torch.float32)
+    _call("tvl_tconv2x2_unshuffle", _p(blocked), _ps(y), y.stride(0), B, H, W, Cc, levels)
+    return y
+
+
+def colscale_add(a: torch.Tensor, b: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(a)
+    _call("tvl_colscale_add", _p(a), _p(b), _p(g), _p(out), a.numel() // a.shape[-1], a.shape[-1])
+    return out
+
+
+def colscale_bwd(d: torch.Tensor, b: torch.Tensor, g: torch.Tensor, want_db: bool, want_dg: bool):
+    db = torch.empty_like(d) if want_db else None
+    dg = torch.empty_like(g) if want_dg else None
+    _call("tvl_colscale_bwd", _p(d), _p(b), _p(g), _p(db), _p(dg), d.numel() // d.shape[-1], d.shape[-1])
+    return db, dg
