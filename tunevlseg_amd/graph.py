@@ -14,7 +14,11 @@ What makes the capture legal (the two failed attempts of rounds 2 and 3 are in D
 * the optimiser update stays outside the graph (its bias correction takes the step count as a launch argument), so does the gradient
   exchange of a multi-GPU job (``opt.step()`` launches the buckets the disarmed hooks did not);
 * the slot pool of the tagged ``atomicMax`` hand-over (``hip._max_slot``) is cleared inside the captured region: a replay re-uses the slots
-  and tags of the capture.
+  and tags of the capture;
+* nothing in the step may take a per-step launch argument from the host.  The one such thing in the package is train-mode dropout
+  (``ops.DropoutFn``: the SharedAttn learner's TransformerEncoderLayer): a step that used it is not kept as a graph and its shape stays
+  eager (``GraphedStep._eager_only``);
+* batches may carry host entries (the reference's collate leaves ``mask_shape`` on the CPU): only device tensors are keyed and copied.
 """
 from __future__ import annotations
 
@@ -22,7 +26,7 @@ from typing import Any, Mapping
 
 import torch
 
-from . import hip
+from . import hip, ops
 
 
 def use_private_stream(device=None) -> "torch.cuda.Stream":
@@ -36,8 +40,14 @@ def use_private_stream(device=None) -> "torch.cuda.Stream":
     return s
 
 
+def _device_tensors(batch: Mapping[str, Any]) -> dict:
+    """The entries a captured step can read: device tensors.  What the data pipeline leaves on the host (``mask_shape`` of the reference's
+    collate, file names) is only read by Python outside the step, so it is neither part of the shape key nor copied per replay."""
+    return {k: v for k, v in batch.items() if isinstance(v, torch.Tensor) and v.is_cuda}
+
+
 def _key(batch: Mapping[str, Any]):
-    return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if isinstance(v, torch.Tensor))
+    return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(_device_tensors(batch).items()))
 
 
 class GraphedStep:
@@ -52,6 +62,7 @@ class GraphedStep:
         self.module, self.opt, self.max_graphs = module, opt, max_graphs
         self._seen: set = set()
         self._graphs: dict = {}
+        self._eager_only: set = set()   # shapes whose step takes per-step launch arguments from the host (train-mode dropout seeds)
         self.replays = 0
 
     def _eager(self, batch):
@@ -64,10 +75,14 @@ class GraphedStep:
         key = _key(batch)
         entry = self._graphs.get(key)
         if entry is None:
-            if key not in self._seen or len(self._graphs) >= self.max_graphs:
+            if key not in self._seen or key in self._eager_only or len(self._graphs) >= self.max_graphs:
                 self._seen.add(key)
                 return self._eager(batch)
-            entry = self._graphs[key] = self._capture(batch)
+            entry = self._capture(batch)
+            if entry is None:   # the step draws a fresh dropout mask per call: a replay would repeat the captured one
+                self._eager_only.add(key)
+                return self._eager(batch)
+            self._graphs[key] = entry
         g, static, loss, appended = entry
         for k, v in static.items():
             v.copy_(batch[k], non_blocking=True)
@@ -78,18 +93,22 @@ class GraphedStep:
         return loss
 
     def _capture(self, batch):
-        dev = next(v for v in batch.values() if isinstance(v, torch.Tensor)).device
+        on_device = _device_tensors(batch)
+        if not on_device:
+            raise RuntimeError("GraphedStep: the batch holds no device tensor")
+        dev = next(iter(on_device.values())).device
         stream = torch.cuda.current_stream(dev)
         if stream == torch.cuda.default_stream(dev):
             raise RuntimeError("GraphedStep: the current stream is the default stream -- call tunevlseg_amd.graph.use_private_stream() before building "
                                "the module and its optimiser (the AccumulateGrad nodes must live on the capture stream)")
-        static = {k: v.clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+        static = {k: v.clone() for k, v in on_device.items()}
         step_in = {**batch, **static}
         # metric states are python lists of per-batch count tensors (task.DiceSamples / JaccardBinary): note what the captured step appends
         lists = [(m, a) for m in getattr(self.module, "metrics", {}).values() for a, lst in vars(m).items() if isinstance(lst, list)]
         before = [len(getattr(m, a)) for m, a in lists]
         arm = getattr(self.opt, "set_exchange_armed", lambda armed: None)
         arm(False)   # no collective inside the graph: opt.step() -> exchange.finish() launches every bucket after the replay
+        dropout_calls = ops._dropout_calls
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
@@ -98,6 +117,15 @@ class GraphedStep:
                 loss = self._eager(step_in)
         finally:
             arm(True)
+        if ops._dropout_calls != dropout_calls:
+            # ops.DropoutFn passes its (seed, call index) as a launch argument: frozen into the graph, every replay would re-use the capture's
+            # mask and the training dynamics would silently differ from the eager step.  Drop the graph; this shape stays eager, with the
+            # counter put back so that the eager steps draw the masks they would have drawn without the attempt.
+            ops._dropout_calls = dropout_calls
+            for (m, a), n0 in zip(lists, before):
+                del getattr(m, a)[n0:]
+            del g
+            return None
         appended = []
         for (m, a), n0 in zip(lists, before):   # the capture did not run: its appends come back per replay, as copies of the captured step's outputs
             lst = getattr(m, a)

@@ -231,6 +231,7 @@ class EncoderLayerTp3Fn(Fn):
         dh_in, dh_in_t = ln_bwd(dx1, h2d, lw.ln1_w, mean1, rstd1, dres=dh2)
         g = dh_in.view(B, T, D)
         g._tvl_tp3 = ((g.data_ptr(), g._version, g.numel()), dh_in_t)  # the layer below starts its backward with a tp3 GEMM on this
+        g._tvl_owned = True   # a fresh tensor nobody else holds yet: its single consumer may edit it in place (RowsOverwriteFn.backward)
         return g, None, None, None
 
 
@@ -496,6 +497,46 @@ class TextAssembleFn(Fn):
         return None, None, None, dctx, None, None
 
 
+_EXCLUSIVE_RC: int | None = None
+
+
+def _exclusive_refcount() -> int:
+    """Reference count a gradient tensor shows inside a custom node's backward when the producing node's backward just returned it and nobody
+    else holds it (measured once on a toy CPU graph of the same structure: it is a property of the autograd engine, not of the device).  A
+    tensor hook that kept the gradient, or any other holder, shows up as a larger count in RowsOverwriteFn.backward."""
+    global _EXCLUSIVE_RC
+    if _EXCLUSIVE_RC is None:
+        import sys
+
+        seen = []
+
+        class _Producer(Fn):
+            @staticmethod
+            def forward(ctx, x):
+                return x * 2
+
+            @staticmethod
+            def backward(ctx, d):
+                return d * 2
+
+        class _Consumer(Fn):
+            @staticmethod
+            def forward(ctx, h):
+                ctx.mark_dirty(h)
+                return h
+
+            @staticmethod
+            def backward(ctx, dh):
+                seen.append(sys.getrefcount(dh))
+                return dh
+
+        with torch.enable_grad():
+            x = torch.ones(1, requires_grad=True)
+            _Producer.apply(_Consumer.apply(x * 1)).sum().backward()
+        _EXCLUSIVE_RC = seen[0]
+    return _EXCLUSIVE_RC
+
+
 class RowsOverwriteFn(Fn):
     """In-place ``h[:, row0:row0+n] = src`` (base_visual_learner.py:18-23, coop_context_learner.py:124-134).
 
@@ -516,7 +557,15 @@ class RowsOverwriteFn(Fn):
         row0, n, per_sample = ctx.meta
         B, T, D = dh.shape
         img = _tp3_of(dh) if dh.is_contiguous() else None
-        if isinstance(img, hip.H2):
+        # In place only when the producer marked the tensor as exclusively owned (EncoderLayerTp3Fn.backward) AND autograd hands this node the
+        # very object the producer returned: a tensor hook on the layer output, gradient accumulation from a second consumer or retain_graph
+        # replays give a different object (or one whose flag was consumed below), and those get the clone.  The flag is cleared on read.
+        import sys
+
+        owned = bool(getattr(dh, "_tvl_owned", False)) and not torch.is_grad_enabled() and sys.getrefcount(dh) <= _exclusive_refcount()
+        if getattr(dh, "_tvl_owned", False):
+            dh._tvl_owned = False
+        if isinstance(img, hip.H2) and owned:
             # dh is the fresh tensor an encoder layer's backward just produced, with its operand image attached, and this node is its only
             # consumer: cut the rows in place -- in the fp32 gradient and in the image -- instead of cloning 49 MB and packing them again
             dh_in = dh
