@@ -217,10 +217,11 @@ def main():
                          "the line is marked cond_cache=true)")
     ap.add_argument("--cpu-steps32", type=int, default=2, help="timed CPU-oracle steps at the headline shape (bs 32)")
     ap.add_argument("--cpu-steps4", type=int, default=10, help="timed CPU-oracle steps of config C1 (CoOp-4, bs 4)")
-    ap.add_argument("--workload", choices=("vpt", "cris", "maple", "vit640"), default="vpt",
+    ap.add_argument("--workload", choices=("vpt", "cris", "maple", "vit640", "denseclip"), default="vpt",
                     help="vpt = BASELINE configs[1] (the headline line); cris = configs[2] (CRIS + CoCoOp, 416x416) and maple = configs[3] "
                          "(MaPLe depth 9) are reported for DESIGN.md; vit640 = the ViT-B/16 encoder leg of configs[4] (640x640, bs 16: "
-                         "forward + data gradient of the 12 layers; the DenseCLIP FPN / context decoder / head are not built)")
+                         "forward + data gradient of the 12 layers); denseclip = configs[4] up to the mmseg neck / head: ViT-B/16 backbone with its four FPN taps, "
+                         "context text encoder, context decoder, pixel-text score map, backward into contexts / gamma, AdamW (640x640, bs 16, 20 classes)")
     args = ap.parse_args()
 
     from tunevlseg_amd import dist as tdist
@@ -240,7 +241,72 @@ def main():
         use_private_stream(device)   # before the parameters exist
 
     cris, maple, vit640 = args.workload == "cris", args.workload == "maple", args.workload == "vit640"
-    if vit640:
+    denseclip = args.workload == "denseclip"
+    if denseclip:
+        # BASELINE configs[4] up to what reaches the mmseg neck / head (reference denseclip.py:136-169 over models.py:530-714,805-960): the frozen
+        # ViT-B/16 backbone with its four FPN taps (no tape), the context text encoder over the 20 class prompts, the context decoder against
+        # the 1 + 40^2 projected tokens, the score map; backward of a fixed cotangent on score map + text embeddings (the head's loss is mmseg's and
+        # not built: its gradient enters here) into contexts / gamma; fused AdamW on them.
+        from tunevlseg_amd.denseclip_backbone import DenseCLIPWeights
+        from tunevlseg_amd.denseclip_config import DenseCLIPConfig
+        from tunevlseg_amd.nets import DenseCLIP
+        from tunevlseg_amd.task import FusedAdamW
+
+        if "--batch" not in sys.argv:
+            args.batch = 16
+        dcfg = DenseCLIPConfig.vitb16_640(num_classes=20)
+        g = torch.Generator().manual_seed(100 + rank)
+        sot, eot = dcfg.vocab_size - 2, dcfg.vocab_size - 1
+        texts = torch.zeros(dcfg.num_classes, dcfg.context_length, dtype=torch.long)
+        for k in range(dcfg.num_classes):
+            row = [sot, *torch.randint(320, 40000, (1 + k % 3,), generator=g).tolist(), eot]
+            texts[k, : len(row)] = torch.tensor(row)
+        torch.manual_seed(12345)
+        dnet = DenseCLIP(pretrained=DenseCLIPWeights(dcfg, None, seed=0), texts=texts).to(device)
+        with torch.no_grad():
+            dnet.gamma.fill_(0.3)   # (the reference's 1e-4 start would leave the context decoder's path numerically idle)
+        opt = FusedAdamW([dnet.contexts, dnet.gamma], lr=1e-4, weight_decay=1e-4)
+        img640 = torch.randn(args.batch, 3, 640, 640, generator=g).to(device)
+        G640 = 640 // dcfg.patch_size
+        gs640 = torch.randn(args.batch, dcfg.num_classes, G640, G640, generator=g).to(device)
+        gt640 = (torch.randn(args.batch, dcfg.num_classes, dcfg.embed_dim, generator=g) * 0.1).to(device)
+        T640, D640, E640, K640, Dd = 1 + G640 * G640, dcfg.width, dcfg.output_dim, dcfg.num_classes, dcfg.decoder_width
+        fl = dcfg.layers * (24.0 * T640 * D640 * D640 + 4.0 * T640 * T640 * D640)                        # the 12 encoder layers, forward only
+        fl += 2.0 * (T640 - 1) * D640 * (3 * 16 * 16) + 2.0 * T640 * D640 * E640                         # patch conv, ln_post @ proj
+        fl += 2.0 * (T640 - 1) * D640 * 4 * D640 * (1 + 4 + 1)                                           # fpn1 (two transposed convs: HW and 4 HW pixels), fpn2
+        fl += 2.0 * T640 * E640 * Dd + dcfg.decoder_layers * (2 * 2.0 * T640 * Dd * Dd + 4.0 * K640 * T640 * Dd)   # memory projection, cross-attention K / V + products
+        fl += 2.0 * (T640 - 1) * E640 * K640 * 2                                                         # score map, and its gradient w.r.t. the text side
+        gflop_per_image = fl / 1e9   # (text tower / decoder rows over 20 classes are < 1 % and left out)
+        module = batch = None
+
+        def step():
+            opt.zero_grad()
+            text_embeddings, maps, score_map = dnet(img640)
+            loss = ops_dot(score_map.permute(0, 2, 3, 1), gs_nhwc) + ops_dot(text_embeddings, gt640)   # (the score map lives as [B, H, W, K])
+            loss.backward()
+            opt.step()
+            return loss
+
+        from tunevlseg_amd import hip as _hip
+        from tunevlseg_amd import ops as _ops
+
+        class _DotFn(_ops.Fn):   # sum(x * w) with a fixed w: the stand-in for the head's loss, one launch each way
+            @staticmethod
+            def forward(ctx, x, w):
+                ctx.save_for_backward(w)
+                ctx.shape = x.shape
+                return _hip.dot(_ops._c(x).view(-1), w.view(-1)).view(())
+
+            @staticmethod
+            def backward(ctx, d):
+                (w,) = ctx.saved_tensors
+                return _hip.scale_dev(w.view(-1), d.reshape(1).contiguous(), False).view(ctx.shape), None
+
+        gs_nhwc = gs640.permute(0, 2, 3, 1).contiguous()
+
+        def ops_dot(x, w):
+            return _DotFn.apply(x, w)
+    elif vit640:
         # configs[4]'s encoder leg (reference src/models/components/denseclip/models.py:530-714: 12 ResidualAttentionBlocks of width 768 over
         # 1 + 40^2 tokens): forward + data gradient through the frozen layers -- what a prompt-tuned DenseCLIP step would spend in the tower
         from tunevlseg_amd import ops
@@ -380,8 +446,10 @@ def main():
         out = {
             "metric": ("images/sec, train step (fwd + DiceCE + bwd + AdamW on prompts), " +
                        ("CRIS (CLIP-RN50) + CoCoOp, 416x416" if cris else "CLIPSeg ViT-B/16 + MaPLe depth 9, 352x352" if maple
-                        else "CLIPSeg ViT-B/16 + VPT-10 shallow, 352x352")) if not vit640 else
-                      "images/sec, forward + data gradient of the 12 ViT-B/16 encoder layers at 640x640 (the encoder leg of DenseCLIP ViT-B FPN; no head, no optimizer)",
+                        else "CLIPSeg ViT-B/16 + VPT-10 shallow, 352x352")) if not (vit640 or denseclip) else
+                      ("images/sec, DenseCLIP ViT-B/16 FPN 640x640 up to the mmseg neck / head: frozen backbone + 4 FPN taps, context text encoder, context decoder, "
+                       "score map; backward of a fixed cotangent into contexts / gamma; AdamW" if denseclip else
+                       "images/sec, forward + data gradient of the 12 ViT-B/16 encoder layers at 640x640 (the encoder leg of DenseCLIP ViT-B FPN; no head, no optimizer)"),
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": (("f32 (fp32-equivalent: operands split into 2 fp16 pieces with exact power-of-two scales [3x3 convs with C_in % 32 == 0 and C_out >= 128, "
@@ -393,7 +461,9 @@ def main():
             "data": "synthetic", "per_gpu": round(value / world, 2),
             "config": {"workload": ("CRIS (CLIP-RN50 + cross-attn decoder) + CoCoOp meta-net, 416x416, bs=32/GPU (BASELINE configs[2])" if cris else
                                     "CLIPSeg ViT-B/16 + MaPLe (coupled V+L prompts, depth=9), 352x352, bs=32/GPU (BASELINE configs[3])" if maple else
-                                    "ViT-B/16 encoder leg of DenseCLIP ViT-B FPN 640x640, bs=16/GPU (BASELINE configs[4]: encoder layers only, parity unpinned)" if vit640 else
+                                    "ViT-B/16 encoder leg of DenseCLIP ViT-B FPN 640x640, bs=16/GPU (BASELINE configs[4]: encoder layers only)" if vit640 else
+                                    "DenseCLIP ViT-B/16 FPN 640x640, 20 classes, bs=16/GPU (BASELINE configs[4]) up to after_extract_feat; the mmseg FPN neck / FPNHead and "
+                                    "their loss are not built (no source in the reference tree)" if denseclip else
                                     "CLIPSeg ViT-B/16 + VPT-shallow (10 visual prompts), 352x352, bs=32/GPU (BASELINE configs[1])"),
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
                        "weights": "seeded random init (RN50 CRIS geometry)" if cris else "seeded random init (rd64 geometry)",
