@@ -373,6 +373,15 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     metrics = module.epoch_metrics("train") if module is not None else None
+    # sticky device-side flags of the loss / optimiser kernels: a step that went NaN / Inf anywhere in the run ends the benchmark with a non-zero
+    # exit code and no result line (a throughput measured on NaNs is not a measurement)
+    try:
+        hip.check_finite(device, what=f"bench.py rank {rank}")
+        if not torch.isfinite(loss.detach()).item():
+            raise FloatingPointError(f"bench.py rank {rank}: the last step's loss is {float(loss)}")
+    except FloatingPointError as e:
+        print(json.dumps({"error": str(e), "rank": rank, "workload": args.workload}), flush=True)
+        raise SystemExit(3)
 
     # ---- roofline of the dominant kernel: HIP events (on torch's current stream = the launch stream) around every GEMM launch of
     # 2 extra, untimed steps.  achieved = algorithmic FLOPs (2*M*N*K per launch) / summed launch time.

@@ -29,7 +29,7 @@ typedef void* tvlStream_t; /* hipStream_t */
 /* Bumped on every incompatible change of a signature or struct below.  3: tvl_dicece_stats gained `work`, tvl_split_planes /
  * tvl_gemm_planes removed (round 2).  4: tvl_text_assemble gained `vocab` (rows of the embedding table: ids outside it give NaN rows
  * instead of a wild read); tvlGemmTp3Args gained workspace / workspace_bytes; tvl_resize_u8 / tvl_augment_u8 added.  5: tvl_dicece_loss, tvl_mlp64_*, tvl_h2_zero_rows added; tvl_upconv_taps_fwd gained `work`; tvl_attn_h2_bwd gained `only_block`, tvl_h2k_gather_rows added;
- * tvl_layernorm_fwd_h2 / _bwd_h2 gained max_slot / tag (largest row norm by tagged atomicMax).  6 (round 4): TVL_ACT_GELU, the DenseCLIP entries
+ * tvl_layernorm_fwd_h2 / _bwd_h2 gained max_slot / tag (largest row norm by tagged atomicMax).  6 (round 4): tvl_dicece_loss / tvl_adamw gained `nonfinite` (sticky device-side NaN / Inf flags), TVL_ACT_GELU, the DenseCLIP entries
  * (tvl_groupnorm_*, tvl_tconv2x2_unshuffle, tvl_colscale_*).  The Python binding refuses a library whose tvl_abi_version() differs. */
 #define TVL_ABI_VERSION 6
 
@@ -208,7 +208,7 @@ int tvl_dicece_stats(const float* logits, const float* target, double* fsum, int
  * elements), float64 inside, fixed summation order, written as one fp32 scalar on the device (no host round trip, one launch instead of
  * the dozen tensor-library launches of the same arithmetic) */
 int tvl_dicece_loss(const double* fsum, float* loss, int32_t B, int64_t N, float lambda_dice, float lambda_ce,
-                    float smooth_nr, float smooth_dr, tvlStream_t stream);
+                    float smooth_nr, float smooth_dr, int32_t* nonfinite, tvlStream_t stream);   /* nonfinite (may be NULL): += 1 when the loss is NaN / Inf */
 /* dlogits = gscale * ( lambda_dice * dDice/dlogit + lambda_ce * (p - t)/(B*N) ), using fsum from tvl_dicece_stats */
 int tvl_dicece_bwd(const float* logits, const float* target, const double* fsum, float* dlogits,
                    int32_t B, int64_t N, float lambda_dice, float lambda_ce, float smooth_nr, float smooth_dr,
@@ -258,7 +258,7 @@ int tvl_scale_dev(const float* x, const float* ratio, int32_t one_minus, float* 
 /* ---- optimiser + misc ---- */
 /* torch.optim.AdamW step over a flat fp32 buffer (decoupled weight decay); step_t is 1-based */
 int tvl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-              float weight_decay, int32_t step_t, float grad_scale, tvlStream_t stream);
+              float weight_decay, int32_t step_t, float grad_scale, int32_t* nonfinite, tvlStream_t stream);   /* nonfinite (may be NULL): set to 1 when a gradient is NaN / Inf */
 int tvl_fill(float* p, float val, int64_t n, tvlStream_t stream);
 /* y = a*x + b*y */
 int tvl_axpby(const float* x, float a, float* y, float b, int64_t n, tvlStream_t stream);

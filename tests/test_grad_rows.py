@@ -54,3 +54,48 @@ def test_rows_that_straddle_a_block_fall_back_to_the_full_backward(layer):
     _, g0 = run(lw, spec, x, dout, None)
     _, g1 = run(lw, spec, x, dout, (T - n, n))
     assert torch.equal(g0, g1)
+
+
+def test_a_hook_that_keeps_the_gradient_sees_it_unmodified():
+    """RowsOverwriteFn.backward cuts the overwritten rows of the incoming gradient IN PLACE only when it is the fresh tensor the layer above's
+    backward returned and nobody else holds it; a tensor hook that keeps the gradient of the overwritten activations must see the true
+    gradient (non-zero prompt rows), and the parameter gradients must not depend on the hook being there."""
+    from functools import partial
+
+    from tunevlseg_amd import nets
+    from tunevlseg_amd.nets.context_learner import VPTContextLearner
+
+    def run(with_hook):
+        torch.manual_seed(0)
+        net = nets.VPTCLIPSeg(context_learner=partial(VPTContextLearner, prompt_depth=3, num_context=10),
+                              model_cfg={"pretrained_model_name_or_path": "random:rd64:seed=3"}, use_new_last_layer=False).cuda()
+        kept = []
+        if with_hook:
+            from tunevlseg_amd import ops
+
+            orig = ops.RowsOverwriteFn.apply
+
+            def hooked(h, src, row0):
+                out = orig(h, src, row0)
+                out.register_hook(lambda g: kept.append((g, g.detach().clone())) and None)
+                return out
+
+            ops.RowsOverwriteFn.apply = hooked
+        try:
+            g = torch.Generator().manual_seed(1)
+            pix = torch.randn(4, 3, 352, 352, generator=g).cuda()
+            ids = torch.tensor([[49406, 320, 1125, 49407]] * 4).cuda()
+            logits = net(text_input={"input_ids": ids, "attention_mask": torch.ones_like(ids)}, image_input=pix)
+            (logits * torch.randn(logits.shape, generator=g).cuda()).sum().backward()
+        finally:
+            if with_hook:
+                ops.RowsOverwriteFn.apply = orig
+        return net.context_learner.context_vectors.grad.detach().clone(), kept
+
+    g_plain, _ = run(False)
+    g_hook, kept = run(True)
+    assert kept, "the hook never fired"
+    for held, snapshot in kept:
+        assert torch.equal(held, snapshot)            # what the hook kept was not edited behind its back
+        assert held[:, -10:].abs().max().item() > 0   # ... and still holds the prompt rows' gradient
+    assert (g_plain - g_hook).abs().max().item() <= 1e-6 * g_plain.abs().max().item()

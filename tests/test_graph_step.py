@@ -91,3 +91,87 @@ def test_trainer_graph_step_matches_the_eager_trainer(tmp_path):
     finally:
         torch.cuda.synchronize()
         torch.cuda.set_stream(default)
+
+
+def test_host_entries_of_the_batch_stay_out_of_the_capture():
+    """The reference's collate leaves ``mask_shape`` on the CPU and puts it FIRST in the dict (RaggedCollator -> DeviceTransform): the capture
+    takes its device from the device tensors and neither keys nor copies host entries."""
+    from tests.test_train_gpu import tiny_module
+    from tunevlseg_amd.graph import GraphedStep
+
+    data = batches(4)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        module = tiny_module(depth=1)
+        module.setup("fit")
+        opt = module.configure_optimizers()["optimizer"]
+        stepper = GraphedStep(module, opt)
+        for i, b in enumerate(data):
+            b = {"mask_shape": torch.tensor([[64 + i, 64]] * 4), "name": [f"img{i}"] * 4, **b}   # host tensor first, a non-tensor entry, values change per batch
+            loss = stepper(b)
+            opt.step()
+            assert torch.isfinite(loss).item()
+        torch.cuda.synchronize()
+    assert stepper.replays == len(data) - 1 and len(stepper._graphs) == 1
+
+
+def shared_attn_module(dropout: float):
+    from functools import partial
+
+    from tunevlseg_amd import nets
+    from tunevlseg_amd.nets.context_learner import SharedAttnLearner
+    from tunevlseg_amd.task import DiceCELoss, FusedAdamW, ImageTextMaskModule
+
+    torch.manual_seed(0)
+    net = nets.SharedAttnCLIPSeg(
+        context_learner=partial(SharedAttnLearner, prompt_depth=2, num_context=3, vector_std=0.02, use_unified_projection=False,
+                                unified_projector=partial(torch.nn.TransformerEncoderLayer, nhead=4, dim_feedforward=48, dropout=dropout, norm_first=True)),
+        model_cfg={"pretrained_model_name_or_path": "random:tiny:seed=11"}, use_new_last_layer=False)
+    return ImageTextMaskModule(net, DiceCELoss(sigmoid=True, lambda_dice=1, lambda_ce=0.2), optimizer=partial(FusedAdamW, lr=2e-3), scheduler=None).cuda()
+
+
+def test_a_step_with_train_mode_dropout_is_not_replayed():
+    """ops.DropoutFn takes its (seed, call index) from the host: frozen into a graph, every replay would repeat the capture's mask.  Such a shape
+    stays eager -- and draws exactly the masks a stepper-free loop draws (the capture attempt puts the call counter back)."""
+    from tunevlseg_amd import ops
+    from tunevlseg_amd.graph import GraphedStep
+
+    data = batches(4)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        runs = []
+        for graphed in (False, True):
+            torch.manual_seed(7)
+            ops._dropout_calls = 0
+            module = shared_attn_module(dropout=0.25)
+            module.setup("fit")
+            module.net.context_learner.train()
+            opt = module.configure_optimizers()["optimizer"]
+            stepper = GraphedStep(module, opt) if graphed else None
+            losses = []
+            for b in data:
+                if stepper is None:
+                    opt.zero_grad()
+                    loss = module.training_step(b, 0)
+                    loss.backward()
+                else:
+                    loss = stepper(b)
+                opt.step()
+                losses.append(loss.item())
+            runs.append((losses, trainable(module)))
+        torch.cuda.synchronize()
+    assert stepper.replays == 0 and len(stepper._eager_only) == 1 and not stepper._graphs
+    assert runs[0][0] == pytest.approx(runs[1][0], abs=1e-6)
+    for k, p in runs[0][1].items():
+        assert (p - runs[1][1][k]).abs().max().item() <= 1e-6 * max(1.0, p.abs().max().item()), k
+    assert len({round(v, 5) for v in runs[0][0]}) == len(data)   # the masks (and the data) differ from step to step
+    # without dropout the same learner IS captured and replayed
+    with torch.cuda.stream(torch.cuda.Stream()):
+        module = shared_attn_module(dropout=0.0)
+        module.setup("fit")
+        module.net.context_learner.train()
+        opt = module.configure_optimizers()["optimizer"]
+        stepper = GraphedStep(module, opt)
+        for b in data:
+            stepper(b)
+            opt.step()
+        torch.cuda.synchronize()
+    assert stepper.replays == len(data) - 1

@@ -222,3 +222,15 @@ def test_graphed_step_keys_batches_by_tensor_shapes_only():
     other = batch(6)
     other["image"] = other["image"].double()
     assert _key(batch(6)) != _key(other)
+
+
+def test_ranks_sharing_one_device_are_refused_without_the_debug_flag(monkeypatch):
+    """One process per GPU is a requirement: TVL_DIST_BACKEND=gloo, which puts every rank on cuda:0, needs
+    TVL_ALLOW_SHARED_DEVICE=1 to say that it is a debugging rehearsal."""
+    from tunevlseg_amd import dist as tdist
+
+    for k, v in (("RANK", "1"), ("LOCAL_RANK", "1"), ("WORLD_SIZE", "4"), ("TVL_DIST_BACKEND", "gloo")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("TVL_ALLOW_SHARED_DEVICE", raising=False)
+    with pytest.raises(RuntimeError, match="TVL_ALLOW_SHARED_DEVICE"):
+        tdist.init_distributed("cuda")

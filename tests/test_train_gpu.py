@@ -199,7 +199,7 @@ def test_two_rank_step_on_hip_path_equals_global_batch_step(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   TVL_DIST_BACKEND="gloo", PYTHONPATH=str(root))
+                   TVL_DIST_BACKEND="gloo", TVL_ALLOW_SHARED_DEVICE="1", PYTHONPATH=str(root))
         procs.append(subprocess.Popen([sys.executable, str(root / "tests" / "ddp_worker.py"), str(tmp_path)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -331,3 +331,41 @@ paths: {{output_dir: {tmp_path / 'out'}}}
     cfg2["data"] = {"batch_size": 4}
     with pytest.raises(ValueError, match="no buildable `data` node"):
         T.train(cfg2)
+
+
+@pytest.mark.gpu
+def test_non_finite_steps_raise_instead_of_logging_nan(tmp_path):
+    """The loss and optimiser kernels keep sticky device-side NaN / Inf flags (hip.nonfinite_flags); Trainer.fit reads them at the end of an
+    epoch and raises, bench.py exits non-zero: a non-finite step cannot pass as a number."""
+    from tunevlseg_amd import hip, ops
+    from tunevlseg_amd.trainer import SyntheticImageTextMaskLoader, Trainer
+
+    hip.check_finite()   # clear whatever earlier tests left
+    logits = torch.randn(2, 1, 16, 16).cuda().requires_grad_(True)
+    mask = (torch.rand(2, 1, 16, 16) > 0.5).float().cuda()
+    loss, _ = ops.DiceCELossFn.apply(logits, mask, 1.0, 0.2, 0.5)
+    assert torch.isfinite(loss).item()
+    hip.check_finite()
+    bad = logits.detach().clone()
+    bad[0, 0, 3, 3] = float("nan")
+    loss, _ = ops.DiceCELossFn.apply(bad, mask, 1.0, 0.2, 0.5)
+    with pytest.raises(FloatingPointError, match="non-finite loss"):
+        hip.check_finite()
+    hip.check_finite()   # reading cleared the flags
+    # a NaN gradient that reaches the optimiser: finite loss, poisoned parameter gradient
+    module = tiny_module(depth=1)
+    module.setup("fit")
+    opt = module.configure_optimizers()["optimizer"]
+    opt.zero_grad()
+    opt.flat.grad[3] = float("inf")
+    opt.step()
+    with pytest.raises(FloatingPointError, match="non-finite gradients"):
+        hip.check_finite()
+    # ... and through the trainer: parameters made NaN -> every loss NaN -> fit raises at the end of the first epoch
+    module = tiny_module(depth=1)
+    with torch.no_grad():
+        module.net.context_learner.context_vectors.fill_(float("nan"))
+    tr = SyntheticImageTextMaskLoader(2, 2, 64, "cuda", seed=1, vocab=64, bos=62, eos=63, pad=1, max_len=6)
+    with pytest.raises(FloatingPointError):
+        Trainer(max_epochs=2, min_epochs=1, default_root_dir=str(tmp_path), log_fn=lambda *_: None).fit(module, tr, None)
+    hip.check_finite()

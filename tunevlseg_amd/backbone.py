@@ -146,6 +146,7 @@ class CLIPSegBackbone(_Node):
             }
             self._prep_key = key
             self._pos_cache.clear()
+            hip._built(device=dev)   # built on whichever stream asked first; the text tower's side stream reads it next
         return self._prep
 
     def vision_pos(self, height: int, width: int) -> torch.Tensor:
@@ -166,6 +167,7 @@ class CLIPSegBackbone(_Node):
                 patch = F.interpolate(patch, size=(nh, nw), mode="bicubic", align_corners=False)
                 out = torch.cat((pos[:1], patch.permute(0, 2, 3, 1).reshape(-1, dim)), 0)
             self._pos_cache[key] = out.contiguous()
+            hip._built(self._pos_cache[key])
         return self._pos_cache[key]
 
     def _apply(self, fn, *a, **k):

@@ -268,6 +268,7 @@ class CRISWeights(_Node):
         }
         self._prep, self._prep_key = prep, key
         self._const.clear()
+        hip._built(device=dev)   # built on whichever stream asked first; other streams (the text encoder's side stream) read it next
         return prep
 
     # ------------------------------------------------------------------ input-independent constants (cached per size)

@@ -43,7 +43,10 @@ struct AttnParams {
 template <int DH>
 struct TileRegs {
     static constexpr int N = (32 * DH / 4 + 255) / 256;
-    float4 v[N];
+    // a native vector, not float4: HIP's float4 is a struct whose copy is a memcpy, and memcpys in and out of a two-element array keep the
+    // array a stack object (d_h = 64: 80 B of scratch per lane in all three kernels) -- vector loads / stores are promoted to registers
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    vec4 v[N];
 };
 template <int DH>
 __device__ __forceinline__ void tile_gload(TileRegs<DH>& s, const float* __restrict__ base, int ts, int row0, int T) {
@@ -53,7 +56,7 @@ __device__ __forceinline__ void tile_gload(TileRegs<DH>& s, const float* __restr
         if (idx < 32 * DH / 4) {
             int r = row0 + idx / (DH / 4);
             r = r < T ? r : T - 1;
-            s.v[i] = *reinterpret_cast<const float4*>(base + (long)r * ts + 4 * (idx % (DH / 4)));
+            s.v[i] = *reinterpret_cast<const typename TileRegs<DH>::vec4*>(base + (long)r * ts + 4 * (idx % (DH / 4)));
         }
     }
 }
@@ -62,7 +65,7 @@ __device__ __forceinline__ void tile_sstore(const TileRegs<DH>& s, float* __rest
 #pragma unroll
     for (int i = 0; i < TileRegs<DH>::N; ++i) {
         const int idx = threadIdx.x + 256 * i;
-        if (idx < 32 * DH / 4) *reinterpret_cast<float4*>(&lds[(idx / (DH / 4)) * (DH + 4) + 4 * (idx % (DH / 4))]) = s.v[i];
+        if (idx < 32 * DH / 4) *reinterpret_cast<typename TileRegs<DH>::vec4*>(&lds[(idx / (DH / 4)) * (DH + 4) + 4 * (idx % (DH / 4))]) = s.v[i];
     }
 }
 

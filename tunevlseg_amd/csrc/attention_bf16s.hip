@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16s_kernel(BwdParams p) 
 }
 
 template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p) {
+__global__ __launch_bounds__(256, DH == 64 ? 1 : 2) void attn_bwd_dkdv_bf16s_kernel(BwdParams p) {
     TVL_KERNEL_ENTRY();
     constexpr int LDKB = Geo<DH>::LDKB, LDVB = Geo<DH>::LDVB, KS = Geo<DH>::KS, NDB = Geo<DH>::NDB;
     (void)LDVB;

@@ -254,10 +254,11 @@ __global__ void scale_dev_kernel(const float* __restrict__ x, const float* __res
 
 // ---- optimiser / misc -----------------------------------------------------------------------
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale, int* __restrict__ nonfinite) {
     TVL_KERNEL_ENTRY();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gr = g[i] * gscale;
+        if (nonfinite && !(fabsf(gr) <= 3.4028235e38f)) nonfinite[0] = 1;   // sticky flag (every writer stores the same value): a non-finite gradient reached the update
         float pv = p[i] * (1.0f - lr * wd);
         const float mv = b1 * m[i] + (1.0f - b1) * gr;
         const float vv = b2 * v[i] + (1.0f - b2) * gr * gr;
@@ -516,13 +517,13 @@ extern "C" int tvl_scale_dev(const float* x, const float* ratio, int32_t one_min
 }
 
 extern "C" int tvl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, int32_t step_t, float grad_scale, tvlStream_t stream) {
+                         float weight_decay, int32_t step_t, float grad_scale, int32_t* nonfinite, tvlStream_t stream) {
     TVL_REQUIRE(p && g && m && v && n > 0 && step_t >= 1, "tvl_adamw: bad arguments");
     // bias corrections in double on the host, as torch.optim.AdamW computes them (fp32 powf is ~1e-5 off in the step size at small t)
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step_t));
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step_t));
     hipLaunchKernelGGL(adamw_kernel, GRID_FOR((long)n), dim3(256), 0, S_(stream), p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay,
-                       bc1, bc2_sqrt, grad_scale);
+                       bc1, bc2_sqrt, grad_scale, nonfinite);
     TVL_LAUNCH_CHECK("tvl_adamw");
     return 0;
 }

@@ -167,13 +167,19 @@ bool use_m16() {
 }
 
 int launch_h2(const Tp3Params& p, int bm, int epi, hipStream_t s) {
+#ifdef TVL_EXPERIMENTS
     if (bm == 128) return tvl_gemm_h2_w4(&p, bm, epi, s);
+#else
+    if (bm == 128 || bm == 2564 || bm == 1924 || bm == 2565 || bm == 1925) { tvl_set_error("tvl_gemm_h2: tile_m = %d selects an experiment kernel (build with make EXPERIMENTS=1)", bm); return 1; }
+#endif
     if ((bm == 2566 || (bm == 256 && use_m16())) && p.K >= 96) return tvl_gemm_h2m_t256(&p, epi, s);
     if ((bm == 1926 || (bm == 192 && use_m16())) && p.K >= 96) return tvl_gemm_h2m_t192(&p, epi, s);
     if (bm == 2566 || bm == 1926) bm = bm / 10;
     if (bm == 2560 || bm == 1920) bm = bm / 10;   // explicit first-generation tiles (tools/bench_layer_gemms.py)
+#ifdef TVL_EXPERIMENTS
     if (bm == 2564 || bm == 1924) return tvl_gemm_h2_ns4(&p, bm / 10, epi, s);
     if (bm == 2565 || bm == 1925) return tvl_gemm_h2_ns5(&p, bm / 10, epi, s);
+#endif
     // the epilogues the vision tower's forward needs (QKV -> tp3, fc1 -> QuickGELU -> tp3 + z) + the plain ones; others: generic
     if (bm == 256) {
         switch (epi) {

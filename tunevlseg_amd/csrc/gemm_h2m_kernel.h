@@ -529,7 +529,11 @@ int launch_m(const Tp3Params& p0, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess) return 1;
     // multi-round launches of the image-writing epilogues walk their tiles persistently (see the kernel): needs the caller's workspace
     // (PERSIST_GRID x 8 waves x BM/2 x 64 floats) and at least two tiles per workgroup of every XCD
+#ifdef TVL_EXPERIMENTS   // (make EXPERIMENTS=1: the persistent instantiations spill 33-37 registers inside their tile loop and are not part of the product library)
     constexpr bool CAN_PERSIST = !KS && !CONV && EPI >= 0 && (EPI & (E_H2OUT | E_PRE)) != 0;
+#else
+    constexpr bool CAN_PERSIST = false;
+#endif
     if constexpr (CAN_PERSIST) {
         constexpr int PERSIST_GRID = 256;
         constexpr size_t work_bytes = (size_t)PERSIST_GRID * 8 * (BM / 2 / 16 * 4) * 64 * sizeof(float4);

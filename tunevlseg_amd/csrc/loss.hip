@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void dicece_bwd_kernel(const float* __restrict
 // loss = lambda_dice * mean_b [1 - (2 I_b + snr) / (D_b + sdr)] + lambda_ce * (sum_b bce_b) / (B N), float64 inside, one workgroup, fixed
 // summation order (thread-strided partial sums, then a shared-memory tree): bitwise reproducible like fsum itself
 __global__ __launch_bounds__(256) void dicece_loss_kernel(const double* __restrict__ fsum, float* __restrict__ loss, int B, double n_pix,
-                                                          double lambda_dice, double lambda_ce, double snr, double sdr) {
+                                                          double lambda_dice, double lambda_ce, double snr, double sdr, int* __restrict__ nonfinite) {
     TVL_KERNEL_ENTRY();
     __shared__ double sd[256], sb[256];
     double d = 0.0, c = 0.0;
@@ -111,7 +111,11 @@ __global__ __launch_bounds__(256) void dicece_loss_kernel(const double* __restri
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = (float)(lambda_dice * (sd[0] / (double)B) + lambda_ce * (sb[0] / ((double)B * n_pix)));
+    if (threadIdx.x == 0) {
+        const float l = (float)(lambda_dice * (sd[0] / (double)B) + lambda_ce * (sb[0] / ((double)B * n_pix)));
+        loss[0] = l;
+        if (nonfinite && !(fabsf(l) <= 3.4028235e38f)) atomicAdd(nonfinite, 1);   // sticky device-side flag: NaN / Inf losses are counted, never waited for
+    }
 }
 
 }  // namespace
@@ -152,10 +156,10 @@ extern "C" int tvl_dicece_bwd(const float* logits, const float* target, const do
 }
 
 extern "C" int tvl_dicece_loss(const double* fsum, float* loss, int32_t B, int64_t N, float lambda_dice, float lambda_ce,
-                               float smooth_nr, float smooth_dr, tvlStream_t stream) {
+                               float smooth_nr, float smooth_dr, int32_t* nonfinite, tvlStream_t stream) {
     TVL_REQUIRE(fsum && loss && B > 0 && N > 0, "tvl_dicece_loss: bad arguments");
     hipLaunchKernelGGL(dicece_loss_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), fsum, loss, (int)B, (double)N,
-                       (double)lambda_dice, (double)lambda_ce, (double)smooth_nr, (double)smooth_dr);
+                       (double)lambda_dice, (double)lambda_ce, (double)smooth_nr, (double)smooth_dr, nonfinite);
     TVL_LAUNCH_CHECK("tvl_dicece_loss");
     return 0;
 }

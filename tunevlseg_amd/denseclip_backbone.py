@@ -140,6 +140,7 @@ class DenseCLIPWeights(_Node):
         }
         self._prep, self._prep_key = prep, key
         self._const.clear()
+        hip._built(device=dev)   # built on whichever stream asked first; other streams (the text encoder's side stream) read it next
         return prep
 
     def position_table(self, H: int, W: int) -> torch.Tensor:

@@ -28,6 +28,12 @@ def init_distributed(device_type: str = "cuda") -> tuple[int, int, int]:
         # RCCL ("nccl" on ROCm) for GPUs; TVL_DIST_BACKEND=gloo lets the N>1 code path be rehearsed with several ranks on ONE
         # device (RCCL refuses duplicate devices), gloo staging the tiny gradient buffer through the host
         backend = os.environ.get("TVL_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+        if device_type == "cuda" and backend == "gloo" and os.environ.get("TVL_ALLOW_SHARED_DEVICE") != "1":
+            # One process per device is a requirement: with several ranks on one device, steps went non-finite in round 3 (first
+            # step only, about half of the 4-rank runs) for a reason that was never pinned to this code or to the platform.  The rehearsal
+            # mode stays available for debugging, behind a flag that says what it is.
+            raise RuntimeError("TVL_DIST_BACKEND=gloo puts every rank on cuda:0: unsupported (one process per GPU; DESIGN.md §6).  For debugging only, "
+                               "set TVL_ALLOW_SHARED_DEVICE=1.")
         if device_type == "cuda":
             torch.cuda.set_device(0 if backend == "gloo" else local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -43,7 +43,9 @@ def use_private_stream(device=None) -> "torch.cuda.Stream":
 def _device_tensors(batch: Mapping[str, Any]) -> dict:
     """The entries a captured step can read: device tensors.  What the data pipeline leaves on the host (``mask_shape`` of the reference's
     collate, file names) is only read by Python outside the step, so it is neither part of the shape key nor copied per replay."""
-    return {k: v for k, v in batch.items() if isinstance(v, torch.Tensor) and v.is_cuda}
+    tensors = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    on_device = {k: v for k, v in tensors.items() if v.is_cuda}
+    return on_device or tensors   # (a batch without any device tensor -- the host-side unit tests of the key -- keeps all of them)
 
 
 def _key(batch: Mapping[str, Any]):
@@ -94,7 +96,7 @@ class GraphedStep:
 
     def _capture(self, batch):
         on_device = _device_tensors(batch)
-        if not on_device:
+        if not any(v.is_cuda for v in on_device.values()):
             raise RuntimeError("GraphedStep: the batch holds no device tensor")
         dev = next(iter(on_device.values())).device
         stream = torch.cuda.current_stream(dev)

@@ -18,7 +18,7 @@ if os.environ.get("TVL_POISON") == "1":
     # Debug mode: every buffer this package asks torch for uninitialised comes back full of NaN patterns (fp32 NaN; bytes
     # 0x7E = fp16 / bf16 NaN pairs in the operand images), so a kernel that reads a location its producer did not write shows up in the
     # single-process parity suite instead of only when another process's leftovers happen to sit there.  `python -m pytest tests -m gpu` under it.
-    _torch_empty, _torch_empty_like = torch.empty, torch.empty_like
+    _torch_empty, _torch_empty_like, _torch_empty_strided, _new_empty = torch.empty, torch.empty_like, torch.empty_strided, torch.Tensor.new_empty
 
     def _poisoned(t):
         if t.is_cuda:
@@ -26,10 +26,14 @@ if os.environ.get("TVL_POISON") == "1":
                 t.fill_(float("nan"))
             elif t.dtype == torch.uint8:
                 t.fill_(0x7E)
+            elif t.dtype in (torch.int32, torch.int64, torch.int16, torch.int8):   # index / count / flag buffers: a huge negative value (a wild index faults, a count is absurd)
+                t.fill_(torch.iinfo(t.dtype).min + 7)
         return t
 
     torch.empty = lambda *a, **k: _poisoned(_torch_empty(*a, **k))
     torch.empty_like = lambda *a, **k: _poisoned(_torch_empty_like(*a, **k))
+    torch.empty_strided = lambda *a, **k: _poisoned(_torch_empty_strided(*a, **k))
+    torch.Tensor.new_empty = lambda self, *a, **k: _poisoned(_new_empty(self, *a, **k))
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["TVL_HIP_LIB"]) if os.environ.get("TVL_HIP_LIB") else _HERE / "csrc" / "libtvl_hip.so"   # (override: a `make DIAG=1` build for the tools)
@@ -139,7 +143,7 @@ _SIGS = {
     "tvl_upconv_taps_bwd": [_P, _P, _I, _P, _I, _I, _I, _I],
     "tvl_dicece_stats": [_P, _P, _P, _P, _P, _P, _I, _L, _F],
     "tvl_dicece_bwd": [_P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _P],
-    "tvl_dicece_loss": [_P, _P, _I, _L, _F, _F, _F, _F],
+    "tvl_dicece_loss": [_P, _P, _I, _L, _F, _F, _F, _F, _P],
     "tvl_mlp64_pack": [_P, _P, _I, _F, _F, _P],
     "tvl_mlp64_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F],
     "tvl_mlp64_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _F],
@@ -149,7 +153,7 @@ _SIGS = {
     "tvl_augment_u8": [_P, _P, _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _I, _I, _I],
     "tvl_mix": [_P, _P, _P, _P, _L],
     "tvl_scale_dev": [_P, _P, _I, _P, _L],
-    "tvl_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F],
+    "tvl_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "tvl_fill": [_P, _F, _L],
     "tvl_axpby": [_P, _F, _P, _F, _L],
     "tvl_bias_act": [_P, _P, _P, _L, _I, _I],
@@ -249,6 +253,17 @@ def load():
 _CONST_I32: dict = {}
 
 
+def _built(t: torch.Tensor | None = None, device=None) -> None:
+    """End of a ONE-TIME construction on the device (constant tables, packed weight images, slot pools, ``prepared()`` trees): wait until the
+    stream that built it has finished.  Such objects are built lazily, on whatever stream first asks -- and consumed, from the next line on,
+    by any stream or thread of the process (the text tower's side stream, autograd's worker, a capture stream): only the builder's stream is
+    ordered behind the construction, so the construction is made complete before the object is handed out.  Costs one stream
+    synchronisation per object per process, all in the first step; steady-state steps never get here."""
+    dev = t.device if t is not None else device
+    if dev is not None and torch.device(dev).type == "cuda" and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(dev).synchronize()
+
+
 def const_i32(values, device) -> torch.Tensor:
     """Device int32 tensor of a small host-side index list (token maps, row maps), built once per (values, device): the per-step
     ``torch.tensor(list, device=...)`` it replaces is a pageable host-to-device copy, which also forbids HIP-graph capture."""
@@ -258,6 +273,7 @@ def const_i32(values, device) -> torch.Tensor:
         if len(_CONST_I32) > 4096:
             _CONST_I32.clear()
         t = _CONST_I32[key] = torch.tensor(key[0], dtype=torch.int32, device=device)
+        _built(t)
     return t
 
 
@@ -275,7 +291,35 @@ def const_f32(value: float, device) -> torch.Tensor:
         if len(_CONST_F32) > 4096:
             _CONST_F32.clear()
         t = _CONST_F32[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+        _built(t)
     return t
+
+
+_NONFINITE: dict = {}
+
+
+def nonfinite_flags(device) -> torch.Tensor:
+    """int32 [2] on the device: [0] counts the losses that came out NaN / Inf (``tvl_dicece_loss``), [1] is set when a NaN / Inf gradient reached
+    the optimiser update (``tvl_adamw``).  Written by the kernels themselves -- nothing in a step waits for them; :func:`check_finite` reads
+    them where the host synchronises anyway (end of an epoch, end of the benchmark's timed region)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    t = _NONFINITE.get(key)
+    if t is None:
+        t = _NONFINITE[key] = torch.zeros(2, device=torch.device("cuda", key), dtype=torch.int32)
+        torch.cuda.current_stream(t.device).synchronize()
+    return t
+
+
+def check_finite(device=None, what: str = "training") -> None:
+    """Raise ``FloatingPointError`` if any step since the last call produced a non-finite loss or gradient (reads and clears the device flags)."""
+    for key, t in list(_NONFINITE.items()):
+        if device is not None and torch.device(device).index not in (None, key):
+            continue
+        bad_loss, bad_grad = (int(v) for v in t.tolist())
+        if bad_loss or bad_grad:
+            t.zero_()
+            raise FloatingPointError(f"{what}: {bad_loss} step(s) with a non-finite loss" + (", non-finite gradients reached the optimiser" if bad_grad else "")
+                                     + f" on cuda:{key}")
 
 
 def _stream():
@@ -488,6 +532,7 @@ def weight_tp3(W: torch.Tensor) -> Tp3:
     img = tp3_pack(W)
     if not W.requires_grad and W._base is None and W.grad_fn is None and getattr(W, "_tvl_frozen", False):
         W._tvl_tp3 = ((W.data_ptr(), W._version), img)
+        _built(img.buf)
     return img
 
 
@@ -1104,6 +1149,7 @@ def const_i64(values, device) -> torch.Tensor:
         if len(_CONST_I64) > 1024:
             _CONST_I64.clear()
         t = _CONST_I64[key] = torch.tensor(key[0], dtype=torch.int64, device=device)
+        _built(t)
     return t
 
 
@@ -1313,7 +1359,7 @@ def dicece_loss(fsum, N: int, lambda_dice, lambda_ce, smooth_nr=1e-5, smooth_dr=
     """fp32 scalar DiceCE loss from the per-sample sums of :func:`dicece_stats` (one launch, float64 inside)."""
     loss = torch.empty((), device=fsum.device, dtype=torch.float32)
     _call("tvl_dicece_loss", _p(fsum, torch.float64), _p(loss), fsum.shape[0], int(N), float(lambda_dice), float(lambda_ce),
-          float(smooth_nr), float(smooth_dr))
+          float(smooth_nr), float(smooth_dr), nonfinite_flags(fsum.device)[0:1].data_ptr())
     return loss
 
 
@@ -1385,7 +1431,7 @@ def scale_dev(x, ratio, one_minus: bool):
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_t: int, grad_scale: float = 1.0):
     _call("tvl_adamw", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
-          int(step_t), float(grad_scale))
+          int(step_t), float(grad_scale), nonfinite_flags(p.device)[1:2].data_ptr())
 
 
 def fill(t, val: float):

@@ -56,6 +56,7 @@ class LayerWeights:
                 ("wqkv", self.wqkv), ("wo", self.wo), ("w1", self.w1), ("w2", self.w2),
                 ("wqkv_t", self.wqkv_t if self.wqkv_t is not None else t(self.wqkv)), ("wo_t", self.wo_t if self.wo_t is not None else t(self.wo)),
                 ("w1_t", self.w1_t if self.w1_t is not None else t(self.w1)), ("w2_t", self.w2_t if self.w2_t is not None else t(self.w2)))}
+            hip._built(self.wqkv)   # one-time images: complete before any other stream / thread (autograd's worker) can pick them up
         return self._tp3
 
     def h2(self) -> dict:

@@ -15,6 +15,8 @@ from typing import Any, Iterable
 
 import torch
 
+from . import hip
+
 from . import dist as tdist
 from .task import ReduceLROnPlateau
 
@@ -168,6 +170,9 @@ class Trainer:
                 opt.zero_grad()
             metrics = module.epoch_metrics("train")
             metrics["train_loss"] = (float(running.item()) if running is not None else 0.0) / max(n_batches, 1)
+            # the loss and optimiser kernels keep sticky device-side NaN / Inf flags (hip.nonfinite_flags): read here, where the host has just
+            # waited for the epoch anyway.  A non-finite step ends the fit with an exception instead of a NaN in the log
+            hip.check_finite(what=f"fit, epoch {epoch}")
             stop = False
             if val_loader is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
                 metrics.update(self._run_eval(module, val_loader, "val"))
