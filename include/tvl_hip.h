@@ -35,6 +35,8 @@ typedef void* tvlStream_t; /* hipStream_t */
 
 const char* tvl_last_error(void);
 int tvl_abi_version(void);
+/* how the library was built: bit 0 = make EXPERIMENTS=1 (retired GEMM variants present), bit 1 = DIAG=1, bit 2 = POISON=1 (LDS poison debug build) */
+int tvl_build_flags(void);
 
 /* row' = (r / div) * mul + (r % div) + off   (div <= 0: identity) */
 typedef struct { int32_t div, mul, off; } tvlRowMap;

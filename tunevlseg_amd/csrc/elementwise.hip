@@ -15,6 +15,19 @@ void tvl_set_error(const char* fmt, ...) {
 }
 extern "C" const char* tvl_last_error(void) { return g_err; }
 extern "C" int tvl_abi_version(void) { return TVL_ABI_VERSION; }
+extern "C" int tvl_build_flags(void) {
+    int f = 0;
+#ifdef TVL_EXPERIMENTS
+    f |= 1;
+#endif
+#ifdef TVL_DIAGNOSTIC_KERNELS
+    f |= 2;
+#endif
+#ifdef TVL_POISON_LDS
+    f |= 4;
+#endif
+    return f;
+}
 
 namespace {
 

@@ -207,7 +207,7 @@ _SIGS = {
     "tvl_colscale_add": [_P, _P, _P, _P, _L, _I],
     "tvl_colscale_bwd": [_P, _P, _P, _P, _P, _L, _I],
 }
-EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_h2_bytes", "tvl_dicece_work_doubles",
+EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_build_flags", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_h2_bytes", "tvl_dicece_work_doubles",
            "tvl_gemm_aux_floats", "tvl_mlp64_image_bytes", "tvl_groupnorm_work_doubles", *_SIGS]
 
 _lib = None
@@ -227,6 +227,7 @@ def load():
     lib = C.CDLL(str(LIB_PATH))
     lib.tvl_last_error.restype = C.c_char_p
     lib.tvl_abi_version.restype = C.c_int
+    lib.tvl_build_flags.restype = C.c_int
     if lib.tvl_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH} has C-ABI version {lib.tvl_abi_version()}, this package binds version {ABI_VERSION}: rebuild it "
                            f"(`make -C {LIB_PATH.parent}`)")
