@@ -337,7 +337,8 @@ typedef struct {
     void* workspace; int64_t workspace_bytes;
     int32_t aux_blocked;   /* tvl_gemm_h2_out only: pre_out (written) / dact_aux (read) is not a row-major matrix but a private buffer of
                             * tvl_gemm_aux_floats(M, N) floats in the producing kernel's accumulator order -- fc1's z handed to its data
-                            * gradient's QuickGELU' epilogue; both calls must have the same M and N */
+                            * gradient's QuickGELU' epilogue; both calls must have the same M and N.  2 (experiment, TVL_GEMM_ZHALF=1): the
+                            * buffer holds QuickGELU'(z) as one fp16 per element instead of z as fp32 (half the bytes each way) */
     int32_t a_scale_one;   /* tvl_gemm_h2 / tvl_gemm_h2_out: a_row_scale points at ONE inverse scale for every row of A (a tensor-scaled
                             * activation image, e.g. the attention output that shares the QKV scale) instead of at M of them */
 } tvlGemmTp3Args;

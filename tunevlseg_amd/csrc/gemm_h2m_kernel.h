@@ -76,6 +76,13 @@ __device__ __forceinline__ void epilogue16(const Tp3Params& p, f32x4 (&acc)[TMo]
 // fp32 row-major: 64 contiguous bytes per row and instruction.
 // p.aux_blocked: z does not leave as a row-major matrix but in the accumulators' own order -- tile after tile, wave after wave, 1 KB per
 // (16 x 16 block): a private layout between fc1's epilogue and the dz epilogue of the same (M, N, tile), both fully coalesced.
+__device__ __forceinline__ float4 half4_as_float4(const unsigned char* p8) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p8);
+    _Float16 h[4];
+    *reinterpret_cast<uint2*>(h) = u;
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+
 template <int TMo, int EPI>
 __device__ __forceinline__ void epilogue16_direct(const Tp3Params& p, f32x4 (&acc)[TMo][4], int row_base, int col_base, int lane, long blk_base) {
     static_assert((EPI & E_H2OUT) && !(EPI & (E_F32 | E_TP3 | E_RES | E_RELU)) && (EPI & E_RSCALE), "image-only epilogues");
@@ -97,7 +104,8 @@ __device__ __forceinline__ void epilogue16_direct(const Tp3Params& p, f32x4 (&ac
         if constexpr ((EPI & E_DQGELU) != 0 && i < TMo) {
             const long row = row_base + 16 * i + m;
             [&]<int... J>(std::integer_sequence<int, J...>) {
-                ((zrow[bsel][J] = p.aux_blocked ? *reinterpret_cast<const float4*>(p.dact_aux + (blk_base + i * 4 + J) * 256 + lane * 4)
+                ((zrow[bsel][J] = p.aux_blocked == 2 ? half4_as_float4(reinterpret_cast<const unsigned char*>(p.dact_aux) + ((blk_base + i * 4 + J) * 256 + lane * 4) * 2)
+                                  : p.aux_blocked ? *reinterpret_cast<const float4*>(p.dact_aux + (blk_base + i * 4 + J) * 256 + lane * 4)
                                                 : ((row < p.M && col_base + 16 * J + 4 * q + 3 < p.N)
                                                        ? *reinterpret_cast<const float4*>(p.dact_aux + row * p.ld_aux + col_base + 16 * J + 4 * q)
                                                        : make_float4(0.f, 0.f, 0.f, 0.f))), ...);
@@ -112,12 +120,23 @@ __device__ __forceinline__ void epilogue16_direct(const Tp3Params& p, f32x4 (&ac
         if constexpr ((EPI & E_BIAS) != 0) { v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w; }
         if constexpr ((EPI & E_DQGELU) != 0) {
             const float4 z4 = zrow[i & 1][j];
-            v[0] *= quick_gelu_grad_fast(z4.x); v[1] *= quick_gelu_grad_fast(z4.y);
-            v[2] *= quick_gelu_grad_fast(z4.z); v[3] *= quick_gelu_grad_fast(z4.w);
+            if (p.aux_blocked == 2) {   // the buffer holds QuickGELU'(z) itself (one fp16 per element, written by fc1's epilogue), not z
+                v[0] *= z4.x; v[1] *= z4.y; v[2] *= z4.z; v[3] *= z4.w;
+            } else {
+                v[0] *= quick_gelu_grad_fast(z4.x); v[1] *= quick_gelu_grad_fast(z4.y);
+                v[2] *= quick_gelu_grad_fast(z4.z); v[3] *= quick_gelu_grad_fast(z4.w);
+            }
         }
         if constexpr ((EPI & E_PRE) != 0) {
-            float* zo = p.aux_blocked ? p.pre_out + (blk_base + i * 4 + j) * 256 + lane * 4 : p.pre_out + row * p.ldc + col;
-            *reinterpret_cast<float4*>(zo) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.aux_blocked == 2) {   // experiment (TVL_GEMM_ZHALF=1): the backward needs z only for QuickGELU'(z) -- leave that, as ONE fp16 per element
+                _Float16 g[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = (_Float16)quick_gelu_grad_fast(v[e]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.pre_out) + ((blk_base + i * 4 + j) * 256 + lane * 4) * 2) = *reinterpret_cast<const uint2*>(g);
+            } else {
+                float* zo = p.aux_blocked ? p.pre_out + (blk_base + i * 4 + j) * 256 + lane * 4 : p.pre_out + row * p.ldc + col;
+                *reinterpret_cast<float4*>(zo) = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
         if constexpr ((EPI & E_QGELU) != 0) {
 #pragma unroll

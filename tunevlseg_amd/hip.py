@@ -503,8 +503,12 @@ class Tp3:
         n = (rows + 31) // 32 * (cols // 16) * 3072
         # rows beyond `rows` in the last 32-row block are read by whole-block consumers (attention key tiles: p = 0 times a stale
         # NaN would poison the sum): an image with padded rows starts zeroed
-        make = torch.zeros if rows % 32 else torch.empty
-        self.buf = buf if buf is not None else make(n, device=device, dtype=torch.uint8)
+        # (only the last block row needs it: zeroing the whole image cost 4 % of the DenseCLIP step, whose M = 16 * 1601 is not a multiple of 32)
+        if buf is None:
+            buf = torch.empty(n, device=device, dtype=torch.uint8)
+            if rows % 32:
+                buf[(rows // 32) * (cols // 16) * 3072:].zero_()
+        self.buf = buf
 
     @property
     def shape(self):
@@ -652,7 +656,9 @@ class H2:
             self.buf = torch.empty(n + (cols // 16) * 2048, device=device, dtype=torch.uint8)
             self.buf[n:].zero_()
         else:
-            self.buf = (torch.zeros if rows % 32 else torch.empty)(n, device=device, dtype=torch.uint8)
+            self.buf = torch.empty(n, device=device, dtype=torch.uint8)
+            if rows % 32:   # padded rows of the last block row are read by whole-block consumers: they start as zeros (the rest is written by the producer)
+                self.buf[(rows // 32) * (cols // 16) * 2048:].zero_()
         self.inv_scale = torch.empty(rows if per_row else 1, device=device, dtype=torch.float32)
         self._alpha = None   # host copy of a per-tensor inverse scale, read once (frozen weights)
         self.row_norm = None   # [rows] L2 norms of the rows (per-row operands whose consumer GEMM writes an h2 output)
@@ -740,7 +746,7 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
                        _p(bias), _ps(residual), 0 if residual is None else residual.stride(0), act, pre_p, aux_p,
                        ld_aux, dact, B.alpha(), tile_m, GEMM_TP3_VARIANT,
                        gemm_workspace().data_ptr() if (persistent and (Ch is not None or pre_out is not None)) else None, GEMM_WORKSPACE_BYTES,
-                       1 if aux_blocked else 0, 0 if A.per_row else 1)
+                       (2 if GEMM_ZHALF else 1) if aux_blocked else 0, 0 if A.per_row else 1)
     if _gemm_prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -761,6 +767,7 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
 _H2_EPI_BUILT = {192: {193, 161, 160, 192, 163, 385, 384, 673}, 256: {213, 197, 200, 405, 389, 392, 161, 673, 160}}   # launch_h2's compile-time epilogues per row tile (csrc/gemm_h2.hip)
 
 
+GEMM_ZHALF = os.environ.get("TVL_GEMM_ZHALF", "0") == "1"   # experiment: fc1 leaves QuickGELU'(z) as one fp16 per element instead of z as fp32 (profiles/r4_gemm_experiments.md)
 GEMM_M16 = os.environ.get("TVL_GEMM_M16", "1") != "0"   # the h2 ring GEMMs on v_mfma_f32_16x16x32_f16 (csrc/gemm_h2m_kernel.h); 0 = the 32x32x16 generation
 _H2M_EPI_BUILT = {385, 384, 163, 160, 405, 389, 392, 161, 673}   # launch_m_layer_epi's compile-time epilogues
 
