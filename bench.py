@@ -127,8 +127,9 @@ def rocprof_avg_us(workload: str, kernel: str):
     """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of the same command (profiles/), or None."""
     import csv
 
-    f = ROOT / "profiles" / {"cris": "r3_cris_kernel_stats.csv", "maple": "r3_maple_kernel_stats.csv", "vit640": "r3_vit640_kernel_stats.csv"}.get(workload, "r3_kernel_stats.csv")
-    if not f.exists():
+    stem = {"cris": "cris_kernel_stats.csv", "maple": "maple_kernel_stats.csv", "vit640": "vit640_kernel_stats.csv", "denseclip": "denseclip_kernel_stats.csv"}.get(workload, "kernel_stats.csv")
+    f = next((c for c in (ROOT / "profiles" / f"r4_{stem}", ROOT / "profiles" / f"r3_{stem}") if c.exists()), None)
+    if f is None:
         return None, None
     want = kernel.replace(" ", "")
     with open(f, newline="") as fh:
@@ -409,17 +410,25 @@ def main():
         # HBM bytes per launch of that kernel: recorded by two separate rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE; FETCH_SIZE
         # doubled per the gfx950 note of MI355X_MICROARCH.md §HBM) and committed under profiles/.  It is a RECORDED number: reported
         # only when the record names the same kernel instantiation, and always with the file and commit it came from.
+        # A record is reported only while the kernel sources are the ones it was taken on (csrc_sha: the GPU box has no .git to ask about
+        # ancestry); otherwise traffic is null and traffic_source says which record was refused.
         traffic, traffic_source = None, None
-        stem = {"cris": "cris_hbm_traffic.json", "maple": "maple_hbm_traffic.json"}.get(args.workload, "hbm_traffic.json")
-        tf = next((f for f in (ROOT / "profiles" / f"r3_{stem}", ROOT / "profiles" / f"r2_{stem}") if f.exists()), ROOT / "profiles" / f"r3_{stem}")
+        stem = {"cris": "cris_hbm_traffic.json", "maple": "maple_hbm_traffic.json", "denseclip": "denseclip_hbm_traffic.json"}.get(args.workload, "hbm_traffic.json")
+        tf = next((f for f in (ROOT / "profiles" / f"r4_{stem}", ROOT / "profiles" / f"r3_{stem}") if f.exists()), ROOT / "profiles" / f"r4_{stem}")
         if tf.exists():
             rec_all = json.loads(tf.read_text())
             rec = rec_all.get("kernels", rec_all).get(name.replace(", ", ","))
-            if rec:
+            same = rec_all.get("csrc_sha") is not None and rec_all.get("csrc_sha") == hip.csrc_sha()
+            traffic_source = {"file": str(tf.relative_to(ROOT)), "recorded_at_commit": rec_all.get("commit"), "recorded_csrc_sha": rec_all.get("csrc_sha"),
+                              "this_build_csrc_sha": hip.csrc_sha(), "kind": "recorded (rocprofv3 --pmc), not measured by this run"}
+            if rec and same:
                 traffic = rec["hbm_bytes_per_launch"]
-                traffic_source = {"file": str(tf.relative_to(ROOT)), "recorded_at_commit": rec_all.get("commit"), "kind": "recorded (rocprofv3 --pmc), not measured by this run"}
+            else:
+                traffic_source["refused"] = "no record for this kernel" if not rec else "the kernel sources changed since the record was taken"
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "kernel": name,
+                    "hbm_algorithmic_bytes": round(d["bytes"] / d["launches"]) if d.get("bytes") else None,
+                    "hbm_frac": round(d["bytes"] / (d["ms"] * 1e-3) / 1e12 / PEAK_HBM_TBS, 4) if d.get("bytes") else None,
                     "peak_note": ("algorithmic fp32 FLOP/s ceiling = dense fp16 MFMA peak (2.5 PFLOP/s) / 3 MFMAs per fp32 product" if two_piece else
                                   "algorithmic fp32 FLOP/s ceiling = dense bf16 MFMA peak (2.5 PFLOP/s) / 6 MFMAs per fp32 product") if split
                     else "dense f32-input MFMA peak",
@@ -431,10 +440,20 @@ def main():
                     "rocprof_avg_launch_us": rocprof_avg_us(args.workload, name)[0], "rocprof_source": rocprof_avg_us(args.workload, name)[1],
                     "flops_per_launch": round(d["flops"] / d["launches"]), "all_gemm_ms_per_step": round(gemm_ms, 2),
                     # every GEMM instantiation of the step (one instantiation serves several shapes: the average mixes them)
-                    "gemm_kernels": [{"kernel": k.replace("gemm_bf16s_kernel", "bf16s").replace("gemm_f32_kernel", "f32").replace("gemm_tp3_kernel", "tp3").replace("gemm_h2m_kernel", "h2m"),
-                                      "ms_per_step": round(v["ms"] / 2, 2), "launches_per_step": v["launches"] // 2,
-                                      "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
-                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:5]],
+                    # both rooflines per instantiation: MFMA (flops / the arithmetic's ceiling) and HBM (algorithmic bytes: operands once, every
+                    # output once / 8 TB/s), and the bound of a kernel that does the two one after the other (t_mfma + t_hbm): the measured time sits
+                    # near that sum where a round of tiles loads, computes and stores in lock-step
+                    "gemm_kernels": [dict({"kernel": k.replace("gemm_bf16s_kernel", "bf16s").replace("gemm_f32_kernel", "f32").replace("gemm_tp3_kernel", "tp3").replace("gemm_h2m_kernel", "h2m"),
+                                           "ms_per_step": round(v["ms"] / 2, 2), "launches_per_step": v["launches"] // 2, "avg_us": round(1e3 * v["ms"] / v["launches"], 1),
+                                           "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)},
+                                          **({"mfma_frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 3),
+                                              "hbm_algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"]),
+                                              "hbm_GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e12 / PEAK_HBM_TBS, 3),
+                                              "t_mfma_us": round(v["flops"] / v["launches"] / (PEAK_BF16_MFMA_TFLOPS / 3 * 1e12) * 1e6, 1),
+                                              "t_hbm_us": round(v["bytes"] / v["launches"] / (PEAK_HBM_TBS * 1e12) * 1e6, 1),
+                                              "frac_of_serial_bound": round((v["flops"] / (PEAK_BF16_MFMA_TFLOPS / 3 * 1e12) + v["bytes"] / (PEAK_HBM_TBS * 1e12)) / (v["ms"] * 1e-3), 3)}
+                                             if v.get("bytes") else {}))
+                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:6]],
                     "all_gemm_tflops": round(sum(v["flops"] for v in prof.values()) / 2 / (gemm_ms * 1e-3) / 1e12, 2),
                     # the non-GEMM kernels of a vision layer, each against its own roofline: attention on the same MFMA ceiling (its
                     # products are 3 MFMAs on two fp16 pieces), LayerNorm on HBM (algorithmic bytes)

@@ -3,7 +3,8 @@
 
     python tools/hbm_traffic.py <dir of the FETCH_SIZE run> <dir of the WRITE_SIZE run> [commit] > profiles/<round>_hbm_traffic.json
 
-Output: {"commit": <the build the passes ran>, "kernels": {name: {...}}}, names without blanks after commas (bench.py's lookup key).
+Output: {"commit": <the build the passes ran>, "csrc_sha": <tunevlseg_amd.hip.csrc_sha() of the sources the passes ran: bench.py reports a
+record only while the sources are the same>, "kernels": {name: {...}}}, names without blanks after commas (bench.py's lookup key).
 
 Both counters are reported in KB; FETCH_SIZE is doubled (gfx950 counts 128-byte read requests as 64 B,
 MI355X_MICROARCH.md, HBM section).  Kernel names are reduced to `name<template args>` without the namespace."""
@@ -47,7 +48,10 @@ def main():
         w = sum(write[k]) / len(write[k]) if write.get(k) else 0.0
         out[k] = {"dispatches": max(len(fetch.get(k, [])), len(write.get(k, []))), "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
                   "hbm_bytes_per_launch": int(round((2.0 * f + w) * 1024))}
-    json.dump({"commit": sys.argv[3] if len(sys.argv) > 3 else None, "counters": "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) KB, "
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    from tunevlseg_amd.hip import csrc_sha
+
+    json.dump({"commit": sys.argv[3] if len(sys.argv) > 3 else None, "csrc_sha": csrc_sha(), "counters": "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) KB, "
                "mean over dispatches; two separate rocprofv3 --pmc passes", "kernels": out}, sys.stdout, indent=1)
 
 

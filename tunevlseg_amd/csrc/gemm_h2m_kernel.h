@@ -76,11 +76,18 @@ __device__ __forceinline__ void epilogue16(const Tp3Params& p, f32x4 (&acc)[TMo]
 // fp32 row-major: 64 contiguous bytes per row and instruction.
 // p.aux_blocked: z does not leave as a row-major matrix but in the accumulators' own order -- tile after tile, wave after wave, 1 KB per
 // (16 x 16 block): a private layout between fc1's epilogue and the dz epilogue of the same (M, N, tile), both fully coalesced.
-__device__ __forceinline__ float4 half4_as_float4(const unsigned char* p8) {
+// four fp16 as they come from memory, carried in the first two lanes of a float4 WITHOUT touching them: a conversion at load time would make
+// the wave wait for the load it has just issued, and the point of the z rows is that they are requested one row block ahead
+__device__ __forceinline__ float4 half4_raw(const unsigned char* p8) {
     const uint2 u = *reinterpret_cast<const uint2*>(p8);
+    return make_float4(__builtin_bit_cast(float, u.x), __builtin_bit_cast(float, u.y), 0.f, 0.f);
+}
+__device__ __forceinline__ void half4_unpack(const float4& raw, float (&g)[4]) {
+    const uint2 u = make_uint2(__builtin_bit_cast(unsigned, raw.x), __builtin_bit_cast(unsigned, raw.y));
     _Float16 h[4];
     *reinterpret_cast<uint2*>(h) = u;
-    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = (float)h[e];
 }
 
 template <int TMo, int EPI>
@@ -104,7 +111,7 @@ __device__ __forceinline__ void epilogue16_direct(const Tp3Params& p, f32x4 (&ac
         if constexpr ((EPI & E_DQGELU) != 0 && i < TMo) {
             const long row = row_base + 16 * i + m;
             [&]<int... J>(std::integer_sequence<int, J...>) {
-                ((zrow[bsel][J] = p.aux_blocked == 2 ? half4_as_float4(reinterpret_cast<const unsigned char*>(p.dact_aux) + ((blk_base + i * 4 + J) * 256 + lane * 4) * 2)
+                ((zrow[bsel][J] = p.aux_blocked == 2 ? half4_raw(reinterpret_cast<const unsigned char*>(p.dact_aux) + ((blk_base + i * 4 + J) * 256 + lane * 4) * 2)
                                   : p.aux_blocked ? *reinterpret_cast<const float4*>(p.dact_aux + (blk_base + i * 4 + J) * 256 + lane * 4)
                                                 : ((row < p.M && col_base + 16 * J + 4 * q + 3 < p.N)
                                                        ? *reinterpret_cast<const float4*>(p.dact_aux + row * p.ld_aux + col_base + 16 * J + 4 * q)
@@ -121,7 +128,9 @@ __device__ __forceinline__ void epilogue16_direct(const Tp3Params& p, f32x4 (&ac
         if constexpr ((EPI & E_DQGELU) != 0) {
             const float4 z4 = zrow[i & 1][j];
             if (p.aux_blocked == 2) {   // the buffer holds QuickGELU'(z) itself (one fp16 per element, written by fc1's epilogue), not z
-                v[0] *= z4.x; v[1] *= z4.y; v[2] *= z4.z; v[3] *= z4.w;
+                float g[4];
+                half4_unpack(z4, g);
+                v[0] *= g[0]; v[1] *= g[1]; v[2] *= g[2]; v[3] *= g[3];
             } else {
                 v[0] *= quick_gelu_grad_fast(z4.x); v[1] *= quick_gelu_grad_fast(z4.y);
                 v[2] *= quick_gelu_grad_fast(z4.z); v[3] *= quick_gelu_grad_fast(z4.w);

@@ -403,6 +403,19 @@ class _aux_span:
         return False
 
 
+def csrc_sha() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile, include/tvl_hip.h): the identity of the code a recorded profile belongs to.
+    (The GPU box gets a snapshot without .git, so a commit hash cannot be checked there; identical sources can.)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted([*(_HERE / "csrc").glob("*.hip"), *(_HERE / "csrc").glob("*.h"), _HERE / "csrc" / "Makefile", _HERE.parent / "include" / "tvl_hip.h"])
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def gemm_profile_start():
     global _gemm_prof, _aux_prof
     _gemm_prof, _aux_prof = [], []
@@ -424,10 +437,11 @@ def gemm_profile_stop() -> dict:
     torch.cuda.synchronize()
     empty = max(sorted(e0.elapsed_time(e1) for e0, e1 in pairs)[len(pairs) // 2] - 0.003, 0.0) if pairs else 0.0
     out: dict[str, dict] = {}
-    for key, flops, e0, e1 in rec:
-        d = out.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
+    for key, flops, e0, e1, *more in rec:
+        d = out.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
         d["launches"] += 1
         d["flops"] += flops
+        d["bytes"] += more[0] if more else 0.0   # algorithmic HBM bytes of the launch (operands once + every output once), where the caller knows them
         t = e0.elapsed_time(e1)
         d["ms"] += max(t - empty, 0.25 * t)
         d["raw_ms"] = d.get("raw_ms", 0.0) + t
@@ -759,8 +773,11 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
         _call("tvl_gemm_h2", C.byref(args), _p(a_scale))
     if _gemm_prof is not None:
         e1.record()
+        aux_b = 2.0 if (aux_blocked and GEMM_ZHALF) else 4.0
+        nbytes = 4.0 * (M + N) * K + M * N * (4.0 * (Cf is not None) + 6.0 * (Ct is not None) + 4.0 * (Ch is not None) + aux_b * (pre_out is not None)
+                                               + 4.0 * (residual is not None) + aux_b * (dact_aux is not None))
         _gemm_prof.append((h2_kernel_name(M, N, bias is not None, residual is not None, act, dact, pre_out is not None, Cf is not None,
-                                          Ct is not None, tile_m, Ch is not None, K=K), 2.0 * M * N * K, e0, e1))
+                                          Ct is not None, tile_m, Ch is not None, K=K), 2.0 * M * N * K, e0, e1, nbytes))
     return Cf, (Ch if Ch is not None else Ct)
 
 
