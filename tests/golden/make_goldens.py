@@ -160,7 +160,7 @@ def compact_outputs(logits, mask):
 
 
 def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, learner_kw: dict, net_kw: dict,
-             B: int, H: int, L: int, iseed: int, M, compact: bool = False, with_f64: bool = False, tails: int = 0):
+             B: int, H: int, L: int, iseed: int, M, compact: bool = False, with_f64: bool = False, tails: int = 0, big_by_seed: bool = False):
     from src.models.components.hf_clipseg_wrapper import HFCLIPSegWrapper
     from src.models.core_models import coop as R
     from src.models.core_models.coop import context_learner as CL
@@ -203,6 +203,21 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
             elif k.endswith(".bias"):
                 p.copy_(0.05 * torch.randn(p.shape, generator=g))
 
+    # ``big_by_seed``: trainable tensors above 200 k elements (the SharedAttn learner's 1280-wide TransformerEncoderLayers: 10 M parameters a
+    # layer) are re-drawn from a per-tensor seed, and the fixture keeps (seed, std, shape) instead of the values and every 61st gradient
+    # entry + the gradient's absolute sum instead of the gradient (tests/golden_util.py trainable_of / grad_of rebuild / compare)
+    by_seed = {}
+    if big_by_seed:
+        import zlib
+
+        from tests.golden_util import redraw
+
+        with torch.no_grad():
+            for k, p in params.items():
+                if p.numel() > 200_000:
+                    seed, std = (zlib.crc32(k.encode()) ^ (7919 * iseed)) & 0x7FFFFFFF, float(f"{float(p.std()):.3g}")
+                    p.copy_(redraw(seed, std, tuple(p.shape)))
+                    by_seed[k] = (seed, std)
     pix, ids, am, mask = synth_inputs(cfg, B, H, L, iseed)
     logits = net(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix)
     loss = dice_ce_loss(logits, mask)
@@ -215,9 +230,15 @@ def run_case(name: str, *, preset: str, eos: int, wseed: int, net_kind: str, lea
                   "in.mask": mask.numpy(), "out.logits": logits.detach().numpy(), "out.loss": loss.detach().numpy()}
     grads_none = []
     for k, p in params.items():
-        arrays["param." + k] = p.detach().numpy()
+        if k in by_seed:
+            arrays["paramseed." + k] = np.array([by_seed[k][0], by_seed[k][1], *p.shape], dtype=np.float64)
+        else:
+            arrays["param." + k] = p.detach().numpy()
         if p.grad is None:
             grads_none.append(k)
+        elif k in by_seed:
+            arrays["gradsub." + k] = p.grad.flatten()[::61].contiguous().numpy()
+            arrays["gradabs." + k] = p.grad.double().abs().sum().numpy()
         else:
             arrays["grad." + k] = p.grad.numpy()
     if with_f64:
@@ -426,6 +447,15 @@ def main():
              learner_kw=dict(prompt_depth=10, num_context=4, vector_std=0.02, use_unified_projection=False,
                              intermediate_dim=128, use_proj_norm=True, use_lora_proj=False, norm_image_features=True),
              net_kw=base_old, with_f64=True, **F_)
+    # --- row A16 at full size: the reference's own SharedAttn / SharedSeparate settings (configs/model/shared_attn_clipseg.yaml:9-27: 4 context
+    # tokens, 1280-wide shared prompt through TransformerEncoderLayer(nhead 16, ff 1536, norm_first), new last layer; dropout 0 for a
+    # deterministic fixture; depth 2 so that the deep-prompt path of both towers is in it; shared_separate_clipseg.yaml at shared_dim 64)
+    run_case("rd64_sharedattn_n4_d2_newlast", eos=2, wseed=21, net_kind="shared_attn", iseed=29,
+             learner_kw=dict(prompt_depth=2, num_context=4, vector_std=0.02, use_unified_projection=False,
+                             _tlayer=dict(nhead=16, dim_feedforward=1536, dropout=0.0, norm_first=True)), net_kw=base_new, big_by_seed=True, **F_)
+    run_case("rd64_sharedsep_n4_d2_i64_newlast", eos=2, wseed=21, net_kind="shared_separate", iseed=30,
+             learner_kw=dict(prompt_depth=2, num_context=4, vector_std=0.02, shared_dim=64, use_unified_projection=False,
+                             intermediate_dim=64, use_proj_norm=True, use_lora_proj=False), net_kw=base_new, **F_)
     # --- BASELINE configs[1] exactly: VPT-10 shallow, 352x352, B = 32 (seed 1).  Compact fixture: the inputs
     # are re-drawn from the seed; kept are loss, the 7 680-float prompt gradient, per-sample integer counts / Dice and
     # every 11th logit.  This is the case whose M = 15 840 rows select the large GEMM tiles of the benchmarked step.

@@ -39,13 +39,33 @@ def state_of(fx) -> dict[str, torch.Tensor]:
     return sd
 
 
+def redraw(seed: int, std: float, shape) -> torch.Tensor:
+    """A large trainable tensor of a fixture that keeps (seed, std, shape) instead of its values (make_goldens.py ``big_by_seed``)."""
+    return torch.randn(tuple(int(d) for d in shape), generator=torch.Generator().manual_seed(int(seed))) * float(std)
+
+
 def trainable_of(fx, requires_grad: bool = True) -> dict[str, torch.Tensor]:
     out = {}
     for k, v in fx.items():
         if k.startswith("param."):
             t = torch.from_numpy(np.array(v)).clone()
             out[k[len("param."):]] = t.requires_grad_(requires_grad)
+        elif k.startswith("paramseed."):
+            out[k[len("paramseed."):]] = redraw(v[0], v[1], v[2:]).requires_grad_(requires_grad)
     return out
+
+
+def grad_of(fx, k: str, g: torch.Tensor | None = None):
+    """(reference gradient, this path's gradient) in comparable form: whole tensors, or -- for the by-seed tensors, whose fixture keeps every
+    61st entry and the absolute sum -- the same subsample of ``g`` (the absolute sum is checked here, to 1e-3)."""
+    if "grad." + k in fx:
+        return torch.from_numpy(fx["grad." + k]), g
+    ref = torch.from_numpy(fx["gradsub." + k])
+    if g is None:
+        return ref, None
+    s = float(fx["gradabs." + k])
+    assert abs(float(g.detach().double().abs().sum()) - s) <= 1e-3 * max(s, 1e-12), (k, float(g.detach().double().abs().sum()), s)
+    return ref, g.detach().flatten()[::61]
 
 
 def oracle_learner(fx, params: dict[str, torch.Tensor]) -> dict:

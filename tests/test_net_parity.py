@@ -10,7 +10,7 @@ from functools import partial
 import pytest
 import torch
 
-from tests.golden_util import config_of, golden_names, inputs_of, load_golden, trainable_of
+from tests.golden_util import config_of, golden_names, grad_of, inputs_of, load_golden, trainable_of
 
 pytestmark = pytest.mark.gpu
 
@@ -103,8 +103,8 @@ def run_case(name):
         if k in fx["meta"]["grads_none"]:
             assert p.grad is None or p.grad.abs().max().item() == 0, k
             continue
-        g_ref = torch.from_numpy(fx["grad." + k])
         assert p.grad is not None, f"{name}: no grad for {k}"
+        g_ref, g_own = grad_of(fx, k, p.grad.cpu())
         scale = g_ref.abs().max().item() + 1e-12
         if "grad64." + k in fx:
             # ill-conditioned fixture (deep prompts: the gradient is a small difference of larger terms).  The fixture also holds
@@ -127,7 +127,7 @@ def run_case(name):
             agg[1] += (g_ref.double() - truth.double()).pow(2).sum().item()
             agg[2] += truth.double().pow(2).sum().item()
         else:
-            gerr = (p.grad.cpu() - g_ref).abs().max().item()
+            gerr = (g_own - g_ref).abs().max().item()
             assert gerr <= GRAD_RTOL * scale + 1e-9, f"{name}: grad {k} err {gerr:.3e} scale {scale:.3e}"
         worst = max(worst, gerr / scale)
     from tunevlseg_amd import hip
@@ -208,7 +208,7 @@ def run_compact_case(name):
             print(f"PARITY(fp64, compact) case={name} {k}: rel-L2 vs float64 HIP {ours:.3e}, reference fp32 {theirs:.3e}")
             assert ours <= max(GRAD_RTOL, 2.5 * theirs), (ours, theirs)
         else:
-            gerr = (p.grad.cpu() - g_ref).abs().max().item()
+            gerr = (g_own - g_ref).abs().max().item()
             assert gerr <= GRAD_RTOL * scale + 1e-9, f"{name}: grad {k} err {gerr:.3e} scale {scale:.3e}"
         worst = max(worst, gerr / scale)
     print(f"PARITY(compact) case={name} label_flips_at_ambiguous_pixels={flips} logit_err={err:.3e} loss_err={abs(loss.item() - float(fx['out.loss'])):.2e} worst_grad_rel={worst:.3e} "

@@ -10,7 +10,7 @@ import torch
 
 from oracle import clipseg_oracle as O
 from oracle import cris_oracle as OC
-from tests.golden_util import (config_of, cris_config_of, cris_new_last_of, cris_state_of, golden_names, inputs_of,
+from tests.golden_util import (config_of, cris_config_of, cris_new_last_of, cris_state_of, golden_names, grad_of, inputs_of,
                                load_golden, new_last_of, oracle_learner, state_of, trainable_of)
 
 
@@ -60,9 +60,9 @@ def check(fx):
         if k in fx["meta"]["grads_none"]:
             assert params[k].grad is None or params[k].grad.abs().max() == 0, k
             continue
-        g_ref = torch.from_numpy(fx["grad." + k])
         g = params[k].grad
         assert g is not None, k
+        g_ref, g = grad_of(fx, k, g)
         scale = g_ref.abs().max().item() + 1e-12
         gnoise = (g_ref - torch.from_numpy(fx["grad64." + k])).abs().max().item() if (noise and "grad64." + k in fx) else 0.0
         assert (g - g_ref).abs().max().item() <= max(2e-4 * scale, 3.0 * gnoise) + 1e-9, (k, (g - g_ref).abs().max().item(), scale)

@@ -641,7 +641,10 @@ def gemm_aux(M: int, N: int, device) -> torch.Tensor | None:
     """A buffer for fc1's pre-activation in the GEMM's own accumulator order (``aux_blocked``), or None when the shape does not qualify:
     written by fc1's epilogue, read by the QuickGELU' epilogue of its data gradient, never anything else -- fully coalesced both ways."""
     n = load().tvl_gemm_aux_floats(M, N)
-    return torch.empty(n, device=device, dtype=torch.float32) if n > 0 and GEMM_M16 else None
+    if n <= 0 or not GEMM_M16:
+        return None
+    # with TVL_GEMM_ZHALF (default) the buffer holds QuickGELU'(z) as one fp16 per element: half the floats
+    return torch.empty((n + 1) // 2 if GEMM_ZHALF else n, device=device, dtype=torch.float32)
 
 
 def gemm_workspace() -> torch.Tensor:
@@ -784,7 +787,11 @@ def gemm_h2(A: H2, B: H2, *, M: int | None = None, out: torch.Tensor | None = No
 _H2_EPI_BUILT = {192: {193, 161, 160, 192, 163, 385, 384, 673}, 256: {213, 197, 200, 405, 389, 392, 161, 673, 160}}   # launch_h2's compile-time epilogues per row tile (csrc/gemm_h2.hip)
 
 
-GEMM_ZHALF = os.environ.get("TVL_GEMM_ZHALF", "0") == "1"   # experiment: fc1 leaves QuickGELU'(z) as one fp16 per element instead of z as fp32 (profiles/r4_gemm_experiments.md)
+# fc1 leaves QuickGELU'(z) -- all its data gradient needs of z -- as ONE fp16 per element in the accumulator-order buffer instead of z as fp32: 2 B
+# instead of 4 written by fc1 and read by dz (-195 MB per layer and step at the headline shape).  Its rounding (2^-12 relative, zero-mean) enters dz
+# once and is averaged by the K = 3072 contraction of dx2; every fixture incl. the *_tails ones passes its unchanged gates (profiles/r4_gemm_experiments.md).
+# 0 = fp32 z (A/B switch).
+GEMM_ZHALF = os.environ.get("TVL_GEMM_ZHALF", "1") != "0"
 GEMM_M16 = os.environ.get("TVL_GEMM_M16", "1") != "0"   # the h2 ring GEMMs on v_mfma_f32_16x16x32_f16 (csrc/gemm_h2m_kernel.h); 0 = the 32x32x16 generation
 _H2M_EPI_BUILT = {385, 384, 163, 160, 405, 389, 392, 161, 673}   # launch_m_layer_epi's compile-time epilogues
 
