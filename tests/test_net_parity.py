@@ -197,7 +197,7 @@ def run_compact_case(name):
     for k, p in net.named_parameters():
         if not p.requires_grad or k in m["grads_none"]:
             continue
-        g_ref = torch.from_numpy(fx["grad." + k])
+        g_ref, g_own = grad_of(fx, k, p.grad.cpu())
         scale = g_ref.abs().max().item() + 1e-12
         if "grad64." + k in fx:   # heavy-tailed batch fixture: anchored at the reference's float64 gradient, as in run_case
             truth = torch.from_numpy(fx["grad64." + k])
@@ -222,6 +222,29 @@ def test_hip_net_matches_reference_headline_batch():
     prof = run_compact_case("rd64_vpt_n10_d1_b32")
     big = [k for k in prof if k.startswith(("gemm_tp3_kernel<192", "gemm_h2m_kernel<192")) or "gemm_bf16s_kernel<192" in k]
     assert big, sorted(prof)
+
+
+def test_eval_forward_without_a_tape_matches_the_headline_fixture():
+    """The eval / predict forward (``torch.no_grad()``, what validation, test and predict run under: no saved activations, ``want_stats`` off,
+    fc1 without its pre-activation output) at the headline batch against the same reference logits, label map and integer counts."""
+    from tests.golden_util import check_compact_labels, synth_inputs
+    from tunevlseg_amd import ops
+
+    fx = load_golden("rd64_vpt_n10_d1_b32")
+    m = fx["meta"]
+    net = build_net(fx)
+    pix, ids, am, mask = (t.cuda() for t in synth_inputs(config_of(fx), m["B"], m["H"], m["L"], m["input_seed"]))
+    with torch.no_grad():
+        logits = net(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix)
+        assert not logits.requires_grad
+        loss, isum = ops.DiceCELossFn.apply(logits, mask, 1.0, 0.2, 0.5)
+    err = (logits[..., ::11, ::11].cpu() - torch.from_numpy(fx["out.logits_s11"])).abs().max().item()
+    assert err <= LOGIT_TOL, err
+    assert abs(loss.item() - float(fx["out.loss"])) <= 1e-5
+    check_compact_labels(fx, logits, isum, mask)
+    # ... and it is the same arithmetic as the taped forward: bit for bit
+    taped = net(text_input={"input_ids": ids, "attention_mask": am}, image_input=pix)
+    assert torch.equal(taped.detach(), logits)
 
 
 def test_hip_net_matches_reference_maple_per_gpu_batch():
