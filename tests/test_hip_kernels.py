@@ -776,8 +776,11 @@ def test_gemm_h2_pre_activation_in_accumulator_order_round_trips(hip):
     (a1, d1, s1, f1), (a0, d0, s0, f0) = res
     assert torch.equal(a1, a0) and torch.equal(s1, s0)
     if hip.GEMM_ZHALF:
-        assert z.numel() * 4 == (hip.load().tvl_gemm_aux_floats(M, N) + 1) // 2 * 4 or True
-        assert ((f1 - f0).abs() <= 2.0**-10 * f0.abs() + 1e-30).all()   # one fp16 rounding of the factor (+ the image's own 2^-22)
+        assert z.numel() == (hip.load().tvl_gemm_aux_floats(M, N) + 1) // 2
+        # one fp16 rounding of the factor: 2^-11 relative where QuickGELU'(z) is a normal fp16, 2^-25 absolute (times the row's largest |dy W2|, bounded
+        # here by the row's largest |dz| / min |factor| ~ a few row maxima) where it is subnormal (|factor| < 6e-5: z far in the negative tail)
+        rowmax = f0.abs().amax(1, keepdim=True)
+        assert ((f1 - f0).abs() <= 2.0**-10 * f0.abs() + 2.0**-20 * rowmax).all()
         assert float((f1 - f0).abs().max()) > 0.0                          # ... and it is the half-precision path that ran
     else:
         assert torch.equal(d1, d0)

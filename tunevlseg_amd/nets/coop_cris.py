@@ -18,6 +18,7 @@ from .. import cris_ops as C
 from .. import hip, ops
 from ..cris_backbone import CRISWeights
 from .context_learner import CoCoOpContextLearner, CoOpContextLearner
+from .towers import SideStream
 
 RELU, NONE = hip.ACT_RELU, hip.ACT_NONE
 LN_EPS = 1e-5
@@ -175,18 +176,27 @@ class COOPCRIS(nn.Module):
         return x, state
 
     # ------------------------------------------------------------------ FPN neck (layers.py:412-445)
-    def neck_forward(self, vis, state: torch.Tensor) -> tuple[torch.Tensor, int, int]:
-        prep = self.weights.prepared()
-        nk = prep["neck"]
+    def neck_visual(self, vis, B: int):
+        """The text-independent branches of the neck (``f1/f2/f3_v_proj``, layers.py:414-427 before the text gate): no tape, and -- being
+        independent of the text tower -- enqueued while that tower runs on the side stream (forward)."""
+        nk = self.weights.prepared()["neck"]
         (v3, H3, W3), (v4, H4, W4), (v5, H5, W5) = vis
-        B = state.shape[0]
-        with torch.no_grad():  # text-independent branches
+        with torch.no_grad():
             f5pre = C.flinear(v5, nk["f1_v_proj"], RELU)
             Cn = f5pre.shape[1]
             scale_b = nk["norm_scale"].expand(B, Cn).contiguous()
             f5pre = hip.film_fwd(f5pre.view(B, H5 * W5, Cn), scale_b, torch.zeros_like(scale_b))  # BN scale of norm_layer
             f4a = C.fconv3(v4, nk["f2_v_proj"], B, H4, W4, RELU)
             f3a = hip.avgpool_fwd(C.fconv3(v3, nk["f3_v_proj"], B, H3, W3, RELU), B, H3, W3, 2)
+        return f5pre, f4a, f3a
+
+    def neck_forward(self, vis, state: torch.Tensor, visual=None) -> tuple[torch.Tensor, int, int]:
+        prep = self.weights.prepared()
+        nk = prep["neck"]
+        (v3, H3, W3), (v4, H4, W4), (v5, H5, W5) = vis
+        B = state.shape[0]
+        f5pre, f4a, f3a = visual if visual is not None else self.neck_visual(vis, B)
+        Cn = f5pre.shape[-1]
         s = C.flinear_g(state, nk["txt_proj"], RELU)  # [B, C5]
         f5 = C.ReluFn.apply(ops.FilmFn.apply(f5pre, s, nk["norm_shift"].expand(B, Cn).contiguous())).view(B * H5 * W5, Cn)
         f5u = C.BilinearUpFn.apply(f5, B, H5, W5, 2)
@@ -246,7 +256,7 @@ class COOPCRIS(nn.Module):
             word = C.flinear_g(state, pj["txt"])
         return C.DynConvFn.apply(x, word, B, 4 * H, 4 * W)  # [B, 4H, 4W]
 
-    def get_unimodal_outputs(self, image_input: torch.Tensor, input_ids: torch.Tensor, *args, **kwargs):
+    def encode_image_features(self, image_input: torch.Tensor):
         vis = self.encode_image(image_input)
         image_features = None
         if self._is_cocoop:  # C5.mean((2, 3)) (coop_cris.py:96-99) == one avg-pool window covering the whole map
@@ -255,6 +265,10 @@ class COOPCRIS(nn.Module):
                 raise NotImplementedError("square inputs only")
             with torch.no_grad():
                 image_features = hip.avgpool_fwd(x5, image_input.shape[0], H5, W5, H5)
+        return vis, image_features
+
+    def get_unimodal_outputs(self, image_input: torch.Tensor, input_ids: torch.Tensor, *args, **kwargs):
+        vis, image_features = self.encode_image_features(image_input)
         words, state = self.encode_text(input_ids, image_features, *args, **kwargs)
         return vis, words, state
 
@@ -265,8 +279,16 @@ class COOPCRIS(nn.Module):
         if image_input.shape[-1] != self.img_size or image_input.shape[-2] != self.img_size:
             raise ValueError(f"COOPCRIS was built for img_size={self.img_size}, got {tuple(image_input.shape[-2:])}")
         pad_mask = self.get_pad_mask(input_ids.to(image_input.device), None if attention_mask is None else attention_mask.to(image_input.device))
-        vis, words, state = self.get_unimodal_outputs(image_input, input_ids, key_padding_mask=pad_mask)
-        fq, H, W = self.neck_forward(vis, state)
+        # The text tower (12 layers over B * L <= 640 rows: latency-bound launches on a fraction of the CUs) shares nothing with the neck's
+        # text-independent convs: it runs on the side stream, forked AFTER the image tower (CoCoOp's meta-net reads C5), while the main
+        # stream goes on with those convs -- the forward overlap only (in the backward the text tower is the last thing left).
+        vis, image_features = self.encode_image_features(image_input)
+        side = SideStream(image_input.device)
+        with side:
+            words, state = self.encode_text(input_ids, image_features, key_padding_mask=pad_mask)
+        visual = self.neck_visual(vis, B)
+        side.join(words, state)
+        fq, H, W = self.neck_forward(vis, state, visual)
         fq = self.decoder_forward(fq, H, W, words, pad_mask)
         pred = self.proj_forward(fq, H, W, state)
         logits = C.BicubicFn.apply(pred, self.img_size, self.img_size)
