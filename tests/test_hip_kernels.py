@@ -776,7 +776,7 @@ def test_gemm_h2_pre_activation_in_accumulator_order_round_trips(hip):
     (a1, d1, s1, f1), (a0, d0, s0, f0) = res
     assert torch.equal(a1, a0) and torch.equal(s1, s0)
     if hip.GEMM_ZHALF:
-        assert z.numel() == (hip.load().tvl_gemm_aux_floats(M, N) + 1) // 2
+        assert hip.gemm_aux(M, N, "cuda").numel() == (hip.load().tvl_gemm_aux_floats(M, N) + 1) // 2   # one fp16 per element
         # one fp16 rounding of the factor: 2^-11 relative where QuickGELU'(z) is a normal fp16, 2^-25 absolute (times the row's largest |dy W2|, bounded
         # here by the row's largest |dz| / min |factor| ~ a few row maxima) where it is subnormal (|factor| < 6e-5: z far in the negative tail)
         rowmax = f0.abs().amax(1, keepdim=True)

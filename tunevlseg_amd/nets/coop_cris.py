@@ -18,7 +18,6 @@ from .. import cris_ops as C
 from .. import hip, ops
 from ..cris_backbone import CRISWeights
 from .context_learner import CoCoOpContextLearner, CoOpContextLearner
-from .towers import SideStream
 
 RELU, NONE = hip.ACT_RELU, hip.ACT_NONE
 LN_EPS = 1e-5
@@ -279,16 +278,10 @@ class COOPCRIS(nn.Module):
         if image_input.shape[-1] != self.img_size or image_input.shape[-2] != self.img_size:
             raise ValueError(f"COOPCRIS was built for img_size={self.img_size}, got {tuple(image_input.shape[-2:])}")
         pad_mask = self.get_pad_mask(input_ids.to(image_input.device), None if attention_mask is None else attention_mask.to(image_input.device))
-        # The text tower (12 layers over B * L <= 640 rows: latency-bound launches on a fraction of the CUs) shares nothing with the neck's
-        # text-independent convs: it runs on the side stream, forked AFTER the image tower (CoCoOp's meta-net reads C5), while the main
-        # stream goes on with those convs -- the forward overlap only (in the backward the text tower is the last thing left).
-        vis, image_features = self.encode_image_features(image_input)
-        side = SideStream(image_input.device)
-        with side:
-            words, state = self.encode_text(input_ids, image_features, key_padding_mask=pad_mask)
-        visual = self.neck_visual(vis, B)
-        side.join(words, state)
-        fq, H, W = self.neck_forward(vis, state, visual)
+        # (Measured in round 4 and dropped: the text tower on a side stream beside the neck's text-independent convs -- 35.3-35.5 ms against
+        # 35.1 ms on one box: those convs fill the chip, the tower's latency-bound launches only get in their way.)
+        vis, words, state = self.get_unimodal_outputs(image_input, input_ids, key_padding_mask=pad_mask)
+        fq, H, W = self.neck_forward(vis, state)
         fq = self.decoder_forward(fq, H, W, words, pad_mask)
         pred = self.proj_forward(fq, H, W, state)
         logits = C.BicubicFn.apply(pred, self.img_size, self.img_size)
