@@ -81,3 +81,16 @@ def test_product_never_imports_oracle():
     pkg = ROOT / "tunevlseg_amd"
     for f in pkg.rglob("*.py"):
         assert "oracle" not in f.read_text().replace("CPU oracle", ""), f
+
+
+def test_no_kernel_outside_the_allow_list_owns_scratch():
+    """tools/kernel_resources.py --check on the built library (the gate csrc/Makefile runs at link time): a private segment only in the 256-row
+    tile of the ring GEMM, and there no scratch instruction inside the hand-counted DMA ring."""
+    import subprocess
+    import sys
+
+    from tunevlseg_amd import hip
+
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "kernel_resources.py"), "--check", str(hip.LIB_PATH)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "with a private segment" in r.stdout
