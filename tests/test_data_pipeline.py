@@ -305,3 +305,22 @@ def test_token_ids_outside_the_embedding_table_give_nan_rows_not_a_wild_read():
     out = hip.text_assemble(ids, hip.const_i32([0, 1, 2, 3], "cuda"), table, None, 0, pos, 1, 4, 32)
     assert torch.equal(out[0, 0], table[62]) and torch.equal(out[0, 1], table[5]) and torch.equal(out[0, 3], table[63])
     assert torch.isnan(out[0, 2]).all()
+
+
+@pytest.mark.skipif(not REF_BPE.exists(), reason="the CLIP merge table is not shipped with the repo (build container only)")
+def test_denseclip_class_names_tokenise_to_the_references_own_ids():
+    """DenseCLIP's ``self.texts`` (denseclip.py:99-101): [SOT, ids, EOT, 0-pads] per class name in the id order of the reference's vendored
+    tokenizer (specials at 512 / 513, merges two places later than OpenAI's) -- the golden file's ids verbatim."""
+    from tunevlseg_amd.nets.denseclip import tokenize
+
+    names = ["polyp", "Skin Melanoma", "a photo of a"]
+    by_text = {c["text"]: c["ids"] for c in GOLDEN["cases"]}
+    t = tokenize(names, 8, REF_BPE)
+    assert t.shape == (3, 8) and t.dtype == torch.long
+    for row, name in zip(t.tolist(), names):
+        want = [GOLDEN["bos"], *by_text[name], GOLDEN["eos"]]
+        assert row == want + [0] * (8 - len(want)), name
+    hf = tokenize(names, 8, REF_BPE, vendored_ids=False)
+    assert hf[0, 0].item() == 49406 and hf[0].max().item() == 49407
+    with pytest.raises(RuntimeError, match="too long for context length"):
+        tokenize(["one small pink round polyp located in center of the image."], 5, REF_BPE)

@@ -308,16 +308,24 @@ def hip_zeros(B: int, Cc: int, device) -> torch.Tensor:
     return _ZEROS[key]
 
 
-def tokenize(class_names: Iterable[str], context_length: int, bpe_path=None) -> torch.Tensor:
+def tokenize(class_names: Iterable[str], context_length: int, bpe_path=None, vendored_ids: bool = True) -> torch.Tensor:
     """``torch.cat([tokenize(c, context_length=...) for c in class_names])`` (denseclip.py:99-101, untils.py:173-221): [SOT, ids, EOT] zero-padded;
-    a name that does not fit raises like the reference (``truncate=False``)."""
+    a name that does not fit raises like the reference (``truncate=False``).
+
+    ``vendored_ids`` (default): the ids of the reference's own ``SimpleTokenizer`` (untils.py:96-104), whose vocabulary lists the two specials
+    right AFTER the 512 byte symbols -- SOT = 512, EOT = 513, every merge two places later than in OpenAI's order -- so that the rows of
+    ``text_encoder.token_embedding`` a class name selects, and the row ``text.argmax(-1)`` pools, are the ones the reference selects
+    (a quirk that is behaviour: with it EOT is NOT the largest id of a row).  False: OpenAI / HF order (specials last)."""
     from ..data.tokenizer import ClipBpeTokenizer
 
     tok = ClipBpeTokenizer(bpe_path)
+    bos, eos = tok.bos_token_id, tok.eos_token_id
     rows = []
     for name in class_names:
         ids = tok(name)["input_ids"]
         if len(ids) > context_length:
             raise RuntimeError(f"Input {name} is too long for context length {context_length}")
+        if vendored_ids:
+            ids = [512 if i == bos else 513 if i == eos else (i if i < 512 else i + 2) for i in ids]
         rows.append(ids + [0] * (context_length - len(ids)))
     return torch.tensor(rows, dtype=torch.long)
