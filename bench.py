@@ -143,7 +143,7 @@ def rocprof_avg_us(workload: str, kernel: str):
     return None, None
 
 
-def cpu_baseline(steps32: int = 2, steps4: int = 10) -> dict:
+def cpu_baseline(steps32: int = 3, steps4: int = 10) -> dict:
     """The reference's trainer=cpu path on the host cores of this box: the CPU oracle -- a port pinned by the
     golden fixtures; the reference's own Python cannot travel -- runs the identical train step (forward, DiceCE, backward, AdamW),
     fp32, ``set_float32_matmul_precision("medium")`` (reference src/models/__init__.py:6), all host threads.
@@ -216,7 +216,7 @@ def main():
     ap.add_argument("--cond-cache", action="store_true",
                     help="vpt only: keep the frozen text tower's conditional embeddings per distinct token row (skips work: NOT the headline number; "
                          "the line is marked cond_cache=true)")
-    ap.add_argument("--cpu-steps32", type=int, default=2, help="timed CPU-oracle steps at the headline shape (bs 32)")
+    ap.add_argument("--cpu-steps32", type=int, default=3, help="timed CPU-oracle steps at the headline shape (bs 32)")
     ap.add_argument("--cpu-steps4", type=int, default=10, help="timed CPU-oracle steps of config C1 (CoOp-4, bs 4)")
     ap.add_argument("--workload", choices=("vpt", "cris", "maple", "vit640", "denseclip"), default="vpt",
                     help="vpt = BASELINE configs[1] (the headline line); cris = configs[2] (CRIS + CoCoOp, 416x416) and maple = configs[3] "
