@@ -433,7 +433,14 @@ __global__ __launch_bounds__(512) void gemm_h2m_kernel(Tp3Params p) {
         const int gm0 = group * GROUP_M;
         const int gm = p.tiles_m - gm0 < GROUP_M ? p.tiles_m - gm0 : GROUP_M;
         const int in_group = bid - group * gsize_full;
-        const int tile_m = gm0 + in_group % gm, tile_n = in_group / gm;
+        int tile_m = gm0 + in_group % gm, tile_n = in_group / gm;
+        if constexpr (BM == 192) if (p.row_walk) {   // (192-row tile only: any change of the 256-row instantiations, which sit on the 256-VGPR cliff, moves their spills)
+            // few column tiles (N = 768: three): walk them fastest, so that all column tiles of a row tile sit side by side in ONE XCD's chunk of the
+            // grid and A's rows are fetched into one L2 only -- the grouped order above puts a group's later columns into the next XCD's chunk
+            // whenever a chunk (31-32 tiles) ends inside a group (traffic of out-proj / fc2: 1.43x algorithmic)
+            tile_m = bid / p.tiles_n;
+            tile_n = bid - tile_m * p.tiles_n;
+        }
         kbase = 2 * t0;
 
         // this wave's DMA sources (slab 0): wave-uniform bases + one lane offset
@@ -547,6 +554,10 @@ int launch_m(const Tp3Params& p0, hipStream_t s) {
     Tp3Params p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + 255) / 256;
+    {
+        static const int walk = getenv("TVL_GEMM_ROWWALK") ? atoi(getenv("TVL_GEMM_ROWWALK")) : 1;
+        p.row_walk = (walk && !CONV && p.tiles_n <= 4) ? 1 : 0;
+    }
     constexpr size_t stage_bytes = (size_t)4 * (2 * (BM + 256) / 32) * PIECE;
     constexpr size_t epi_bytes = (size_t)8 * (BM / 2) * 37 * sizeof(float);
     constexpr size_t ks_bytes = KS ? (size_t)BM * 64 * sizeof(float) : 0;

@@ -72,6 +72,7 @@ struct Tp3Params {
     // row m of the GEMM gathers its nine taps from it (3x3, pad 1, stride 1; K = 9 * 16 * cC16 ordered (c / 16, ky, kx, c % 16))
     int cH, cW, cC16;
     int tiles_m, tiles_n;
+    int row_walk;        // gemm_h2m_kernel: column tiles fastest in the tile walk (few column tiles: all of a row tile's in one XCD's chunk)
     int stagger_ticks;   // NW = 4 kernels: start delay (10 ns ticks of s_memrealtime) of the second workgroup of each CU, 0 = none
     int f32_direct;                 // gemm_h2m_kernel: plain fp32-output epilogues straight from the accumulators (64-byte row segments, no LDS round trip)
     int aux_blocked;                // gemm_h2m_kernel's direct epilogue: pre_out / dact_aux in accumulator order (tvlGemmTp3Args.aux_blocked)
