@@ -447,6 +447,9 @@ int tvl_tconv2x2_unshuffle(const float* in, float* out, int32_t ldo, int32_t B, 
 /* out[r, c] = a[r, c] + g[c] * b[r, c]  (text_embeddings + gamma * text_diff, denseclip.py:157); bwd: db = d * g (may be NULL), dg[c] = sum_r d * b (may be NULL) */
 int tvl_colscale_add(const float* a, const float* b, const float* g, float* out, int64_t rows, int32_t cols, tvlStream_t stream);
 int tvl_colscale_bwd(const float* d, const float* b, const float* g, float* db, float* dg, int64_t rows, int32_t cols, tvlStream_t stream);
+/* out[b*rows + i, k] = full[b*T + skip + i, b*K + k]: the per-sample score maps (denseclip.py:162-165) as the diagonal blocks of ONE GEMM of all samples' pixel rows
+ * against all samples' class vectors, full [B*T, ld >= B*K] */
+int tvl_blockdiag_gather(const float* full, int32_t ld, float* out, int32_t B, int32_t T, int32_t skip, int32_t rows, int32_t K, tvlStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -206,6 +206,7 @@ _SIGS = {
     "tvl_tconv2x2_unshuffle": [_P, _P, _I, _I, _I, _I, _I, _I],
     "tvl_colscale_add": [_P, _P, _P, _P, _L, _I],
     "tvl_colscale_bwd": [_P, _P, _P, _P, _P, _L, _I],
+    "tvl_blockdiag_gather": [_P, _I, _P, _I, _I, _I, _I, _I],
 }
 EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_build_flags", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_h2_bytes", "tvl_dicece_work_doubles",
            "tvl_gemm_aux_floats", "tvl_mlp64_image_bytes", "tvl_groupnorm_work_doubles", *_SIGS]
@@ -1797,3 +1798,10 @@ def colscale_bwd(d: torch.Tensor, b: torch.Tensor, g: torch.Tensor, want_db: boo
     dg = torch.empty_like(g) if want_dg else None
     _call("tvl_colscale_bwd", _p(d), _p(b), _p(g), _p(db), _p(dg), d.numel() // d.shape[-1], d.shape[-1])
     return db, dg
+
+
+def blockdiag_gather(full: torch.Tensor, B: int, T: int, skip: int, rows: int, K: int) -> torch.Tensor:
+    """out[b*rows + i, k] = full[b*T + skip + i, b*K + k] (full: [B*T, B*K])."""
+    out = torch.empty((B * rows, K), device=full.device, dtype=torch.float32)
+    _call("tvl_blockdiag_gather", _p(full), full.stride(0), _p(out), B, T, skip, rows, K)
+    return out
