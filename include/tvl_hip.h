@@ -450,6 +450,19 @@ int tvl_colscale_bwd(const float* d, const float* b, const float* g, float* db, 
 /* out[b*rows + i, k] = full[b*T + skip + i, b*K + k]: the per-sample score maps (denseclip.py:162-165) as the diagonal blocks of ONE GEMM of all samples' pixel rows
  * against all samples' class vectors, full [B*T, ld >= B*K] */
 int tvl_blockdiag_gather(const float* full, int32_t ld, float* out, int32_t B, int32_t T, int32_t skip, int32_t rows, int32_t K, tvlStream_t stream);
+/* Cross-attention with few queries (Tq <= 32) and many keys, no masks: DenseCLIP's ContextDecoder (models.py:463-481,520-524: the K class embeddings attend over
+ * 1 + H*W visual tokens).  The key dimension carries the parallelism and the probabilities are materialised ([B, H, Tq, Tk] fp32); all sums in a fixed order.
+ * Matrices are [B*T, ld] with head h in columns h*dh ..; dh in {16, 32, 64}.
+ *   tvl_fq_qk       S[b,h,q,k] = alpha * <A[b,q,h,:], Bm[b,k,h,:]>            S = Q K^T * scale;  dP = dO V^T
+ *   tvl_fq_softmax  rows of S -> probabilities in place; lse[row] (natural log, may be NULL)
+ *   tvl_fq_pk       O[b,q,h,:] = alpha * sum_k P[b,h,q,k] Bm[b,k,h,:]         O = P V;  dQ = scale * dS K
+ *   tvl_fq_ds       dP := P * (dP - <dO[b,q,h,:], O[b,q,h,:]>)                 the softmax backward
+ *   tvl_fq_tk       G[b,k,h,:] = alpha * sum_q W[b,h,q,k] A[b,q,h,:]          dV = P^T dO;  dK = scale * dS^T Q */
+int tvl_fq_qk(const float* A, int32_t lda, const float* Bm, int32_t ldb, float* S, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t dh, float alpha, tvlStream_t stream);
+int tvl_fq_softmax(float* S, float* lse, int64_t rows, int32_t Tk, tvlStream_t stream);
+int tvl_fq_pk(const float* P, const float* Bm, int32_t ldb, float* O, int32_t ldo, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t dh, float alpha, tvlStream_t stream);
+int tvl_fq_ds(const float* P, float* dP, const float* dO, int32_t lddo, const float* O, int32_t ldo, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t dh, tvlStream_t stream);
+int tvl_fq_tk(const float* W, const float* A, int32_t lda, float* G, int32_t ldg, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t dh, float alpha, tvlStream_t stream);
 
 #ifdef __cplusplus
 }

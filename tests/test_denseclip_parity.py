@@ -161,3 +161,36 @@ def test_colscale_add_and_backward():
     ((a2 + g2 * b2) * w).sum().backward()
     for x, y in ((a, a2), (b, b2), (gm, g2)):
         assert (x.grad - y.grad).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,dh", [(3, 4, 20, 1601, 64), (2, 2, 7, 300, 16), (1, 4, 32, 257, 32), (16, 4, 20, 1601, 64)])
+def test_few_query_cross_attention_matches_torch(B, H, Tq, Tk, dh):
+    """csrc/attention_fq.hip through the autograd node the context decoder uses: output and all three gradients against float64 torch; repeated calls
+    bit-identical (every reduction has a fixed order); the dispatch takes the few-query kernels for these shapes and leaves dK / dV out when unasked."""
+    from tunevlseg_amd import cris_ops as C
+    from tunevlseg_amd import hip
+
+    assert hip.fq_attention_ok(Tq, Tk, dh, False, None) and not hip.fq_attention_ok(Tq, Tk, dh, False, torch.ones(1))
+    D = H * dh
+    g = torch.Generator().manual_seed(B * 1000 + Tk)
+    q, k, v = torch.randn(B * Tq, D, generator=g), torch.randn(B * Tk, D, generator=g), torch.randn(B * Tk, D, generator=g)
+    w = torch.randn(B * Tq, D, generator=g)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.view(B, -1, H, dh).transpose(1, 2) for t in (qd, kd, vd))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * dh**-0.5, -1) @ vh).transpose(1, 2).reshape(B * Tq, D)
+    (ref * w.double()).sum().backward()
+    outs = []
+    for _ in range(2):
+        qg, kg, vg = (t.cuda().requires_grad_(True) for t in (q, k, v))
+        o = C.CrossAttnFn.apply(qg, kg, vg, None, B, Tq, Tk, H, dh)
+        (o * w.cuda()).sum().backward()
+        outs.append((o.detach().clone(), qg.grad.clone(), kg.grad.clone(), vg.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    o, dq, dk, dv = outs[0]
+    for got, want in ((o, ref.detach()), (dq, qd.grad), (dk, kd.grad), (dv, vd.grad)):
+        assert (got.cpu().double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    # frozen keys / values (the prompt-tuning path): only dQ is computed
+    qg = q.cuda().requires_grad_(True)
+    o2 = C.CrossAttnFn.apply(qg, k.cuda(), v.cuda(), None, B, Tq, Tk, H, dh)
+    (o2 * w.cuda()).sum().backward()
+    assert torch.equal(o2.detach(), o) and torch.equal(qg.grad, dq)

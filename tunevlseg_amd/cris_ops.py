@@ -309,20 +309,30 @@ FFN_H2 = __import__("os").environ.get("TVL_CRIS_FFN_H2", "1") != "0"   # A/B swi
 
 
 class CrossAttnFn(Fn):
-    """T visual queries x Tk word keys with a key-padding mask (layers.py:341-349)."""
+    """T visual queries x Tk word keys with a key-padding mask (layers.py:341-349); also DenseCLIP's context decoder (K class queries x 1 + H*W
+    visual keys, models.py:463-481), which takes the few-query kernels (csrc/attention_fq.hip) and computes dK / dV only when asked."""
 
     @staticmethod
     def forward(ctx, q, k, v, key_mask, B, T, Tk, H, dh):
         q, k, v = _c(q), _c(k), _c(v)
+        ctx.geom = (B, T, Tk, H, dh)
+        ctx.fq = hip.fq_attention_ok(T, Tk, dh, False, key_mask)
+        if ctx.fq:
+            o, P = hip.fq_attn_fwd(q, k, v, B, T, Tk, H, dh, dh**-0.5)
+            ctx.save_for_backward(q, k, v, o, P, None)
+            return o
         o, lse = hip.attn_fwd(q, k, v, B, T, Tk, H, dh, dh**-0.5, key_mask=key_mask)
         ctx.save_for_backward(q, k, v, o, lse, key_mask)
-        ctx.geom = (B, T, Tk, H, dh)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
         q, k, v, o, lse, key_mask = ctx.saved_tensors
         B, T, Tk, H, dh = ctx.geom
+        if ctx.fq:
+            dq, dk, dv = hip.fq_attn_bwd(q, k, v, o, _c(d_o), lse, B, T, Tk, H, dh, dh**-0.5, need_dq=ctx.needs_input_grad[0],
+                                         need_dkv=ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+            return dq, dk, dv, None, None, None, None, None, None
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         hip.attn_bwd(q, k, v, o, _c(d_o), lse, dq, dk, dv, B, T, Tk, H, dh, dh**-0.5, key_mask=key_mask)
         return dq, dk, dv, None, None, None, None, None, None

@@ -207,6 +207,11 @@ _SIGS = {
     "tvl_colscale_add": [_P, _P, _P, _P, _L, _I],
     "tvl_colscale_bwd": [_P, _P, _P, _P, _P, _L, _I],
     "tvl_blockdiag_gather": [_P, _I, _P, _I, _I, _I, _I, _I],
+    "tvl_fq_qk": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F],
+    "tvl_fq_softmax": [_P, _P, _L, _I],
+    "tvl_fq_pk": [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F],
+    "tvl_fq_ds": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I],
+    "tvl_fq_tk": [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F],
 }
 EXPORTS = ["tvl_last_error", "tvl_abi_version", "tvl_build_flags", "tvl_dynconv_bwd_work_floats", "tvl_tp3_bytes", "tvl_h2_bytes", "tvl_dicece_work_doubles",
            "tvl_gemm_aux_floats", "tvl_mlp64_image_bytes", "tvl_groupnorm_work_doubles", *_SIGS]
@@ -1805,3 +1810,41 @@ def blockdiag_gather(full: torch.Tensor, B: int, T: int, skip: int, rows: int, K
     out = torch.empty((B * rows, K), device=full.device, dtype=torch.float32)
     _call("tvl_blockdiag_gather", _p(full), full.stride(0), _p(out), B, T, skip, rows, K)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# few-query cross-attention (csrc/attention_fq.hip): Tq <= 32 queries, many keys, no masks
+# --------------------------------------------------------------------------------------
+FQ_ATTN = os.environ.get("TVL_FQ_ATTN", "1") != "0"   # 0 = the flash kernels also for few queries (A/B switch)
+
+
+def fq_attention_ok(Tq: int, Tk: int, dh: int, causal: bool, key_mask) -> bool:
+    return bool(FQ_ATTN and Tq <= 32 and Tk >= 256 and dh in (16, 32, 64) and not causal and key_mask is None)
+
+
+def fq_attn_fwd(q, k, v, B: int, Tq: int, Tk: int, H: int, dh: int, scale: float):
+    """-> (o [B*Tq, H*dh], P [B, H, Tq, Tk])."""
+    P = torch.empty((B, H, Tq, Tk), device=q.device, dtype=torch.float32)
+    _call("tvl_fq_qk", _ps(q), q.stride(0), _ps(k), k.stride(0), _p(P), B, H, Tq, Tk, dh, float(scale))
+    _call("tvl_fq_softmax", _p(P), None, B * H * Tq, Tk)
+    o = torch.empty((B * Tq, H * dh), device=q.device, dtype=torch.float32)
+    _call("tvl_fq_pk", _p(P), _ps(v), v.stride(0), _p(o), o.stride(0), B, H, Tq, Tk, dh, 1.0)
+    return o, P
+
+
+def fq_attn_bwd(q, k, v, o, d_o, P, B: int, Tq: int, Tk: int, H: int, dh: int, scale: float, need_dq=True, need_dkv=True):
+    """dq [B*Tq, D], dk, dv [B*Tk, D] (each None when not asked for)."""
+    D = H * dh
+    dS = torch.empty_like(P)
+    _call("tvl_fq_qk", _ps(d_o), d_o.stride(0), _ps(v), v.stride(0), _p(dS), B, H, Tq, Tk, dh, 1.0)          # dP = dO V^T
+    _call("tvl_fq_ds", _p(P), _p(dS), _ps(d_o), d_o.stride(0), _ps(o), o.stride(0), B, H, Tq, Tk, dh)      # dS = P (dP - delta)
+    dq = dk = dv = None
+    if need_dq:
+        dq = torch.empty((B * Tq, D), device=q.device, dtype=torch.float32)
+        _call("tvl_fq_pk", _p(dS), _ps(k), k.stride(0), _p(dq), D, B, H, Tq, Tk, dh, float(scale))
+    if need_dkv:
+        dk = torch.empty((B * Tk, D), device=q.device, dtype=torch.float32)
+        dv = torch.empty((B * Tk, D), device=q.device, dtype=torch.float32)
+        _call("tvl_fq_tk", _p(dS), _ps(q), q.stride(0), _p(dk), D, B, H, Tq, Tk, dh, float(scale))
+        _call("tvl_fq_tk", _p(P), _ps(d_o), d_o.stride(0), _p(dv), D, B, H, Tq, Tk, dh, 1.0)
+    return dq, dk, dv
