@@ -460,7 +460,10 @@ int tvl_blockdiag_gather(const float* full, int32_t ld, float* out, int32_t B, i
  *   tvl_fq_tk       G[b,k,h,:] = alpha * sum_q W[b,h,q,k] A[b,q,h,:]          dV = P^T dO;  dK = scale * dS^T Q */
 int tvl_fq_qk(const float* A, int32_t lda, const float* Bm, int32_t ldb, float* S, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t dh, float alpha, tvlStream_t stream);
 int tvl_fq_softmax(float* S, float* lse, int64_t rows, int32_t Tk, tvlStream_t stream);
-int tvl_fq_pk(const float* P, const float* Bm, int32_t ldb, float* O, int32_t ldo, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t dh, float alpha, tvlStream_t stream);
+/* (tvl_fq_pk: P[b,h,q,k] at P + b*p_bs + h*p_hs + q*p_qs + k*p_ks, sample b of Bm at Bm + b*bm_bs: also the score map's text-side gradient dT[b] = dS[b]^T V[b] with
+ * p_hs = 0, p_qs = 1, p_ks = K over dS [B*H*W, K]) */
+int tvl_fq_pk(const float* P, int64_t p_bs, int64_t p_hs, int64_t p_qs, int64_t p_ks, const float* Bm, int64_t bm_bs, int32_t ldb, float* O, int32_t ldo, int32_t B, int32_t H,
+              int32_t Tq, int32_t Tk, int32_t dh, float alpha, tvlStream_t stream);
 int tvl_fq_ds(const float* P, float* dP, const float* dO, int32_t lddo, const float* O, int32_t ldo, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t dh, tvlStream_t stream);
 int tvl_fq_tk(const float* W, const float* A, int32_t lda, float* G, int32_t ldg, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t dh, float alpha, tvlStream_t stream);
 

@@ -73,9 +73,11 @@ __global__ __launch_bounds__(256) void fq_softmax_kernel(float* __restrict__ S, 
 
 // O[b, q, h, :] = alpha * sum_k P[b, h, q, k] Bm[b, k, h, :].  Workgroup (query group g of QG queries, h, b); 256 threads = DH/4 column quads x KG key groups:
 // P tiles [QG x 64 keys] staged in LDS, each thread walks its keys of the tile; the key groups meet in LDS and are added in a fixed order.
+// P is addressed as P + b * p_bs + h * p_hs + q * p_qs + k * p_ks and Bm's samples are bm_bs elements apart, so the same kernel serves the score map's
+// text-side gradient (dT[b] = dS[b]^T V[b]: the "queries" are the K classes, the "keys" the H*W pixels of dS [B*H*W, K], one P for all column blocks of V).
 template <int DH, int QG>
-__global__ __launch_bounds__(256) void fq_pk_kernel(const float* __restrict__ P, const float* __restrict__ Bm, int ldb, float* __restrict__ O, int ldo, int H, int Tq,
-                                                    int Tk, float alpha) {
+__global__ __launch_bounds__(256) void fq_pk_kernel(const float* __restrict__ P, long p_bs, long p_hs, long p_qs, long p_ks, const float* __restrict__ Bm, long bm_bs, int ldb,
+                                                    float* __restrict__ O, int ldo, int H, int Tq, int Tk, float alpha) {
     TVL_KERNEL_ENTRY();
     constexpr int CQ = DH / 4, KG = 256 / CQ;   // 16 column quads x 16 key groups at DH = 64
     __shared__ float Ps[QG][64];
@@ -85,19 +87,21 @@ __global__ __launch_bounds__(256) void fq_pk_kernel(const float* __restrict__ P,
     float4 acc[QG];
 #pragma unroll
     for (int q = 0; q < QG; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* Pb = P + (((long)b * H + h) * Tq + q0) * Tk;
+    const float* Pb = P + (long)b * p_bs + (long)h * p_hs + (long)q0 * p_qs;
+    const float* Bb = Bm + (long)b * bm_bs + h * DH;
     for (int k0 = 0; k0 < Tk; k0 += 64) {
         __syncthreads();
         for (int i = threadIdx.x; i < QG * 64; i += 256) {
-            const int q = i >> 6, kk = i & 63;
-            Ps[q][kk] = (q0 + q < Tq && k0 + kk < Tk) ? Pb[(long)q * Tk + k0 + kk] : 0.f;
+            // (q fastest when P's query stride is the unit one: adjacent threads then read adjacent addresses)
+            const int q = p_qs == 1 ? i % QG : i >> 6, kk = p_qs == 1 ? i / QG : i & 63;
+            Ps[q][kk] = (q0 + q < Tq && k0 + kk < Tk) ? Pb[(long)q * p_qs + (long)(k0 + kk) * p_ks] : 0.f;
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 64 / KG; ++j) {
             const int kk = kg + KG * j, key = k0 + kk;
             if (key < Tk) {
-                const float4 v = *reinterpret_cast<const float4*>(Bm + ((long)b * Tk + key) * ldb + h * DH + 4 * cq);
+                const float4 v = *reinterpret_cast<const float4*>(Bb + (long)key * ldb + 4 * cq);
 #pragma unroll
                 for (int q = 0; q < QG; ++q) {
                     const float p = Ps[q][kk];
@@ -199,12 +203,13 @@ extern "C" int tvl_fq_softmax(float* S, float* lse, int64_t rows, int32_t Tk, tv
     return 0;
 }
 
-extern "C" int tvl_fq_pk(const float* P, const float* Bm, int32_t ldb, float* O, int32_t ldo, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t dh, float alpha,
-                         tvlStream_t stream) {
+extern "C" int tvl_fq_pk(const float* P, int64_t p_bs, int64_t p_hs, int64_t p_qs, int64_t p_ks, const float* Bm, int64_t bm_bs, int32_t ldb, float* O, int32_t ldo, int32_t B,
+                         int32_t H, int32_t Tq, int32_t Tk, int32_t dh, float alpha, tvlStream_t stream) {
     TVL_REQUIRE(P && B > 0 && H > 0 && Tq > 0 && Tq <= FQ_MAXQ && Tk > 0 && B <= 65535 && H <= 65535, "tvl_fq_pk: bad shape (Tq = %d must be <= %d)", Tq, FQ_MAXQ);
-    TVL_REQUIRE(fq_ok(Bm, ldb, H, dh) && fq_ok(O, ldo, H, dh), "tvl_fq_pk: operands must be 16-byte aligned with row strides divisible by 4 and >= H*dh");
+    TVL_REQUIRE(fq_ok(Bm, ldb, H, dh) && fq_ok(O, ldo, H, dh) && bm_bs % 4 == 0, "tvl_fq_pk: operands must be 16-byte aligned with row / sample strides divisible by 4 and rows >= H*dh");
     constexpr int QG = 4;
-    FQ_DH_DISPATCH(dh, hipLaunchKernelGGL((fq_pk_kernel<DH, QG>), dim3((Tq + QG - 1) / QG, H, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P, Bm, ldb, O, ldo, H, Tq, Tk, alpha));
+    FQ_DH_DISPATCH(dh, hipLaunchKernelGGL((fq_pk_kernel<DH, QG>), dim3((Tq + QG - 1) / QG, H, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P, (long)p_bs, (long)p_hs, (long)p_qs,
+                                          (long)p_ks, Bm, (long)bm_bs, ldb, O, ldo, H, Tq, Tk, alpha));
     TVL_LAUNCH_CHECK("tvl_fq_pk");
     return 0;
 }

@@ -209,7 +209,7 @@ _SIGS = {
     "tvl_blockdiag_gather": [_P, _I, _P, _I, _I, _I, _I, _I],
     "tvl_fq_qk": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F],
     "tvl_fq_softmax": [_P, _P, _L, _I],
-    "tvl_fq_pk": [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F],
+    "tvl_fq_pk": [_P, _L, _L, _L, _L, _P, _L, _I, _P, _I, _I, _I, _I, _I, _I, _F],
     "tvl_fq_ds": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I],
     "tvl_fq_tk": [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F],
 }
@@ -1828,7 +1828,7 @@ def fq_attn_fwd(q, k, v, B: int, Tq: int, Tk: int, H: int, dh: int, scale: float
     _call("tvl_fq_qk", _ps(q), q.stride(0), _ps(k), k.stride(0), _p(P), B, H, Tq, Tk, dh, float(scale))
     _call("tvl_fq_softmax", _p(P), None, B * H * Tq, Tk)
     o = torch.empty((B * Tq, H * dh), device=q.device, dtype=torch.float32)
-    _call("tvl_fq_pk", _p(P), _ps(v), v.stride(0), _p(o), o.stride(0), B, H, Tq, Tk, dh, 1.0)
+    _call("tvl_fq_pk", _p(P), H * Tq * Tk, Tq * Tk, Tk, 1, _ps(v), Tk * v.stride(0), v.stride(0), _p(o), o.stride(0), B, H, Tq, Tk, dh, 1.0)
     return o, P
 
 
@@ -1841,10 +1841,21 @@ def fq_attn_bwd(q, k, v, o, d_o, P, B: int, Tq: int, Tk: int, H: int, dh: int, s
     dq = dk = dv = None
     if need_dq:
         dq = torch.empty((B * Tq, D), device=q.device, dtype=torch.float32)
-        _call("tvl_fq_pk", _p(dS), _ps(k), k.stride(0), _p(dq), D, B, H, Tq, Tk, dh, float(scale))
+        _call("tvl_fq_pk", _p(dS), H * Tq * Tk, Tq * Tk, Tk, 1, _ps(k), Tk * k.stride(0), k.stride(0), _p(dq), D, B, H, Tq, Tk, dh, float(scale))
     if need_dkv:
         dk = torch.empty((B * Tk, D), device=q.device, dtype=torch.float32)
         dv = torch.empty((B * Tk, D), device=q.device, dtype=torch.float32)
         _call("tvl_fq_tk", _p(dS), _ps(q), q.stride(0), _p(dk), D, B, H, Tq, Tk, dh, float(scale))
         _call("tvl_fq_tk", _p(P), _ps(d_o), d_o.stride(0), _p(dv), D, B, H, Tq, Tk, dh, 1.0)
     return dq, dk, dv
+
+
+def score_map_text_grad(dS: torch.Tensor, v_hat: torch.Tensor, B: int, T: int, skip: int, HW: int, K: int) -> torch.Tensor | None:
+    """dT[b] = dS[b]^T V[b] (dS [B*HW, K] contiguous, V = rows skip.. of every sample of v_hat [B*T, C]) on the few-query kernel: the K classes are
+    its "queries", the pixels its "keys", the C columns of V its heads of 64.  None when the shape does not fit (the caller then runs B TN GEMMs)."""
+    Cc = v_hat.shape[1]
+    if not (FQ_ATTN and K <= 32 and Cc % 64 == 0 and v_hat.stride(0) == Cc and dS.is_contiguous() and tuple(dS.shape) == (B * HW, K)):
+        return None
+    dt = torch.empty((B * K, Cc), device=dS.device, dtype=torch.float32)
+    _call("tvl_fq_pk", _p(dS), HW * K, 0, 1, K, v_hat[skip:].data_ptr(), T * Cc, Cc, _p(dt), Cc, B, Cc // 64, K, HW, 64, 1.0)
+    return dt.view(B, K, Cc)

@@ -79,9 +79,11 @@ class ScoreMapFn(ops.Fn):
         T = skip_rows + HW
         if d.dim() != 2 or d.stride(1) != 1:
             d = d.contiguous()
-        dt = torch.empty((B, K, Cc), device=d.device, dtype=torch.float32)
-        for b in range(B):
-            hip.gemm(hip.TN, K, Cc, HW, d[b * HW: (b + 1) * HW], d.stride(0), v_hat[b * T + skip_rows: (b + 1) * T], Cc, dt[b], Cc)
+        dt = hip.score_map_text_grad(d, v_hat, B, T, skip_rows, HW, K) if d.is_contiguous() else None   # one launch (up to 32 classes); else a TN GEMM per sample
+        if dt is None:
+            dt = torch.empty((B, K, Cc), device=d.device, dtype=torch.float32)
+            for b in range(B):
+                hip.gemm(hip.TN, K, Cc, HW, d[b * HW: (b + 1) * HW], d.stride(0), v_hat[b * T + skip_rows: (b + 1) * T], Cc, dt[b], Cc)
         return None, dt, None, None, None
 
 
