@@ -83,8 +83,6 @@ def kernels(lib: Path, check_placement: bool = False):
             txt = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True).stdout
             ring_syms = set()
             if check_placement:
-                for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?.*\.private_segment_fixed_size:\s+(\d+)", txt):
-                    pass
                 blocks = re.findall(r"- \.agpr_count:.*?(?=\n  - \.agpr_count:|\namdhsa\.target|\Z)", txt, re.S)
                 for blk in blocks:
                     nm = re.search(r"\.name:\s+(\S+)", blk).group(1)
