@@ -194,3 +194,30 @@ def test_few_query_cross_attention_matches_torch(B, H, Tq, Tk, dh):
     o2 = C.CrossAttnFn.apply(qg, k.cuda(), v.cuda(), None, B, Tq, Tk, H, dh)
     (o2 * w.cuda()).sum().backward()
     assert torch.equal(o2.detach(), o) and torch.equal(qg.grad, dq)
+
+
+def test_score_map_gradient_in_one_launch_equals_the_per_sample_gemms(monkeypatch):
+    """ScoreMapFn: the one-GEMM + diagonal-gather forward and the few-query-kernel backward against the per-sample GEMMs they replace (B = 1 takes
+    those; TVL_FQ_ATTN=0 forces them) and against float64 torch."""
+    from tunevlseg_amd import hip
+    from tunevlseg_amd.nets.denseclip import ScoreMapFn
+
+    B, HW, K, C_ = 5, 36, 7, 128
+    T = 1 + HW
+    g = torch.Generator().manual_seed(3)
+    v = torch.nn.functional.normalize(torch.randn(B * T, C_, generator=g), dim=1)
+    t = torch.nn.functional.normalize(torch.randn(B, K, C_, generator=g), dim=2)
+    w = torch.randn(B * HW, K, generator=g)
+    td = t.double().requires_grad_(True)
+    ref = torch.einsum("bic,bkc->bik", v.double().view(B, T, C_)[:, 1:], td).reshape(B * HW, K)
+    (ref * w.double()).sum().backward()
+    res = []
+    for fq in (True, False):
+        monkeypatch.setattr(hip, "FQ_ATTN", fq)
+        tg = t.cuda().requires_grad_(True)
+        s = ScoreMapFn.apply(v.cuda(), tg, B, HW, 1)
+        (s * w.cuda()).sum().backward()
+        res.append((s.detach().cpu(), tg.grad.cpu()))
+        assert (res[-1][0].double() - ref.detach()).abs().max().item() <= 1e-5
+        assert (res[-1][1].double() - td.grad).abs().max().item() <= 1e-4 * td.grad.abs().max().item()
+    assert (res[0][1] - res[1][1]).abs().max().item() <= 1e-5 * res[1][1].abs().max().item()
