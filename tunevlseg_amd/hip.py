@@ -830,6 +830,8 @@ def h2_kernel_name(M, N, bias, residual, act, dact, pre_out, c_f32, c_tp3, tile_
 def conv_h2_tile(M: int, N: int) -> int:
     """Rows per workgroup of tvl_conv3x3_h2 (the rule of csrc/gemm_h2.hip): fewest rounds x rows, ties to the larger tile.  (A 128-row
     tile for the 26 x 26 / 13 x 13 maps measured no gain on the CRIS step and was dropped.)"""
+    if CONV_TILE in (192, 256):
+        return CONV_TILE
     t256, t192 = -(-M // 256) * -(-N // 256), -(-M // 192) * -(-N // 256)
     return 256 if -(-t256 // 256) * 256 <= -(-t192 // 256) * 192 else 192
 
@@ -1036,6 +1038,7 @@ def layernorm_bwd_tp3(dy2d, x2d, gamma, mean, rstd, dres=None):
     return dx, dxt
 
 
+CONV_TILE = int(os.environ.get("TVL_CONV_TILE", "0"))   # rows per workgroup of tvl_conv3x3_h2: 0 = its own rule, 192 / 256 = forced (A/B switch, tools/bench_conv.py)
 CONV_H2 = os.environ.get("TVL_CONV_H2", "1") != "0"   # 3x3 convs over frozen weights (C % 32 == 0, N >= 128) as an implicit GEMM on two fp16 pieces
 PACK_H2_MIN_N = int(os.environ.get("TVL_PACK_H2_MIN_N", "256"))
 PACK_H2_MIN_K = int(os.environ.get("TVL_PACK_H2_MIN_K", "256"))
@@ -1721,7 +1724,7 @@ def conv3x3(x2d: torch.Tensor | None, B: int, H: int, W: int, Wm: torch.Tensor, 
         xa = packed if packed is not None else h2_pack(x2d, per_row=False, zero_tail=True, relu_mask=x_relu_mask)
         wb = conv_weight_h2_cached(Wm, Cc)
         args = GemmTp3Args(M, N, 9 * Cc, xa.buf.data_ptr(), M, wb.buf.data_ptr(), wb.rows, _ps(y), y.stride(0), None, _p(bias), None, 0, act, None, None, 0,
-                           ACT_NONE, wb.alpha(), 0, 0)
+                           ACT_NONE, wb.alpha(), CONV_TILE, 0)
         geom = ConvGeom(B, H, W, Cc, 1)
         if _gemm_prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
