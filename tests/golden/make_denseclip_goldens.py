@@ -89,7 +89,7 @@ def glue(cfg, feats, text_encoder, context_decoder, texts, contexts, gamma):
     return text_embeddings, x_orig, score_map
 
 
-def run_case(M, name: str, cfg: DenseCLIPConfig, *, wseed: int, iseed: int, B: int, H: int, compact: bool):
+def run_case(M, name: str, cfg: DenseCLIPConfig, *, wseed: int, iseed: int, B: int, H: int, compact: bool, W: int | None = None):
     if ONLY and not any(name.startswith(o) for o in ONLY):
         return
     torch.set_float32_matmul_precision("highest")
@@ -100,7 +100,7 @@ def run_case(M, name: str, cfg: DenseCLIPConfig, *, wseed: int, iseed: int, B: i
     g = torch.Generator().manual_seed(3000 + iseed)
     contexts = (torch.randn(1, cfg.num_contexts, cfg.token_embed_dim, generator=g) * 0.1).requires_grad_(True)
     gamma = (0.3 + 0.1 * torch.randn(cfg.text_dim, generator=g)).requires_grad_(True)
-    pix, texts, gs, gt = synth_denseclip_inputs(cfg, B, H, iseed)
+    pix, texts, gs, gt = synth_denseclip_inputs(cfg, B, H, iseed, W)
 
     def run(dtype):
         c_, g_ = (contexts.detach().to(dtype).requires_grad_(True), gamma.detach().to(dtype).requires_grad_(True))
@@ -142,7 +142,7 @@ def run_case(M, name: str, cfg: DenseCLIPConfig, *, wseed: int, iseed: int, B: i
         if keep(k, v):
             arrays["grad64." + k] = v.float().numpy()
     dev = max(float((grads[k].double() - grads64[k]).norm() / grads64[k].norm().clamp(min=1e-30)) for k in ("contexts", "gamma"))
-    meta = {"name": name, "family": "denseclip", "compact": compact, "config": cfg.to_dict(), "weight_seed": wseed, "input_seed": iseed, "B": B, "H": H,
+    meta = {"name": name, "family": "denseclip", "compact": compact, "config": cfg.to_dict(), "weight_seed": wseed, "input_seed": iseed, "B": B, "H": H, "W": H if W is None else W,
             "weights_checksum": float(sum(v.double().abs().sum() for k, v in sd.items() if k not in ("contexts", "gamma"))), "torch": torch.__version__}
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(OUT / f"{name}.npz", **arrays)
@@ -159,6 +159,8 @@ def main():
     run_case(M, "denseclip_tiny_b2_96", tiny, wseed=51, iseed=51, B=2, H=96, compact=False)
     # the checkpoint's own grid (identity resize), odd batch, more classes than decoder heads
     run_case(M, "denseclip_tiny_b3_64_k7", DenseCLIPConfig.tiny(num_classes=7), wseed=52, iseed=52, B=3, H=64, compact=False)
+    # a non-square image: the position table resized 4 x 4 -> 4 x 6 (models.py:684-690 takes (H, W)), every map H != W
+    run_case(M, "denseclip_tiny_b2_64x96", tiny, wseed=53, iseed=53, B=2, H=64, W=96, compact=False)
     # BASELINE configs[4] geometry: ViT-B/16 at 640 x 640, 20 classes, 8 contexts (compact: large maps subsampled)
     run_case(M, "denseclip_vitb16_640_b1", DenseCLIPConfig.vitb16_640(), wseed=61, iseed=61, B=1, H=640, compact=True)
     # ... and with two samples (the per-sample context decoder / score map over a batch)

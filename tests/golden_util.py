@@ -254,12 +254,13 @@ def denseclip_state_of(fx) -> dict[str, torch.Tensor]:
     return sd
 
 
-def synth_denseclip_inputs(cfg: DenseCLIPConfig, B: int, H: int, seed: int):
-    """img N(0,1) [B, 3, H, H]; class-name token rows as the reference's ``tokenize(name, context_length)`` lays them out
+def synth_denseclip_inputs(cfg: DenseCLIPConfig, B: int, H: int, seed: int, W: int | None = None):
+    """img N(0,1) [B, 3, H, W] (W defaults to H); class-name token rows as the reference's ``tokenize(name, context_length)`` lays them out
     (untils.py:173-221): [SOT, words, EOT, 0-pads] with EOT the highest id, 1 .. context_length - 2 words per class; the two seeded
     cotangents of the fixture scalar  L = sum(score_map * Gs) + sum(text_embeddings * Gt)."""
     g = torch.Generator().manual_seed(seed)
-    pix = torch.randn(B, 3, H, H, generator=g)
+    W = H if W is None else W
+    pix = torch.randn(B, 3, H, W, generator=g)
     K, N1 = cfg.num_classes, cfg.context_length
     sot, eot = cfg.vocab_size - 2, cfg.vocab_size - 1
     texts = torch.zeros(K, N1, dtype=torch.long)
@@ -267,8 +268,7 @@ def synth_denseclip_inputs(cfg: DenseCLIPConfig, B: int, H: int, seed: int):
         n_words = 1 + k % (N1 - 2)
         row = [sot, *torch.randint(1, min(cfg.vocab_size - 2, 40000), (n_words,), generator=g).tolist(), eot]
         texts[k, : len(row)] = torch.tensor(row)
-    G = H // cfg.patch_size
-    gs = torch.randn(B, K, G, G, generator=g)
+    gs = torch.randn(B, K, H // cfg.patch_size, W // cfg.patch_size, generator=g)
     gt = torch.randn(B, K, cfg.embed_dim, generator=g) * 0.1
     return pix, texts, gs, gt
 

@@ -12,7 +12,7 @@ from tests.golden_util import (denseclip_config_of, denseclip_state_of, densecli
 def run_oracle(fx, train_decoder: bool = True):
     cfg, sd = denseclip_config_of(fx), denseclip_state_of(fx)
     m = fx["meta"]
-    pix, texts, gs, gt = synth_denseclip_inputs(cfg, m["B"], m["H"], m["input_seed"])
+    pix, texts, gs, gt = synth_denseclip_inputs(cfg, m["B"], m["H"], m["input_seed"], m.get("W"))
     if "in.pixel_values" in fx:
         assert torch.equal(pix, torch.from_numpy(fx["in.pixel_values"]))
     assert torch.equal(texts, torch.from_numpy(fx["in.texts"]))

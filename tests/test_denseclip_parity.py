@@ -33,7 +33,7 @@ def test_denseclip_matches_reference(name):
     fx = load_golden(name)
     m = fx["meta"]
     net, cfg = build(fx, train_decoder=True)
-    pix, texts, gs, gt = synth_denseclip_inputs(cfg, m["B"], m["H"], m["input_seed"])
+    pix, texts, gs, gt = synth_denseclip_inputs(cfg, m["B"], m["H"], m["input_seed"], m.get("W"))
     text_embeddings, maps, score_map = net(pix.cuda())
     loss = (score_map * gs.cuda()).sum() + (text_embeddings * gt.cuda()).sum()
     loss.backward()
@@ -74,7 +74,7 @@ def test_frozen_context_decoder_gives_the_same_prompt_gradients():
     fx = load_golden("denseclip_tiny_b2_96")
     m = fx["meta"]
     net, cfg = build(fx, train_decoder=False)
-    pix, texts, gs, gt = synth_denseclip_inputs(cfg, m["B"], m["H"], m["input_seed"])
+    pix, texts, gs, gt = synth_denseclip_inputs(cfg, m["B"], m["H"], m["input_seed"], m.get("W"))
     text_embeddings, maps, score_map = net(pix.cuda())
     ((score_map * gs.cuda()).sum() + (text_embeddings * gt.cuda()).sum()).backward()
     assert all(p.grad is None for p in net.context_decoder.parameters())

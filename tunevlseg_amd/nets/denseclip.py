@@ -280,7 +280,17 @@ class DenseCLIP(nn.Module):
         concat = None
         if cfg.score_concat_index == 2:   # fpn3 and the score map share one [B*H*W, C + K] matrix: the GroupNorm writes its first C columns in place
             concat = torch.empty((B * HW, Cc + K), device=dev, dtype=torch.float32)
-        f1, f2, f3, f4 = self._fpn(taps, B, H, W, None if concat is None else concat[:, :Cc])
+        # The FPN taps (chip-filling GEMMs, GroupNorm, unshuffles: no tape, nothing below reads them) on the second stream, beside the context decoder's
+        # launch-bound chain over K rows per sample; joined before the maps are handed out.
+        fpn_side = SideStream(dev) if FPN_SIDE_STREAM else None
+        if fpn_side is not None and fpn_side.on:
+            for t in taps:
+                t.record_stream(fpn_side.side)   # allocated on this stream, last read on that one
+            with fpn_side:
+                f1, f2, f3, f4 = self._fpn(taps, B, H, W, None if concat is None else concat[:, :Cc])
+        else:
+            fpn_side = None
+            f1, f2, f3, f4 = self._fpn(taps, B, H, W, None if concat is None else concat[:, :Cc])
         del taps
         text = ops.OuterAddFn.apply(hip_zeros(B, te.shape[1], dev), te)                         # expand(B, -1, -1)
         diff = self.decode_context(text, xe, B)                                                  # visual_context = [global | pixels] = the projected tokens as they stand
@@ -290,6 +300,8 @@ class DenseCLIP(nn.Module):
         t_hat = ops.L2NormFn.apply(text_embeddings.view(B * K, -1))
         score = ScoreMapFn.apply(v_hat, t_hat.view(B, K, -1), B, HW, 1)
         score_map = score.view(B, H, W, K).permute(0, 3, 1, 2)
+        if fpn_side is not None:
+            fpn_side.join(f1, f2, f3, f4)
         maps = [self._nchw(f1, B, 4 * H, 4 * W), self._nchw(f2, B, 2 * H, 2 * W), self._nchw(f3, B, H, W), self._nchw(f4, B, H // 2, W // 2)]
         i = cfg.score_concat_index
         if concat is not None:
@@ -307,6 +319,7 @@ class DenseCLIP(nn.Module):
 
 
 _ZEROS: dict = {}
+FPN_SIDE_STREAM = __import__("os").environ.get("TVL_DENSECLIP_FPN_STREAM", "1") != "0"   # A/B switch: the FPN taps beside the context decoder
 
 
 def hip_zeros(B: int, Cc: int, device) -> torch.Tensor:
