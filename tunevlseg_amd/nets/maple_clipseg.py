@@ -8,6 +8,9 @@ from .base_clipseg import BaseCLIPSeg
 from .hf_clipseg_wrapper import SegOutput
 
 
+READY_PER_DEPTH = __import__("os").environ.get("TVL_MAPLE_READY_PER_DEPTH", "1") != "0"   # A/B switch (0 = one event behind all depths' projections)
+
+
 class BaseMultimodalCLIPSeg(BaseCLIPSeg):
     # MaPLe's two towers read the shared prompts independently (text: ctx[idx]; vision: proj_idx(ctx[idx])): the text tower may run
     # beside the vision tower on the side stream.  The shared-attention learners hand a cached half from the vision pass to the text
@@ -36,8 +39,15 @@ class BaseMultimodalCLIPSeg(BaseCLIPSeg):
                 # the visual prompts of every depth are projections of parameters (maple_context_learner.py:7-20): computed ahead of the
                 # text tower on the side stream, they (and their weight gradients in the backward) leave the vision tower's critical path
                 learner = self.context_learner
-                vis = [learner.get_visual_context(index=i) for i in range(learner.prompt_depth)] if side.on else None
-                ready = side.mark()
+                # ... one event per depth: the tower's first layer waits for the first projection only, layer i for the i-th (all of them
+                # behind ONE event cost the tower ~0.3 ms of idle chip at the start of every step: 2 launches x 25 us per depth)
+                vis, ready = None, None
+                if side.on:
+                    vis, marks = [], []
+                    for i in range(learner.prompt_depth):
+                        vis.append(learner.get_visual_context(index=i))
+                        marks.append(side.mark())
+                    ready = marks if READY_PER_DEPTH else marks[-1]
             activations = self.get_vision_outputs(pixel_values, vis, ready)
             with side:   # the text tower: enqueued after the vision tower (whose kernels go first when the host is not ahead), replayed before it in the backward
                 conditional_embeddings = self.get_conditional_embeddings(pixel_values.shape[0], input_ids, attention_mask)

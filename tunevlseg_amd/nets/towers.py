@@ -96,7 +96,8 @@ def patch_embeddings(model: CLIPSegBackbone, pixel_values: torch.Tensor) -> torc
 def vision_tower(model: CLIPSegBackbone, pixel_values: torch.Tensor, learner=None, full: bool = False, visual_contexts=None, ready=None):
     """Returns ``(activations at extract_layers, pooled)``; ``pooled`` = visual_projection(post_layernorm(CLS)) when ``full``.
     ``visual_contexts``: the learner's visual prompts of every depth, computed ahead (they depend on parameters only) -- e.g. on the side
-    stream, in which case ``ready`` is the event after them: the tower then launches nothing between its layers but the row overwrite."""
+    stream, in which case ``ready`` is the event after them (or one event per depth, awaited in front of that depth's row overwrite): the tower then
+    launches nothing between its layers but the row overwrite."""
     cfg = model.config
     v = cfg.vision_config
     prep = model.prepared()
@@ -110,7 +111,8 @@ def vision_tower(model: CLIPSegBackbone, pixel_values: torch.Tensor, learner=Non
         depth = learner.prompt_depth
         if visual_contexts is not None:
             if ready is not None:
-                torch.cuda.current_stream(pixel_values.device).wait_event(ready)
+                ready = list(ready) if isinstance(ready, (list, tuple)) else [ready]   # one event per depth, or one behind all of them
+                torch.cuda.current_stream(pixel_values.device).wait_event(ready[0])
                 for c in visual_contexts:
                     c.record_stream(torch.cuda.current_stream(pixel_values.device))
             prompts = visual_contexts[0]
@@ -129,6 +131,8 @@ def vision_tower(model: CLIPSegBackbone, pixel_values: torch.Tensor, learner=Non
         x = ops.encoder_layer(x, prep["vision_layers"][idx - 1], spec, first_rows)
         if prompts is not None and idx < depth:
             if visual_contexts is not None:   # learner.mutate_image_hidden_states with the context computed ahead
+                if ready is not None and idx < len(ready):
+                    torch.cuda.current_stream(pixel_values.device).wait_event(ready[idx])
                 x = ops.RowsOverwriteFn.apply(x, visual_contexts[idx], x.shape[1] - learner.num_context)
             else:
                 x = learner.mutate_image_hidden_states(x, index=idx)
