@@ -27,12 +27,16 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from tunevlseg_amd import hip  # noqa: E402
 
 hip.load()
-SHAPES = [(384, 512, 32), (384, 512, 64), (384, 512, 512), (384, 512, 2048), (64, 64, 512), (384, 1536, 512)]
+SHAPES = [(384, 512, 32), (384, 512, 64), (384, 512, 512), (384, 512, 2048), (64, 64, 512), (384, 1536, 512), (384, 2048, 512), (260, 1536, 512), (260, 512, 2048)]
+COLD = "--cold" in sys.argv   # evict L2 + the 256 MB memory-side cache between launches (a step touches GBs between two uses of a weight)
 if "--sweep" in sys.argv:   # duration against the number of workgroups at (almost) no work per workgroup, and at K = 512
     SHAPES = [(384, n, k) for k in (64, 512) for n in (64, 512, 1536, 4096, 8192)] + [(64, 64, 64), (3072, 512, 64)]
 for M, N, K in SHAPES:
     A, B, C = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda"), torch.empty(M, N, device="cuda")
+    big = torch.empty(160 * 1024 * 1024, device="cuda") if COLD else None   # 640 MB
     for _ in range(30):
+        if COLD:
+            big.fill_(1.0)
         hip.gemm(hip.NT, M, N, K, A, K, B, K, C, N)
     torch.cuda.synchronize()
 x = torch.randn(1024, device="cuda")
