@@ -83,6 +83,29 @@ def test_frozen_context_decoder_gives_the_same_prompt_gradients():
     assert sorted(n for n, p in net.named_parameters() if p.requires_grad) == ["contexts", "gamma"]
 
 
+def test_repeated_steps_without_a_host_sync_are_bit_identical():
+    """Forward + backward eight times on one input, no parameter update, no host sync in between: the FPN maps (second stream, beside the context
+    decoder), score map, text embeddings and both gradients must be the same bits every time -- a buffer reused across streams while it is still
+    read, or a missing stream dependency, shows up as a step that differs (tools/denseclip_soak.py is the long version at 640 x 640)."""
+    fx = load_golden("denseclip_tiny_b2_64x96")
+    m = fx["meta"]
+    net, cfg = build(fx, train_decoder=False)
+    pix, texts, gs, gt = synth_denseclip_inputs(cfg, m["B"], m["H"], m["input_seed"], m.get("W"))
+    pix, gs, gt = pix.cuda(), gs.cuda(), gt.cuda()
+    sums = torch.zeros(8, 8, device="cuda", dtype=torch.float64)
+    for i in range(8):
+        net.contexts.grad = None
+        net.gamma.grad = None
+        te, maps, score = net(pix)
+        ((score * gs).sum() + (te * gt).sum()).backward()
+        sums[i] = torch.stack([t.detach().double().abs().sum() for t in (*maps, score, te, net.contexts.grad, net.gamma.grad)])
+        del te, maps, score
+    s = sums.cpu()
+    assert torch.isfinite(s).all()
+    for i in range(1, 8):
+        assert torch.equal(s[i], s[0]), (i, s[i].tolist(), s[0].tolist())
+
+
 def test_state_dict_keys_are_the_reference_segmentors():
     fx = load_golden("denseclip_tiny_b2_96")
     net, cfg = build(fx, train_decoder=False)
