@@ -355,8 +355,10 @@ def main():
             opt.step()
             return loss
 
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()   # world > 1, or a one-rank RCCL group (TVL_DIST_SINGLE_RANK_GROUP=1)
+
     def barrier():
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -369,7 +371,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -509,7 +511,7 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.workload == "vpt":
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps32, args.cpu_steps4)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         torch.distributed.destroy_process_group()
 
 

@@ -42,9 +42,11 @@ def main(out_dir: str) -> None:
         opt.step()
     torch.cuda.synchronize()
     torch.save({"params": {k: p.detach().cpu() for k, p in module.named_parameters() if p.requires_grad},
-                "launched_in_backward": opt.exchange.launched_in_backward}, Path(out_dir) / f"world{world}_rank{rank}.pt")
-    if world > 1:
-        torch.distributed.barrier()
+                "launched_in_backward": opt.exchange.launched_in_backward,
+                "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None},
+               Path(out_dir) / f"world{world}_rank{rank}{os.environ.get('TVL_WORKER_TAG', '')}.pt")
+    if torch.distributed.is_initialized():
+        tdist.barrier()
         torch.distributed.destroy_process_group()
 
 

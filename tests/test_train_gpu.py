@@ -216,6 +216,31 @@ def test_two_rank_step_on_hip_path_equals_global_batch_step(tmp_path):
         assert err <= 2e-3 * 2e-2, f"{k}: {err:.3e}"  # Adam's first steps move every entry by ~lr: compare against lr (as above)
 
 
+def test_rccl_group_of_one_rank_runs_the_exchange_and_changes_nothing(tmp_path):
+    """The RCCL half of the N > 1 path on the one GPU of this box: ONE process, a process group of a single rank on backend "nccl"
+    (TVL_DIST_SINGLE_RANK_GROUP=1): the bucketed all-reduces are enqueued asynchronously from the backward's post-accumulate hooks -- on gradients
+    that the side stream produced, too (MaPLe's text tower) --, waited for in the optimiser step, followed by the fused AdamW and a barrier.  A sum
+    over one rank is the identity: the parameters after two steps must equal the plain single-process run bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    runs = {}
+    for tag, extra in (("", {}), ("_rccl1", {"TVL_DIST_SINGLE_RANK_GROUP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29531"})):
+        env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", PYTHONPATH=str(root), TVL_WORKER_TAG=tag, **extra)
+        env.pop("TVL_DIST_BACKEND", None)
+        r = subprocess.run([sys.executable, str(root / "tests" / "ddp_worker.py"), str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        runs[tag] = torch.load(tmp_path / f"world1_rank0{tag}.pt")
+    plain, rccl = runs[""], runs["_rccl1"]
+    assert plain["backend"] is None and rccl["backend"] == "nccl"
+    assert rccl["launched_in_backward"] >= 1 and plain["launched_in_backward"] == 0
+    for k in plain["params"]:
+        assert torch.equal(plain["params"][k], rccl["params"][k]), k
+
+
 def test_train_entry_point_fits_from_a_directory_in_the_reference_layout(tmp_path, monkeypatch):
     """``python -m tunevlseg_amd.train experiment=...`` end to end: a config tree with the reference's structure whose ``data`` node is
     the reference's datamodule schema (``configs/data/image_text_mask.yaml``) over a toy dataset in the reference's wire format

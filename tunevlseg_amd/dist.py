@@ -22,7 +22,10 @@ def env_world() -> tuple[int, int, int]:
 def init_distributed(device_type: str = "cuda") -> tuple[int, int, int]:
     """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    # TVL_DIST_SINGLE_RANK_GROUP=1: a process group of ONE rank (RCCL on one GPU): the collectives of the N > 1 path -- async all-reduce enqueued from
+    # the backward's hooks, waits, barrier -- run for real, as identities (tests/test_train_gpu.py; the only RCCL a one-GPU box can exercise)
+    single = world == 1 and os.environ.get("TVL_DIST_SINGLE_RANK_GROUP") == "1"
+    if (world > 1 or single) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # RCCL ("nccl" on ROCm) for GPUs; TVL_DIST_BACKEND=gloo lets the N>1 code path be rehearsed with several ranks on ONE
@@ -42,6 +45,11 @@ def init_distributed(device_type: str = "cuda") -> tuple[int, int, int]:
 
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def group_active() -> bool:
+    """A process group exists (also one of a single rank, whose collectives are identities): the exchange code runs."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def per_device_batch_size(global_batch_size: int, world: int) -> int:
@@ -86,7 +94,7 @@ class FlatParams:
     def allreduce_grads(self) -> float:
         """SUM all-reduce of the flat gradient; returns the scale (1/world) the optimiser must apply."""
         w = world_size()
-        if w > 1:
+        if group_active():
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
         return 1.0 / w
 
@@ -130,7 +138,7 @@ class GradExchange:
         self._launched[b] = True
 
     def _on_grad(self, i: int) -> None:
-        if not self.armed or world_size() == 1:
+        if not self.armed or not group_active():
             return
         b = self.bucket_of[i]
         self._arrived[b] += 1
@@ -140,7 +148,7 @@ class GradExchange:
 
     def finish(self) -> float:
         w = world_size()
-        if w > 1:
+        if group_active():
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
                     self._launch(b)
@@ -154,7 +162,7 @@ class GradExchange:
 
 def reduce_sums(values: list[float]) -> list[float]:
     """SUM of a few python floats over the ranks (validation loss totals, stop flags); identity for world size 1."""
-    if world_size() == 1:
+    if not group_active():
         return list(values)
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor(values, dtype=torch.float64, device=dev)
@@ -163,13 +171,13 @@ def reduce_sums(values: list[float]) -> list[float]:
 
 
 def barrier() -> None:
-    if world_size() > 1:
+    if group_active():
         dist.barrier()
 
 
 def allreduce_counts(counts: torch.Tensor) -> torch.Tensor:
     """Integer confusion counts: exact SUM across ranks (torchmetrics JaccardIndex state sync)."""
-    if world_size() > 1:
+    if group_active():
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
 
@@ -177,7 +185,7 @@ def allreduce_counts(counts: torch.Tensor) -> torch.Tensor:
 def allgather_cat(values: torch.Tensor) -> torch.Tensor:
     """Per-sample values gathered over ranks (torchmetrics Dice(average='samples') 'cat' state sync)."""
     w = world_size()
-    if w == 1:
+    if not group_active():
         return values
     out = [torch.empty_like(values) for _ in range(w)]
     dist.all_gather(out, values.contiguous())
