@@ -27,6 +27,11 @@ def main():
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     hip.load()
+    if os.environ.get("TVL_DIST_SINGLE_RANK_GROUP") == "1":   # the N > 1 exchange code on a one-rank RCCL group
+        from tunevlseg_amd import dist as tdist
+
+        os.environ.setdefault("WORLD_SIZE", "1")
+        tdist.init_distributed("cuda")
     cris, maple = args.workload == "cris", args.workload == "maple"
     module, opt = bench.build_cris_module(device) if cris else (bench.build_maple_module(device) if maple else bench.build_module(device))
     batch = bench.make_batch(args.batch, 416 if cris else 352, 100, device, pad_id=0 if cris else 1)
