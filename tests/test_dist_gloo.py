@@ -238,3 +238,38 @@ def test_trainer_two_ranks_take_identical_decisions(tmp_path):
     assert training0 and training1 and not evalmode0 and not evalmode1
     # pooled loss = (2 * (w-1)^2 + 4 * (w-5)^2) / 6 at the restored best weights
     assert abs(tl0 - (2 * (w0 - 1) ** 2 + 4 * (w0 - 5) ** 2) / 6) < 1e-5  # the losses are fp32
+
+
+def _one_rank_worker(rank, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", TVL_DIST_SINGLE_RANK_GROUP="1")
+    torch.set_num_threads(2)
+    assert not tdist.group_active()
+    tdist.init_distributed("cpu")
+    assert tdist.group_active() and tdist.world_size() == 1 and dist.get_backend() == "gloo"
+    g = torch.Generator().manual_seed(5)
+    a = torch.nn.Parameter(torch.randn(300, generator=g))
+    b = torch.nn.Parameter(torch.randn(40, 20, generator=g))
+    flat = tdist.FlatParams([a, b])
+    ex = tdist.GradExchange(flat, bucket_bytes=1024)   # two buckets
+    x = torch.randn(20, generator=g)
+    ((a * 2.0).sum() + (b @ x).square().sum()).backward()
+    scale = ex.finish()
+    want_a, want_b = torch.full((300,), 2.0), 2.0 * (b.detach() @ x)[:, None] * x[None, :]
+    tdist.barrier()
+    q.put((scale, ex.launched_in_backward, torch.equal(a.grad, want_a), torch.allclose(b.grad, want_b, rtol=1e-6, atol=1e-6),
+           tdist.reduce_sums([1.5, 2.5]), tdist.allgather_cat(torch.arange(3.0)).tolist()))
+    dist.destroy_process_group()
+
+
+def test_group_of_one_rank_runs_the_exchange_as_an_identity():
+    """TVL_DIST_SINGLE_RANK_GROUP=1: a process group of a single rank (here gloo; on a GPU box RCCL, tests/test_train_gpu.py) -- the bucketed
+    all-reduces are launched from the backward's hooks and waited for, barrier / metric syncs run, and nothing changes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(0, _free_port(), q))
+    p.start()
+    scale, launched, a_ok, b_ok, sums, gathered = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert scale == 1.0 and launched == 2 and a_ok and b_ok
+    assert sums == [1.5, 2.5] and gathered == [0.0, 1.0, 2.0]
